@@ -1,0 +1,149 @@
+/*
+ * include/cstr_rl_hip.h -- C ABI of libcstr_rl_hip.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for the hot path of CHAINNEVERLIU/Pytorch-RL-EnhancedStableBaselines named by
+ * BASELINE.json:north_star: core.{SAC,TD3,MADDPG}("MlpPolicy", env).learn() on the two-series
+ * CSTR environment. The reference is 100 % Python and has no FFI of its own, so
+ * each entry point below names the Python statements it replaces (file:line relative to the
+ * reference root). INTEGRATION.md shows the ctypes stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - plain C: raw DEVICE pointers (HBM) + sizes; no torch / C++ types. `stream` is a hipStream_t
+ *     passed as void* (torch: torch.cuda.current_stream().cuda_stream).
+ *   - every function only enqueues work on `stream`: no allocation, no host sync, graph-capturable.
+ *   - return value: 0 = ok; < 0 = cstr error (CSTR_E_*); > 0 = hipError_t of the failed launch.
+ *   - all floating point is IEEE fp32, compiled with -ffp-contract=off; fused ops are explicit.
+ *   - control words that change every call (ring position, Adam step) live in HBM (`*_ctl`), so a
+ *     captured hipGraph replays correctly; the last workgroup of a launch advances them.
+ */
+#ifndef CSTR_RL_HIP_H
+#define CSTR_RL_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CSTR_ABI_VERSION 1
+
+#define CSTR_OK 0
+#define CSTR_E_BADARG (-1)      /* null pointer / non-positive size / misaligned buffer */
+#define CSTR_E_UNSUPPORTED (-2) /* obs_dim not in {4, 8}, act_dim != 2, batch too large, 64-bit index range */
+
+#define CSTR_INTEGRATOR_EULER 0 /* the reference: forward Euler, dt = 0.1 (twoseriescstr.py:493-496) */
+#define CSTR_INTEGRATOR_RK4 1   /* north_star's ask; no reference counterpart */
+
+typedef void *cstr_stream_t; /* hipStream_t */
+
+/* f32-folded coefficients of TwoSeriesCSTREnv (twoseriescstr.py:37-61, :99, :103-106), folded with
+ * NumPy >= 2 (NEP 50) semantics: Python-float products are formed in double, then rounded to f32
+ * at their first contact with an f32 operand. Passed BY VALUE to the kernels (kernarg -> SGPRs). */
+typedef struct cstr_coef {
+    float q_v1, q_v2, cf, tf, tcf, k0, neg_e, r_gas, hk, rho_cp, cool1, cool2, neg_ua1, neg_ua2, rho_c, c_pc, dt;
+    float s_lo[4], s_hi[4], s_span[4]; /* raw_state_low/high, high-low    (:56-57) */
+    float a_lo[2], a_hi[2], a_span[2]; /* raw_action_low/high, high-low   (:60-61) */
+    float target_c2, conc_span;        /* target_C2, max_conc - min_conc  (:103-106, :290) */
+    int32_t max_steps;                 /* 400 (:99) */
+} cstr_coef_t;
+
+/* Replay ring in HBM, field-level SoA with the reference's array shapes (core/common/buffers.py:212-234):
+ * observations/next_observations [rows][n_envs][obs_dim], actions [rows][n_envs][act_dim],
+ * rewards/dones/timeouts [rows][n_envs]; all f32; obs rows 16-byte aligned. */
+typedef struct cstr_ring {
+    float *obs, *next_obs, *act, *rew, *done, *timeout;
+    int64_t rows, n_envs;
+    int32_t obs_dim, act_dim;
+} cstr_ring_t;
+
+/* ring_ctl: int64[4] in HBM = { pos, full, ticket, adds }  (buffers.py:101-104 `pos`, `full`) */
+#define CSTR_RING_CTL_WORDS 4
+/* adam_ctl: int64[2] in HBM = { step, ticket } (torch.optim.Adam state["step"]) */
+#define CSTR_ADAM_CTL_WORDS 2
+/* mt_state: uint32[625] in HBM = { key[624], pos } (numpy legacy RandomState) */
+#define CSTR_MT_STATE_WORDS 625
+/* pcg_state: uint64[4] per env in HBM = { state_hi, state_lo, inc_hi, inc_lo } (numpy PCG64) */
+#define CSTR_PCG_STATE_WORDS 4
+#define CSTR_MAX_SAMPLE_BATCH 16384
+
+int cstr_abi_version(void);
+const char *cstr_error_string(int code);
+
+/* Host helper: fold the class constants of TwoSeriesCSTREnv (twoseriescstr.py:37-61) and the ctor
+ * arguments default_target / min_concentration / max_concentration (:63-68) into f32 coefficients. */
+void cstr_default_coef(cstr_coef_t *coef, double target_c2, double min_conc, double max_conc, int32_t max_steps);
+
+/* VecEnv.step for N CSTR envs in one launch. Replaces the Python loop of
+ * DummyVecEnv.step_wait (core/common/vec_env/dummy_vec_env.py:56-73) over
+ * TwoSeriesCSTREnv.step/_dynamics/compute_reward (twoseriescstr.py:394-503, :271-392).
+ *   obs        [N][obs_dim] in : current observations (obs_dim 4: normalised state; 8: [normalised | raw])
+ *   act        [N][2]       in : env actions (normalised, clipped to [-1,1] inside, :399)
+ *   step_count [N]          i/o: TwoSeriesCSTREnv.current_step
+ *   reset_obs  [N][obs_dim] in : observation an env restarts from when it finishes this step
+ *   next_obs   [N][obs_dim] out: true next observation (= infos[i]["terminal_observation"] when done)
+ *   obs_after  [N][obs_dim] out: what VecEnv.step returns (reset obs when done); may alias obs
+ *   reward/done/timeout [N] out: f32; timeout = infos[i]["TimeLimit.truncated"] */
+int cstr_vec_step_f32(const cstr_coef_t *coef, int integrator, int obs_dim, const float *obs, const float *act,
+                      int32_t *step_count, const float *reset_obs, float *next_obs, float *obs_after, float *reward,
+                      float *done, float *timeout, int64_t n_envs, cstr_stream_t stream);
+
+/* TwoSeriesCSTREnv.reset draws for envs with mask[i] != 0 (mask NULL = all): generate_initial_state
+ * with init_mode="random" (twoseriescstr.py:187-224, :267) from per-env numpy-PCG64 states that the
+ * host seeds exactly like gymnasium.utils.seeding.np_random(seed + i) (:162). */
+int cstr_reset_draw_f32(uint64_t *pcg_state, const uint8_t *mask, int obs_dim, float *obs_out, int64_t n_envs,
+                        cstr_stream_t stream);
+
+/* ReplayBuffer.add (core/common/buffers.py:247-283) at the device-resident ring position; the last
+ * workgroup advances ring_ctl (pos, full). */
+int cstr_replay_add_f32(const cstr_ring_t *ring, int64_t *ring_ctl, const float *obs, const float *next_obs,
+                        const float *act, const float *rew, const float *done, const float *timeout,
+                        cstr_stream_t stream);
+
+/* One fused collect step = _sample_action's scaling chain + VecEnv.step + _store_transition + ReplayBuffer.add
+ * (core/common/off_policy_algorithm.py:396-406, :564, :477-496; buffers.py:247-283) in ONE pass over the envs:
+ * reads state + policy output once, writes the ring row once, updates the env state in place.
+ *   env_obs    [N][obs_dim] i/o: VecEnv state (_last_obs); replaced by the post-reset observation
+ *   policy_out [N][2]       in : actor output; squashed != 0: tanh output in [-1,1] (predict() then unscales it,
+ *                                core/common/policies.py:375); squashed == 0: an action already in [low, high]
+ *   act_low/act_high [2]    in : HOST pointers, bounds of the algorithm-facing action space
+ *   noise      [N][2] or NULL  : added to the scaled action, then clip [-1,1] (off_policy_algorithm.py:401-402)
+ *   reset_obs  [N][obs_dim] or NULL, pcg_state [N][4] or NULL: reset source (exactly one non-NULL)
+ *   reward_out/done_out [N] or NULL: copies for episode statistics */
+int cstr_collect_step_f32(const cstr_coef_t *coef, int integrator, const cstr_ring_t *ring, int64_t *ring_ctl,
+                          float *env_obs, int32_t *step_count, const float *policy_out, int squashed,
+                          const float *act_low, const float *act_high, const float *noise, const float *reset_obs,
+                          uint64_t *pcg_state, float *reward_out, float *done_out, cstr_stream_t stream);
+
+/* np.random.seed(seed) for the device-resident legacy MT19937 state (core/common/utils.py:46;
+ * twoseriescstr.py:164 reseeds the same global stream). */
+int cstr_mt19937_seed(uint32_t *mt_state, uint32_t seed, cstr_stream_t stream);
+
+/* ReplayBuffer.sample (core/common/buffers.py:106-115, :285-325): upper = rows if full else pos;
+ * batch_inds = np.random.randint(0, upper, batch); env_indices = np.random.randint(0, n_envs, batch)
+ * (legacy MT19937, masked rejection, bit-exact) fused with the gather of the five fields.
+ *   out_obs [B][obs_dim], out_act [B][act_dim], out_next_obs [B][obs_dim], out_done [B] (= dones*(1-timeouts)),
+ *   out_rew [B]; out_row_idx/out_env_idx int64 [B] or NULL. */
+int cstr_replay_sample_mt19937_f32(const cstr_ring_t *ring, const int64_t *ring_ctl, uint32_t *mt_state, int64_t batch,
+                                   float *out_obs, float *out_act, float *out_next_obs, float *out_done,
+                                   float *out_rew, int64_t *out_row_idx, int64_t *out_env_idx, cstr_stream_t stream);
+
+/* Target-Q: SAC core/sac/sac.py:250-254 (logp, ent_coef non-NULL), TD3 core/td3/td3.py:174-176 (both NULL):
+ * out = rew + (1 - done) * gamma * (min(q1, q2) - ent_coef[0] * logp). ent_coef is a DEVICE scalar. */
+int cstr_td_target_min_f32(const float *q1, const float *q2, const float *logp, const float *rew, const float *done,
+                           const float *ent_coef, float gamma, float *out, int64_t n, cstr_stream_t stream);
+
+/* polyak_update over one flat parameter arena (core/common/utils.py:457-481):
+ * target = fma(tau, param, target * (1 - tau)), bit-identical to torch's mul_ + add(alpha=). */
+int cstr_polyak_f32(const float *param, float *target, double tau, int64_t n, cstr_stream_t stream);
+
+/* torch.optim.Adam step (defaults of core/common/policies.py:96-117) over one flat arena; the step
+ * counter lives in adam_ctl and is advanced by the last workgroup. lr is a DEVICE scalar (f64) so
+ * _update_learning_rate (core/common/base_class.py:303-317) needs no re-capture. */
+int cstr_adam_f32(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t *adam_ctl,
+                  const double *lr, double beta1, double beta2, double eps, float grad_scale, int64_t n,
+                  cstr_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CSTR_RL_HIP_H */

@@ -1,0 +1,87 @@
+"""ctypes binding of libcstr_rl_hip.so (the C ABI declared in include/cstr_rl_hip.h).
+
+The library is the product's only implementation of the env / replay / element-wise hot path:
+there is NO CPU or PyTorch fallback. `lib()` raises if the shared object is missing or a symbol
+declared in the header is not exported.
+"""
+import ctypes as C
+import os
+from typing import Optional
+
+_PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(_PKG_ROOT, "libcstr_rl_hip.so")
+
+INTEGRATORS = {"euler": 0, "rk4": 1}
+RING_CTL_WORDS, ADAM_CTL_WORDS, MT_STATE_WORDS, PCG_STATE_WORDS, MAX_SAMPLE_BATCH = 4, 2, 625, 4, 16384
+
+SYMBOLS = (
+    "cstr_abi_version", "cstr_error_string", "cstr_default_coef", "cstr_vec_step_f32", "cstr_reset_draw_f32",
+    "cstr_replay_add_f32", "cstr_collect_step_f32", "cstr_mt19937_seed", "cstr_replay_sample_mt19937_f32",
+    "cstr_td_target_min_f32", "cstr_polyak_f32", "cstr_adam_f32",
+)
+
+
+class Coef(C.Structure):
+    """cstr_coef_t"""
+    _fields_ = [(n, C.c_float) for n in (
+        "q_v1", "q_v2", "cf", "tf", "tcf", "k0", "neg_e", "r_gas", "hk", "rho_cp", "cool1", "cool2", "neg_ua1",
+        "neg_ua2", "rho_c", "c_pc", "dt")] + [
+        ("s_lo", C.c_float * 4), ("s_hi", C.c_float * 4), ("s_span", C.c_float * 4),
+        ("a_lo", C.c_float * 2), ("a_hi", C.c_float * 2), ("a_span", C.c_float * 2),
+        ("target_c2", C.c_float), ("conc_span", C.c_float), ("max_steps", C.c_int32)]
+
+
+class Ring(C.Structure):
+    """cstr_ring_t"""
+    _fields_ = [(n, C.c_void_p) for n in ("obs", "next_obs", "act", "rew", "done", "timeout")] + [
+        ("rows", C.c_int64), ("n_envs", C.c_int64), ("obs_dim", C.c_int32), ("act_dim", C.c_int32)]
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+_lib: Optional[C.CDLL] = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NativeError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or `make -C pytorch-rl-enhancedstablebaselines_amd/csrc`). This stack has no CPU/PyTorch fallback.")
+        l = C.CDLL(LIB_PATH)
+        missing = [s for s in SYMBOLS if not hasattr(l, s)]
+        if missing:
+            raise NativeError(f"{LIB_PATH} does not export {missing}")
+        l.cstr_error_string.restype = C.c_char_p
+        l.cstr_default_coef.restype = None
+        if l.cstr_abi_version() != 1:
+            raise NativeError("libcstr_rl_hip.so ABI version mismatch")
+        _lib = l
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    """Error convention of the ABI: 0 ok, <0 cstr error, >0 hipError_t -> RuntimeError."""
+    if rc != 0:
+        raise NativeError(f"{what} failed: {lib().cstr_error_string(C.c_int(rc)).decode()} (code {rc})")
+
+
+def default_coef(target_c2=0.20, min_conc=0.05, max_conc=0.45, max_steps=400) -> Coef:
+    c = Coef()
+    lib().cstr_default_coef(C.byref(c), C.c_double(target_c2), C.c_double(min_conc), C.c_double(max_conc),
+                            C.c_int32(max_steps))
+    return c
+
+
+def ptr(t) -> C.c_void_p:
+    """Raw device pointer of a torch tensor (None -> NULL)."""
+    return C.c_void_p(None if t is None else t.data_ptr())
+
+
+def stream_ptr() -> C.c_void_p:
+    import torch
+
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,150 @@
+"""Torch-tensor front end of the C ABI (include/cstr_rl_hip.h).
+
+Every wrapper validates shape / dtype / device / contiguity on the host before the launch (a
+mis-shaped operand must never reach a hand-written kernel), passes raw device pointers and the
+current HIP stream, and raises on a non-zero return code. Nothing here computes on the CPU.
+"""
+import ctypes as C
+from typing import Optional
+
+import torch as th
+
+from core import _native as nv
+from core._native import INTEGRATORS, check, ptr, stream_ptr
+
+
+def _chk(t: th.Tensor, name: str, shape, dtype) -> th.Tensor:
+    if not isinstance(t, th.Tensor):
+        raise TypeError(f"{name}: expected a torch.Tensor, got {type(t)}")
+    if not t.is_cuda:
+        raise ValueError(f"{name}: must live in HBM (device tensor); got device {t.device}. No CPU fallback exists.")
+    if t.dtype != dtype:
+        raise ValueError(f"{name}: dtype {t.dtype}, expected {dtype}")
+    if tuple(t.shape) != tuple(shape):
+        raise ValueError(f"{name}: shape {tuple(t.shape)}, expected {tuple(shape)}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name}: must be contiguous")
+    return t
+
+
+def _opt(t: Optional[th.Tensor], name, shape, dtype):
+    return None if t is None else _chk(t, name, shape, dtype)
+
+
+class DeviceRing:
+    """cstr_ring_t + ring_ctl over torch tensors (HBM). Field arrays have the reference's shapes
+    (core/common/buffers.py:212-234): [rows, n_envs, D] / [rows, n_envs, A] / [rows, n_envs]."""
+
+    def __init__(self, rows: int, n_envs: int, obs_dim: int, act_dim: int, device):
+        if obs_dim not in (4, 8) or act_dim != 2:
+            raise ValueError(f"DeviceRing supports obs_dim 4|8 and act_dim 2 (CSTR), got {obs_dim}/{act_dim}")
+        z = lambda *s: th.zeros(*s, dtype=th.float32, device=device)  # noqa: E731
+        self.observations, self.next_observations = z(rows, n_envs, obs_dim), z(rows, n_envs, obs_dim)
+        self.actions = z(rows, n_envs, act_dim)
+        self.rewards, self.dones, self.timeouts = z(rows, n_envs), z(rows, n_envs), z(rows, n_envs)
+        self.ctl = th.zeros(nv.RING_CTL_WORDS, dtype=th.int64, device=device)  # {pos, full, ticket, adds}
+        self.rows, self.n_envs, self.obs_dim, self.act_dim = rows, n_envs, obs_dim, act_dim
+        self.c = nv.Ring(self.observations.data_ptr(), self.next_observations.data_ptr(), self.actions.data_ptr(),
+                         self.rewards.data_ptr(), self.dones.data_ptr(), self.timeouts.data_ptr(), rows, n_envs,
+                         obs_dim, act_dim)
+
+
+def vec_step(coef, integrator: str, obs, act, step_count, reset_obs, next_obs, obs_after, reward, done, timeout):
+    n, d = obs.shape
+    _chk(obs, "obs", (n, d), th.float32), _chk(act, "act", (n, 2), th.float32)
+    _chk(step_count, "step_count", (n,), th.int32), _chk(reset_obs, "reset_obs", (n, d), th.float32)
+    _chk(next_obs, "next_obs", (n, d), th.float32), _chk(obs_after, "obs_after", (n, d), th.float32)
+    for t, nm in ((reward, "reward"), (done, "done"), (timeout, "timeout")):
+        _chk(t, nm, (n,), th.float32)
+    check(nv.lib().cstr_vec_step_f32(C.byref(coef), C.c_int(INTEGRATORS[integrator]), C.c_int(d), ptr(obs), ptr(act),
+                                     ptr(step_count), ptr(reset_obs), ptr(next_obs), ptr(obs_after), ptr(reward),
+                                     ptr(done), ptr(timeout), C.c_int64(n), stream_ptr()), "cstr_vec_step_f32")
+
+
+def reset_draw(pcg_state, mask, obs_out):
+    n, d = obs_out.shape
+    _chk(pcg_state, "pcg_state", (n, nv.PCG_STATE_WORDS), th.int64), _chk(obs_out, "obs_out", (n, d), th.float32)
+    _opt(mask, "mask", (n,), th.uint8)
+    check(nv.lib().cstr_reset_draw_f32(ptr(pcg_state), ptr(mask), C.c_int(d), ptr(obs_out), C.c_int64(n), stream_ptr()),
+          "cstr_reset_draw_f32")
+
+
+def replay_add(ring: DeviceRing, obs, next_obs, act, rew, done, timeout):
+    n, d, a = ring.n_envs, ring.obs_dim, ring.act_dim
+    _chk(obs, "obs", (n, d), th.float32), _chk(next_obs, "next_obs", (n, d), th.float32), _chk(act, "act", (n, a), th.float32)
+    for t, nm in ((rew, "rew"), (done, "done"), (timeout, "timeout")):
+        _chk(t, nm, (n,), th.float32)
+    check(nv.lib().cstr_replay_add_f32(C.byref(ring.c), ptr(ring.ctl), ptr(obs), ptr(next_obs), ptr(act), ptr(rew),
+                                       ptr(done), ptr(timeout), stream_ptr()), "cstr_replay_add_f32")
+
+
+def collect_step(coef, integrator: str, ring: DeviceRing, env_obs, step_count, policy_out, squashed: bool, act_low,
+                 act_high, noise=None, reset_obs=None, pcg_state=None, reward_out=None, done_out=None):
+    n, d = ring.n_envs, ring.obs_dim
+    _chk(env_obs, "env_obs", (n, d), th.float32), _chk(step_count, "step_count", (n,), th.int32)
+    _chk(policy_out, "policy_out", (n, 2), th.float32)
+    _opt(noise, "noise", (n, 2), th.float32), _opt(reset_obs, "reset_obs", (n, d), th.float32)
+    _opt(pcg_state, "pcg_state", (n, nv.PCG_STATE_WORDS), th.int64)
+    _opt(reward_out, "reward_out", (n,), th.float32), _opt(done_out, "done_out", (n,), th.float32)
+    if (reset_obs is None) == (pcg_state is None):
+        raise ValueError("collect_step needs exactly one reset source: reset_obs or pcg_state")
+    lo = (C.c_float * 2)(float(act_low[0]), float(act_low[1]))
+    hi = (C.c_float * 2)(float(act_high[0]), float(act_high[1]))
+    check(nv.lib().cstr_collect_step_f32(C.byref(coef), C.c_int(INTEGRATORS[integrator]), C.byref(ring.c), ptr(ring.ctl),
+                                         ptr(env_obs), ptr(step_count), ptr(policy_out), C.c_int(int(squashed)), lo, hi,
+                                         ptr(noise), ptr(reset_obs), ptr(pcg_state), ptr(reward_out), ptr(done_out),
+                                         stream_ptr()), "cstr_collect_step_f32")
+
+
+def mt19937_seed(mt_state, seed: int):
+    _chk(mt_state, "mt_state", (nv.MT_STATE_WORDS,), th.int32)
+    check(nv.lib().cstr_mt19937_seed(ptr(mt_state), C.c_uint32(seed & 0xFFFFFFFF), stream_ptr()), "cstr_mt19937_seed")
+
+
+def replay_sample(ring: DeviceRing, mt_state, batch: int, out_obs, out_act, out_next_obs, out_done, out_rew,
+                  out_row_idx=None, out_env_idx=None):
+    d, a = ring.obs_dim, ring.act_dim
+    _chk(mt_state, "mt_state", (nv.MT_STATE_WORDS,), th.int32)
+    _chk(out_obs, "out_obs", (batch, d), th.float32), _chk(out_next_obs, "out_next_obs", (batch, d), th.float32)
+    _chk(out_act, "out_act", (batch, a), th.float32)
+    _chk(out_done, "out_done", (batch, 1), th.float32), _chk(out_rew, "out_rew", (batch, 1), th.float32)
+    _opt(out_row_idx, "out_row_idx", (batch,), th.int64), _opt(out_env_idx, "out_env_idx", (batch,), th.int64)
+    if not 0 < batch <= nv.MAX_SAMPLE_BATCH:
+        raise ValueError(f"batch_size must be in [1, {nv.MAX_SAMPLE_BATCH}], got {batch}")
+    check(nv.lib().cstr_replay_sample_mt19937_f32(C.byref(ring.c), ptr(ring.ctl), ptr(mt_state), C.c_int64(batch),
+                                                  ptr(out_obs), ptr(out_act), ptr(out_next_obs), ptr(out_done),
+                                                  ptr(out_rew), ptr(out_row_idx), ptr(out_env_idx), stream_ptr()),
+          "cstr_replay_sample_mt19937_f32")
+
+
+def td_target_min(q1, q2, logp, rew, done, ent_coef, gamma: float, out):
+    n = q1.numel()
+    for t, nm in ((q1, "q1"), (q2, "q2"), (rew, "rew"), (done, "done"), (out, "out")):
+        if t.numel() != n:
+            raise ValueError(f"{nm}: numel {t.numel()} != {n}")
+        _chk(t, nm, t.shape, th.float32)
+    if (logp is None) != (ent_coef is None):
+        raise ValueError("logp and ent_coef go together (SAC) or are both None (TD3)")
+    if logp is not None:
+        _chk(logp, "logp", logp.shape, th.float32), _chk(ent_coef, "ent_coef", ent_coef.shape, th.float32)
+        if logp.numel() != n or ent_coef.numel() != 1:
+            raise ValueError("logp must have n elements and ent_coef exactly one")
+    check(nv.lib().cstr_td_target_min_f32(ptr(q1), ptr(q2), ptr(logp), ptr(rew), ptr(done), ptr(ent_coef),
+                                          C.c_float(gamma), ptr(out), C.c_int64(n), stream_ptr()), "cstr_td_target_min_f32")
+
+
+def polyak(param_flat, target_flat, tau: float):
+    n = param_flat.numel()
+    _chk(param_flat, "param_flat", (n,), th.float32), _chk(target_flat, "target_flat", (n,), th.float32)
+    check(nv.lib().cstr_polyak_f32(ptr(param_flat), ptr(target_flat), C.c_double(tau), C.c_int64(n), stream_ptr()),
+          "cstr_polyak_f32")
+
+
+def adam(param, grad, exp_avg, exp_avg_sq, adam_ctl, lr_dev, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0):
+    n = param.numel()
+    for t, nm in ((param, "param"), (grad, "grad"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq")):
+        _chk(t, nm, (n,), th.float32)
+    _chk(adam_ctl, "adam_ctl", (nv.ADAM_CTL_WORDS,), th.int64), _chk(lr_dev, "lr", (1,), th.float64)
+    check(nv.lib().cstr_adam_f32(ptr(param), ptr(grad), ptr(exp_avg), ptr(exp_avg_sq), ptr(adam_ctl), ptr(lr_dev),
+                                 C.c_double(beta1), C.c_double(beta2), C.c_double(eps), C.c_float(grad_scale),
+                                 C.c_int64(n), stream_ptr()), "cstr_adam_f32")

@@ -1,0 +1,63 @@
+// cstr_device.h -- shared host/device helpers of libcstr_rl_hip (internal, not part of the ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/cstr_rl_hip.h"
+
+static inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+static inline bool aligned8(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 7u) == 0; }
+
+// Launch shape for one-lane-per-env streaming kernels. MI355X: 256 CUs in 8 XCDs. Small N (the 4096-env
+// training case) is latency-bound: one wave per workgroup spreads the launch over as many CUs/XCDs as
+// there are waves. Large N streams: 256-thread workgroups, capped at 8 per CU, grid-stride for the rest.
+static inline void env_launch_shape(int64_t n, int &block, int &grid)
+{
+    if (n <= 65536) {
+        block = 64;
+        grid = (int)((n + 63) / 64);
+    } else {
+        block = 256;
+        int64_t g = (n + 255) / 256;
+        grid = (int)(g < 2048 ? g : 2048);
+    }
+}
+
+// Flat element-wise kernels over float4: same rule.
+static inline void flat_launch_shape(int64_t n_vec, int &block, int &grid)
+{
+    block = 256;
+    int64_t g = (n_vec + 255) / 256;
+    if (g < 1) g = 1;
+    grid = (int)(g < 2048 ? g : 2048);
+}
+
+#ifdef __HIPCC__
+// "Last workgroup out" ticket: every workgroup has finished READING the control words it needs before it
+// takes a ticket (the barrier orders its waves' loads, whose values were already consumed for addressing),
+// so the workgroup that draws gridDim.x-1 may advance them. No data is handed between workgroups inside the
+// launch -- the next kernel on the stream sees the update through the kernel boundary.
+__device__ __forceinline__ bool last_block_ticket(unsigned long long *ticket)
+{
+    __shared__ int is_last;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long t = atomicAdd(ticket, 1ULL);
+        is_last = (t == (unsigned long long)gridDim.x - 1ULL);
+        if (is_last) *ticket = 0ULL;  // self-reset for the next launch
+    }
+    __syncthreads();
+    return is_last != 0;
+}
+
+// ring_ctl = { pos, full, ticket, adds }: ReplayBuffer.add's epilogue (core/common/buffers.py:280-283)
+__device__ __forceinline__ void ring_advance_last_block(int64_t *ring_ctl, int64_t rows)
+{
+    if (last_block_ticket(reinterpret_cast<unsigned long long *>(ring_ctl + 2)) && threadIdx.x == 0) {
+        int64_t pos = ring_ctl[0] + 1;
+        if (pos == rows) { ring_ctl[1] = 1; pos = 0; }
+        ring_ctl[0] = pos;
+        ring_ctl[3] += 1;
+    }
+}
+#endif

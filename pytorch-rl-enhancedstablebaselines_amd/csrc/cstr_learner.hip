@@ -1,0 +1,130 @@
+// cstr_learner.hip -- element-wise learner kernels for gfx950: target-Q min, polyak soft update and Adam
+// over flat fp32 parameter arenas. Pure HBM streaming: 16-byte accesses per lane, grid capped at 8
+// workgroups per CU with a grid-stride loop; rounding points match torch's CPU/GPU kernels bit for bit
+// (fused multiply-adds are written explicitly, the TU is built with -ffp-contract=off).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/cstr_rl_hip.h"
+#include "cstr_device.h"
+
+namespace {
+
+// SAC: core/sac/sac.py:250-254; TD3: core/td3/td3.py:174-176
+__global__ void td_target_min_kernel(const float *__restrict__ q1, const float *__restrict__ q2, const float *__restrict__ logp,
+                                     const float *__restrict__ rew, const float *__restrict__ done,
+                                     const float *__restrict__ ent_coef, const float gamma, float *__restrict__ out,
+                                     const int64_t n)
+{
+    const float alpha = ent_coef ? ent_coef[0] : 0.0f;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float q = fminf(q1[i], q2[i]);                    // th.min(cat(q1, q2), dim=1)
+        if (logp) q = q - alpha * logp[i];                // sac.py:252
+        out[i] = rew[i] + (1.0f - done[i]) * gamma * q;   // sac.py:254
+    }
+}
+
+// polyak_update (core/common/utils.py:478-481): t.mul_(1 - tau); t = t + tau * p  (add(alpha=) is one fma)
+__device__ __forceinline__ float polyak1(float p, float t, float tau, float om) { return __fmaf_rn(tau, p, t * om); }
+
+__global__ void polyak_kernel(const float *__restrict__ param, float *__restrict__ target, const float tau, const float om,
+                              const int64_t n)
+{
+    const int64_t nv = n >> 2;
+    const float4 *p4 = reinterpret_cast<const float4 *>(param);
+    float4 *t4 = reinterpret_cast<float4 *>(target);
+    const int64_t tid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x, stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = tid; i < nv; i += stride) {
+        const float4 p = p4[i];
+        float4 t = t4[i];
+        t.x = polyak1(p.x, t.x, tau, om); t.y = polyak1(p.y, t.y, tau, om);
+        t.z = polyak1(p.z, t.z, tau, om); t.w = polyak1(p.w, t.w, tau, om);
+        t4[i] = t;
+    }
+    for (int64_t i = (nv << 2) + tid; i < n; i += stride) target[i] = polyak1(param[i], target[i], tau, om);
+}
+
+// torch/optim/adam.py::_single_tensor_adam rounding points (amsgrad=False, weight_decay=0):
+//   m = lerp(m, g, 1-b1) = fma(1-b1, g-m, m);  v = fma((1-b2)*g, g, v*b2)
+//   p = p + (-(lr/bc1) * m) / (sqrt(v)/sqrt(bc2) + eps)
+struct AdamScalars { float step_size_neg, bc2_sqrt, w1, b2, omb2, eps, gscale; };
+
+__device__ __forceinline__ void adam1(float &p, float g, float &m, float &v, const AdamScalars &a)
+{
+    g = g * a.gscale;
+    m = __fmaf_rn(a.w1, g - m, m);
+    v = __fmaf_rn(a.omb2 * g, g, v * a.b2);
+    const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
+    p = p + (a.step_size_neg * m) / denom;
+}
+
+__global__ void adam_kernel(float *__restrict__ param, const float *__restrict__ grad, float *__restrict__ exp_avg,
+                            float *__restrict__ exp_avg_sq, int64_t *__restrict__ adam_ctl, const double *__restrict__ lr,
+                            const double beta1, const double beta2, const double eps, const float gscale, const int64_t n)
+{
+    __shared__ AdamScalars sa;
+    if (threadIdx.x == 0) {
+        const int64_t step = adam_ctl[0] + 1;  // state["step"] += 1
+        const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+        sa.step_size_neg = -(float)(lr[0] / bc1);
+        sa.bc2_sqrt = (float)sqrt(bc2);
+        sa.w1 = (float)(1.0 - beta1);
+        sa.b2 = (float)beta2;
+        sa.omb2 = (float)(1.0 - beta2);
+        sa.eps = (float)eps;
+        sa.gscale = gscale;
+    }
+    __syncthreads();
+    const AdamScalars a = sa;
+    const int64_t nv = n >> 2;
+    const int64_t tid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x, stride = (int64_t)gridDim.x * blockDim.x;
+    float4 *p4 = reinterpret_cast<float4 *>(param), *m4 = reinterpret_cast<float4 *>(exp_avg), *v4 = reinterpret_cast<float4 *>(exp_avg_sq);
+    const float4 *g4 = reinterpret_cast<const float4 *>(grad);
+    for (int64_t i = tid; i < nv; i += stride) {
+        float4 p = p4[i], m = m4[i], v = v4[i];
+        const float4 g = g4[i];
+        adam1(p.x, g.x, m.x, v.x, a); adam1(p.y, g.y, m.y, v.y, a);
+        adam1(p.z, g.z, m.z, v.z, a); adam1(p.w, g.w, m.w, v.w, a);
+        p4[i] = p; m4[i] = m; v4[i] = v;
+    }
+    for (int64_t i = (nv << 2) + tid; i < n; i += stride) {
+        float p = param[i], m = exp_avg[i], v = exp_avg_sq[i];
+        adam1(p, grad[i], m, v, a);
+        param[i] = p; exp_avg[i] = m; exp_avg_sq[i] = v;
+    }
+    if (last_block_ticket(reinterpret_cast<unsigned long long *>(adam_ctl + 1)) && threadIdx.x == 0) adam_ctl[0] += 1;
+}
+
+}  // namespace
+
+extern "C" int cstr_td_target_min_f32(const float *q1, const float *q2, const float *logp, const float *rew, const float *done,
+                                      const float *ent_coef, float gamma, float *out, int64_t n, cstr_stream_t stream)
+{
+    if (!q1 || !q2 || !rew || !done || !out || n <= 0 || ((logp == nullptr) != (ent_coef == nullptr))) return CSTR_E_BADARG;
+    int block, grid;
+    flat_launch_shape(n, block, grid);
+    td_target_min_kernel<<<grid, block, 0, (hipStream_t)stream>>>(q1, q2, logp, rew, done, ent_coef, gamma, out, n);
+    return (int)hipGetLastError();
+}
+
+extern "C" int cstr_polyak_f32(const float *param, float *target, double tau, int64_t n, cstr_stream_t stream)
+{
+    if (!param || !target || n <= 0 || !aligned16(param) || !aligned16(target)) return CSTR_E_BADARG;
+    int block, grid;
+    flat_launch_shape((n + 3) / 4, block, grid);
+    polyak_kernel<<<grid, block, 0, (hipStream_t)stream>>>(param, target, (float)tau, (float)(1.0 - tau), n);
+    return (int)hipGetLastError();
+}
+
+extern "C" int cstr_adam_f32(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t *adam_ctl,
+                             const double *lr, double beta1, double beta2, double eps, float grad_scale, int64_t n,
+                             cstr_stream_t stream)
+{
+    if (!param || !grad || !exp_avg || !exp_avg_sq || !adam_ctl || !lr || n <= 0) return CSTR_E_BADARG;
+    if (!aligned16(param) || !aligned16(grad) || !aligned16(exp_avg) || !aligned16(exp_avg_sq)) return CSTR_E_BADARG;
+    int block, grid;
+    flat_launch_shape((n + 3) / 4, block, grid);
+    adam_kernel<<<grid, block, 0, (hipStream_t)stream>>>(param, grad, exp_avg, exp_avg_sq, adam_ctl, lr, beta1, beta2, eps,
+                                                         grad_scale, n);
+    return (int)hipGetLastError();
+}

@@ -1,0 +1,201 @@
+// cstr_replay.hip -- HBM replay ring sampler for gfx950: NumPy-legacy MT19937 index draw (bit-exact)
+// + masked-rejection compaction + SoA gather in one launch (core/common/buffers.py:106-115, :285-325).
+//
+// One workgroup of 256 lanes (4 waves). The 624-word MT19937 state is staged in LDS; a twist is three
+// 227/227/170-lane phases (each output word only needs words that are either old or produced by an
+// earlier phase); tempering, masking, the accept test and a ballot/popcount prefix sum run 256 words
+// per round, so the data-dependent consumption of `randint` (rejection) is reproduced word for word and
+// the second draw starts exactly where the first stopped. The gather then reads 16-byte (D=4) rows of
+// the field arrays by (row, env) index and writes the five output tensors coalesced.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/cstr_rl_hip.h"
+#include "cstr_device.h"
+
+namespace {
+
+constexpr int MT_N = 624, MT_M = 397, TPB = 256;
+
+__device__ __forceinline__ uint32_t mt_mix(uint32_t a, uint32_t b, uint32_t far)
+{
+    const uint32_t y = (a & 0x80000000u) | (b & 0x7fffffffu);
+    return far ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+}
+
+__device__ __forceinline__ uint32_t mt_temper(uint32_t y)
+{
+    y ^= (y >> 11);
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= (y >> 18);
+    return y;
+}
+
+// mt19937_gen (numpy/random/src/mt19937/mt19937.c), parallel over one workgroup. All lanes call it.
+__device__ void mt_twist(uint32_t *mt)
+{
+    const int t = threadIdx.x;
+    uint32_t v = 0;
+    // phase A: kk in [0, 227): needs old mt[kk], old mt[kk+1], old mt[kk+397]
+    if (t < MT_N - MT_M) v = mt_mix(mt[t], mt[t + 1], mt[t + MT_M]);
+    __syncthreads();
+    if (t < MT_N - MT_M) mt[t] = v;
+    __syncthreads();
+    // phase B: kk in [227, 454): needs old mt[kk], old mt[kk+1], NEW mt[kk-227] (phase A)
+    const int kb = t + (MT_N - MT_M);
+    if (t < MT_N - MT_M) v = mt_mix(mt[kb], mt[kb + 1], mt[kb - (MT_N - MT_M)]);
+    __syncthreads();
+    if (t < MT_N - MT_M) mt[kb] = v;
+    __syncthreads();
+    // phase C: kk in [454, 624): NEW mt[kk-227] (phase B); kk = 623 pairs with NEW mt[0]
+    const int kc = t + 2 * (MT_N - MT_M);
+    if (kc < MT_N) v = mt_mix(mt[kc], (kc == MT_N - 1) ? mt[0] : mt[kc + 1], mt[kc - (MT_N - MT_M)]);
+    __syncthreads();
+    if (kc < MT_N) mt[kc] = v;
+    __syncthreads();
+}
+
+struct SampleShared {
+    uint32_t mt[MT_N];
+    int wave_tot[TPB / 64];
+    int consumed;
+};
+
+// random_bounded_uint64_fill(off=0, rng=high-1, use_masked) for rng < 2^32 - 1 (numpy distributions.c):
+// `count` accepted values into out[], consuming words from (mt, pos) in order. Returns the new pos.
+__device__ int mt_randint_fill(SampleShared &sh, int pos, uint32_t rng, int count, int32_t *out)
+{
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    if (rng == 0u) {  // high == 1: zeros, consumes nothing
+        for (int i = t; i < count; i += TPB) out[i] = 0;
+        __syncthreads();
+        return pos;
+    }
+    uint32_t mask = rng;
+    mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+    int filled = 0;
+    while (filled < count) {  // every quantity in the loop condition is workgroup-uniform
+        if (pos == MT_N) { mt_twist(sh.mt); pos = 0; }
+        const int chunk = min(MT_N - pos, TPB);
+        uint32_t w = 0;
+        bool acc = false;
+        if (t < chunk) {
+            w = mt_temper(sh.mt[pos + t]) & mask;
+            acc = (w <= rng);
+        }
+        const unsigned long long bal = __ballot(acc);
+        const int in_wave = __popcll(bal & ((1ULL << lane) - 1ULL));
+        if (lane == 0) sh.wave_tot[wave] = __popcll(bal);
+        if (t == 0) sh.consumed = chunk;
+        __syncthreads();
+        int before = 0, total = 0;
+#pragma unroll
+        for (int wv = 0; wv < TPB / 64; ++wv) {
+            const int c = sh.wave_tot[wv];
+            if (wv < wave) before += c;
+            total += c;
+        }
+        const int rank = before + in_wave, need = count - filled;
+        if (acc && rank < need) {
+            out[filled + rank] = (int32_t)w;
+            if (rank == need - 1) sh.consumed = t + 1;  // the draw stops right after the need-th accepted word
+        }
+        __syncthreads();
+        pos += sh.consumed;
+        filled += min(total, need);
+        __syncthreads();  // sh.consumed / wave_tot are rewritten next round
+    }
+    return pos;
+}
+
+template <int D>
+__global__ __launch_bounds__(TPB) void replay_sample_kernel(const cstr_ring_t ring, const int64_t *__restrict__ ring_ctl,
+                                                            uint32_t *__restrict__ mt_state, const int batch,
+                                                            float *__restrict__ out_obs, float *__restrict__ out_act,
+                                                            float *__restrict__ out_next_obs, float *__restrict__ out_done,
+                                                            float *__restrict__ out_rew, int64_t *__restrict__ out_row_idx,
+                                                            int64_t *__restrict__ out_env_idx)
+{
+    __shared__ SampleShared sh;
+    extern __shared__ __align__(16) int32_t idx[];  // [2][batch]
+    int32_t *row_idx = idx, *env_idx = idx + batch;
+    const int t = threadIdx.x;
+    for (int i = t; i < MT_N; i += TPB) sh.mt[i] = mt_state[i];
+    int pos = (int)mt_state[MT_N];
+    __syncthreads();
+
+    const int64_t upper = ring_ctl[1] ? ring.rows : ring_ctl[0];  // buffers.py:112
+    pos = mt_randint_fill(sh, pos, (uint32_t)(upper - 1), batch, row_idx);          // buffers.py:113
+    pos = mt_randint_fill(sh, pos, (uint32_t)(ring.n_envs - 1), batch, env_idx);    // buffers.py:309
+    __syncthreads();
+
+    for (int i = t; i < MT_N; i += TPB) mt_state[i] = sh.mt[i];
+    if (t == 0) mt_state[MT_N] = (uint32_t)pos;
+
+    const int64_t n = ring.n_envs;
+    for (int b = t; b < batch; b += TPB) {  // buffers.py:316-323
+        const int64_t r = row_idx[b], e = env_idx[b], o = r * n + e;
+        const float4 x0 = *reinterpret_cast<const float4 *>(ring.obs + o * D);
+        const float4 y0 = *reinterpret_cast<const float4 *>(ring.next_obs + o * D);
+        const float2 a = *reinterpret_cast<const float2 *>(ring.act + o * 2);
+        const float dn = ring.done[o], to = ring.timeout[o], rw = ring.rew[o];
+        *reinterpret_cast<float4 *>(out_obs + (int64_t)b * D) = x0;
+        *reinterpret_cast<float4 *>(out_next_obs + (int64_t)b * D) = y0;
+        if (D == 8) {
+            *reinterpret_cast<float4 *>(out_obs + (int64_t)b * D + 4) = *reinterpret_cast<const float4 *>(ring.obs + o * D + 4);
+            *reinterpret_cast<float4 *>(out_next_obs + (int64_t)b * D + 4) = *reinterpret_cast<const float4 *>(ring.next_obs + o * D + 4);
+        }
+        *reinterpret_cast<float2 *>(out_act + (int64_t)b * 2) = a;
+        out_done[b] = dn * (1.0f - to);  // buffers.py:322
+        out_rew[b] = rw;
+        if (out_row_idx) out_row_idx[b] = r;
+        if (out_env_idx) out_env_idx[b] = e;
+    }
+}
+
+// init_genrand (mt19937_seed): serial recurrence, 624 steps, one lane; runs once per (re)seed.
+__global__ void mt_seed_kernel(uint32_t *__restrict__ mt_state, uint32_t seed)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    uint32_t x = seed;
+    mt_state[0] = x;
+    for (int i = 1; i < MT_N; ++i) {
+        x = 1812433253u * (x ^ (x >> 30)) + (uint32_t)i;
+        mt_state[i] = x;
+    }
+    mt_state[MT_N] = MT_N;
+}
+
+}  // namespace
+
+extern "C" int cstr_mt19937_seed(uint32_t *mt_state, uint32_t seed, cstr_stream_t stream)
+{
+    if (!mt_state) return CSTR_E_BADARG;
+    mt_seed_kernel<<<1, 64, 0, (hipStream_t)stream>>>(mt_state, seed);
+    return (int)hipGetLastError();
+}
+
+extern "C" int cstr_replay_sample_mt19937_f32(const cstr_ring_t *ring, const int64_t *ring_ctl, uint32_t *mt_state,
+                                              int64_t batch, float *out_obs, float *out_act, float *out_next_obs,
+                                              float *out_done, float *out_rew, int64_t *out_row_idx,
+                                              int64_t *out_env_idx, cstr_stream_t stream)
+{
+    if (!ring || !ring->obs || !ring->next_obs || !ring->act || !ring->rew || !ring->done || !ring->timeout) return CSTR_E_BADARG;
+    if (!ring_ctl || !mt_state || !out_obs || !out_act || !out_next_obs || !out_done || !out_rew || batch <= 0) return CSTR_E_BADARG;
+    if ((ring->obs_dim != 4 && ring->obs_dim != 8) || ring->act_dim != 2) return CSTR_E_UNSUPPORTED;
+    // 32-bit masked-rejection path only (numpy switches to 64-bit words above 2^32 - 1; rng == 2^32 - 1 is unmasked)
+    if (batch > CSTR_MAX_SAMPLE_BATCH || ring->rows >= 0xFFFFFFFFLL || ring->n_envs >= 0xFFFFFFFFLL) return CSTR_E_UNSUPPORTED;
+    if (!aligned16(ring->obs) || !aligned16(ring->next_obs) || !aligned8(ring->act) || !aligned16(out_obs) ||
+        !aligned16(out_next_obs) || !aligned8(out_act))
+        return CSTR_E_BADARG;
+    const size_t dyn = sizeof(int32_t) * 2 * (size_t)batch;
+    hipStream_t s = (hipStream_t)stream;
+    if (ring->obs_dim == 4)
+        replay_sample_kernel<4><<<1, TPB, dyn, s>>>(*ring, ring_ctl, mt_state, (int)batch, out_obs, out_act, out_next_obs, out_done,
+                                                    out_rew, out_row_idx, out_env_idx);
+    else
+        replay_sample_kernel<8><<<1, TPB, dyn, s>>>(*ring, ring_ctl, mt_state, (int)batch, out_obs, out_act, out_next_obs, out_done,
+                                                    out_rew, out_row_idx, out_env_idx);
+    return (int)hipGetLastError();
+}

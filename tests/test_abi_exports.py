@@ -1,0 +1,72 @@
+"""CPU-side checks of the C-ABI library: it loads, exports every symbol include/cstr_rl_hip.h
+declares, folds the CSTR constants exactly like the oracle, and rejects bad arguments without
+touching a GPU (no compute calls here)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from core import _native as nv
+from oracle import cstr_oracle as orc
+
+
+def _header_functions():
+    src = open(os.path.join(ROOT, "include", "cstr_rl_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(cstr_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = nv.lib()
+    declared = _header_functions()
+    assert len(declared) >= 12
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/cstr_rl_hip.h but not exported"
+    assert sorted(nv.SYMBOLS) == declared
+    assert lib.cstr_abi_version() == 1
+
+
+def test_error_strings():
+    lib = nv.lib()
+    assert lib.cstr_error_string(0) == b"ok"
+    assert b"bad argument" in lib.cstr_error_string(-1)
+    assert b"unsupported" in lib.cstr_error_string(-2)
+
+
+def test_coef_folding_matches_oracle():
+    a, b = nv.default_coef(0.2, 0.05, 0.45, 400), orc.default_coef(0.2, 0.05, 0.45, 400)
+    assert C.sizeof(a) == C.sizeof(b)
+    assert bytes(a) == bytes(b)
+    # NEP-50 folding spot checks (twoseriescstr.py:37-61)
+    assert a.hk == np.float32(6.78e4 * 7.2e10) and a.cool1 == np.float32((1000 * 0.239) / (1000 * 0.239 * 100))
+    assert a.s_span[1] == np.float32(400.0) - np.float32(273.15) and a.conc_span == np.float32(0.45 - 0.05)
+
+
+def test_bad_arguments_are_rejected_on_the_host():
+    lib = nv.lib()
+    coef = nv.default_coef()
+    null = C.c_void_p(None)
+    assert lib.cstr_vec_step_f32(C.byref(coef), 0, 4, null, null, null, null, null, null, null, null, null, C.c_int64(8), null) == -1
+    assert lib.cstr_polyak_f32(null, null, C.c_double(0.005), C.c_int64(4), null) == -1
+    assert lib.cstr_td_target_min_f32(null, null, null, null, null, null, C.c_float(0.99), null, C.c_int64(4), null) == -1
+    fake = C.c_void_p(0x1000)  # never dereferenced: argument checks fail first
+    assert lib.cstr_vec_step_f32(C.byref(coef), 0, 5, fake, fake, fake, fake, fake, fake, fake, fake, fake, C.c_int64(8), null) == -2
+    assert lib.cstr_vec_step_f32(C.byref(coef), 7, 4, fake, fake, fake, fake, fake, fake, fake, fake, fake, C.c_int64(8), null) == -2
+    ring = nv.Ring(0x1000, 0x1000, 0x1000, 0x1000, 0x1000, 0x1000, 4, 4, 4, 3)  # act_dim 3
+    assert lib.cstr_replay_sample_mt19937_f32(C.byref(ring), fake, fake, C.c_int64(8), fake, fake, fake, fake, fake, null, null, null) == -2
+    ring = nv.Ring(0x1000, 0x1000, 0x1000, 0x1000, 0x1000, 0x1000, 4, 4, 4, 2)
+    assert lib.cstr_replay_sample_mt19937_f32(C.byref(ring), fake, fake, C.c_int64(1 << 20), fake, fake, fake, fake, fake, null, null, null) == -2
+    misaligned = C.c_void_p(0x1004)
+    assert lib.cstr_polyak_f32(misaligned, fake, C.c_double(0.005), C.c_int64(4), null) == -1
+
+
+def test_hip_ops_refuse_cpu_tensors():
+    import torch as th
+
+    from core.common import hip_ops
+
+    with pytest.raises(ValueError, match="No CPU fallback"):
+        hip_ops.polyak(th.zeros(8), th.zeros(8), 0.005)

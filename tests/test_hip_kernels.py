@@ -1,0 +1,399 @@
+"""GPU parity tests: every HIP kernel, called through the C ABI, against the oracle and the golden
+vectors generated from the reference. Bit-exact for integer/index/copy work; fp32 tolerances are
+written next to each check (north_star: 1e-5 rel on Q-values/returns; bit-exact replay indices).
+"""
+import numpy as np
+import pytest
+import torch as th
+
+from conftest import rel_err
+from oracle import cstr_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+OBS_FLOOR = 1.0  # observations/rewards: error relative to max(|x|, 1) (see tests/test_oracle_env.py)
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert th.cuda.is_available(), "GPU tests need an MI355X"
+    from core import _native as nv
+    from core.common import hip_ops
+
+    nv.lib()  # fail loudly if the HIP extension is missing
+    return hip_ops
+
+
+def dev(a, dtype=None):
+    t = th.as_tensor(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.cuda().contiguous()
+
+
+def obs8(o4):
+    """[normalised | raw] observation of SURVEY D2 built on the host with the reference's f32 formula."""
+    lo = np.array([0.0, 273.15, 0.0, 273.15], np.float32)
+    hi = np.array([0.7, 400.0, 0.7, 400.0], np.float32)
+    raw = np.clip(lo + (o4 + np.float32(1.0)) * (hi - lo) / np.float32(2.0), lo, hi).astype(np.float32)
+    return np.concatenate([o4, raw], axis=1)
+
+
+def run_vec_step(ops, obs, act, steps, reset_obs, integrator="euler", d=4):
+    from core import _native as nv
+
+    n = len(obs)
+    o = dev(obs if d == 4 else obs8(obs))
+    ro = dev(reset_obs if d == 4 else obs8(reset_obs))
+    a, st = dev(act), dev(steps, th.int32)
+    nxt, after = th.empty_like(o), th.empty_like(o)
+    rew, done, tout = (th.empty(n, dtype=th.float32, device="cuda") for _ in range(3))
+    ops.vec_step(nv.default_coef(), integrator, o, a, st, ro, nxt, after, rew, done, tout)
+    th.cuda.synchronize()
+    return [x.cpu().numpy() for x in (nxt, after, rew, done, tout, st)]
+
+
+# ------------------------------------------------------------------------------------------- env
+@pytest.mark.parametrize("d", [4, 8])
+def test_vec_step_vs_golden_and_oracle(ops, golden, d):
+    g = golden("env_step_kat.npz")
+    rng = np.random.default_rng(1)
+    reset = rng.uniform(-1, 1, g["obs"].shape).astype(np.float32)
+    nxt, after, rew, done, tout, st = run_vec_step(ops, g["obs"], g["act"], g["step_in"], reset, d=d)
+    # vs the reference's own outputs (golden): fp32 tolerance 1e-6 of the box scale, rewards 2e-6
+    assert rel_err(nxt[:, :4], g["obs_next"], OBS_FLOOR) < 1e-6
+    assert rel_err(rew, g["reward"], 1.0) < 2e-6
+    np.testing.assert_array_equal(done.astype(np.uint8), g["truncated"])
+    np.testing.assert_array_equal(tout.astype(np.uint8), g["truncated"])
+    np.testing.assert_array_equal(st, np.where(g["truncated"] > 0, 0, g["step_in"] + 1))
+    # vs the oracle on the same inputs: same rounding points, only expf may differ by an ulp
+    o_nxt, o_after, o_rew, o_done, o_tout, o_st = orc.vec_step(g["obs"], g["act"], g["step_in"], reset)
+    assert rel_err(nxt[:, :4], o_nxt, OBS_FLOOR) < 5e-7
+    assert rel_err(after[:, :4], o_after, OBS_FLOOR) < 5e-7
+    fin = g["truncated"].astype(bool)
+    np.testing.assert_array_equal(after[fin][:, :4], reset[fin])  # reset source copied bit-exactly
+    if d == 8:
+        assert rel_err(nxt[:, 4:], g["raw_next"], 1.0) < 1e-6  # info["original_state"] (twoseriescstr.py:446)
+        np.testing.assert_array_equal(after[fin], obs8(reset)[fin])
+
+
+def test_vec_step_nan_action(ops, golden):
+    g = golden("env_nan_kat.npz")
+    reset = np.full((1, 4), 0.25, np.float32)
+    nxt, after, rew, done, tout, st = run_vec_step(ops, g["obs"][None], g["act"][None], np.array([7], np.int32), reset)
+    np.testing.assert_array_equal(nxt[0], g["obs_next"])
+    assert rew[0] == -10.0 and done[0] == 1.0 and tout[0] == 1.0 and st[0] == 0
+    np.testing.assert_array_equal(after, reset)
+
+
+def test_trajectories_vs_golden(ops, golden):
+    """400-step roll-outs under fixed action tapes: 1e-5 (north_star bound on returns)."""
+    g = golden("env_traj_kat.npz")
+    obs, steps = g["obs0"].copy(), np.zeros(len(g["obs0"]), np.int32)
+    T = g["actions"].shape[0]
+    ret = np.zeros(len(obs), np.float64)
+    for k in range(T):
+        nxt, after, rew, done, tout, steps = run_vec_step(ops, obs, g["actions"][k], steps, obs)
+        assert rel_err(nxt, g["obs"][k], OBS_FLOOR) < 1e-5
+        assert rel_err(rew, g["reward"][k], 1.0) < 1e-5
+        np.testing.assert_array_equal(tout.astype(np.uint8), g["truncated"][k])
+        ret += rew
+        obs = nxt
+    assert rel_err(ret, g["reward"].astype(np.float64).sum(0), 1e-3) < 1e-5  # episode returns
+
+
+def test_autoreset_semantics_vs_golden(ops, golden):
+    g = golden("vecenv_autoreset_kat.npz")
+    obs, steps = g["obs0"].copy(), g["step0"].copy()
+    for k in range(g["actions"].shape[0]):
+        nxt, after, rew, done, tout, steps = run_vec_step(ops, obs, g["actions"][k], steps, g["reset_obs"][k])
+        assert rel_err(nxt, g["next_obs_for_buffer"][k], OBS_FLOOR) < 1e-6
+        assert rel_err(after, g["obs"][k], OBS_FLOOR) < 1e-6
+        np.testing.assert_array_equal(done.astype(np.uint8), g["done"][k])
+        np.testing.assert_array_equal(tout.astype(np.uint8), g["timeout"][k])
+        obs = after
+
+
+@pytest.mark.parametrize("n", [1, 63, 4096, 70001])
+def test_vec_step_rk4_and_ragged_sizes(ops, n):
+    rng = np.random.default_rng(n)
+    obs = rng.uniform(-1, 1, (n, 4)).astype(np.float32)
+    act = rng.uniform(-1.2, 1.2, (n, 2)).astype(np.float32)
+    steps = rng.integers(0, 400, n).astype(np.int32)
+    reset = rng.uniform(-1, 1, (n, 4)).astype(np.float32)
+    for integ in ("euler", "rk4"):
+        got = run_vec_step(ops, obs, act, steps, reset, integrator=integ)
+        exp = orc.vec_step(obs, act, steps, reset, integrator=integ)
+        # RK4 chains four expf-bearing stages: allow 2e-6 of the box scale
+        assert rel_err(got[0], exp[0], OBS_FLOOR) < 2e-6 and rel_err(got[1], exp[1], OBS_FLOOR) < 2e-6
+        assert rel_err(got[2], exp[2], 1.0) < 4e-6
+        for a, b in zip(got[3:], exp[3:]):
+            np.testing.assert_array_equal(a, b)
+
+
+def test_reset_draw_pcg64_bit_exact(ops):
+    """Device PCG64 + Generator.uniform restatement == oracle == numpy Generator (see test_oracle_elementwise)."""
+    n = 1000
+    st = orc.pcg64_states_from_seeds(np.arange(100, 100 + n))
+    dst = dev(st.view(np.uint64).reshape(n, 4).view(np.int64))
+    for rnd in range(3):
+        mask = None if rnd == 0 else (np.arange(n) % (rnd + 1) == 0).astype(np.uint8)
+        out = th.zeros(n, 4, device="cuda")
+        ops.reset_draw(dst, None if mask is None else dev(mask), out)
+        exp = orc.reset_draw(st, mask)
+        got = out.cpu().numpy()
+        sel = slice(None) if mask is None else mask.astype(bool)
+        np.testing.assert_array_equal(got[sel], exp[sel])
+        np.testing.assert_array_equal(dst.cpu().numpy().view(np.uint64).reshape(-1), st.view(np.uint64).reshape(-1))
+
+
+# ---------------------------------------------------------------------------------------- replay
+def _mk_ring(ops, R, N, D, A=2):
+    return ops.DeviceRing(R, N, D, A, "cuda")
+
+
+@pytest.mark.parametrize("tag", ["small", "wide"])
+def test_replay_add_sample_vs_golden(ops, golden, tag):
+    """Reference ReplayBuffer.add/sample round trip incl. wrap-around and dones*(1-timeouts): bit-exact."""
+    g = golden("replay_kat.npz")
+    R, N, D, A, n_add, B = (int(x) for x in g[f"{tag}_dims"])
+    ring = _mk_ring(ops, R, N, D)
+    mt = th.zeros(625, dtype=th.int32, device="cuda")
+    ops.mt19937_seed(mt, int(g["seed"]))
+    outs = [th.empty(B, D, device="cuda"), th.empty(B, A, device="cuda"), th.empty(B, D, device="cuda"),
+            th.empty(B, 1, device="cuda"), th.empty(B, 1, device="cuda")]
+    for k in range(n_add):
+        ops.replay_add(ring, dev(g[f"{tag}_obs"][k]), dev(g[f"{tag}_next_obs"][k]), dev(g[f"{tag}_act"][k]),
+                       dev(g[f"{tag}_rew"][k]), dev(g[f"{tag}_done"][k], th.float32), dev(g[f"{tag}_timeout"][k], th.float32))
+        ops.replay_sample(ring, mt, B, *outs)
+        for name, t in zip(("observations", "actions", "next_observations", "dones", "rewards"), outs):
+            np.testing.assert_array_equal(t.cpu().numpy(), g[f"{tag}_s_{name}"][k], err_msg=f"{tag} add#{k} {name}")
+    for name, t in (("obs", ring.observations), ("next_obs", ring.next_observations), ("act", ring.actions),
+                    ("rew", ring.rewards), ("done", ring.dones), ("timeout", ring.timeouts)):
+        np.testing.assert_array_equal(t.cpu().numpy(), g[f"{tag}_ring_{name}"])
+    ctl = ring.ctl.cpu().numpy()
+    assert ctl[0] == int(g[f"{tag}_pos"]) and ctl[1] == int(g[f"{tag}_full"]) and ctl[2] == 0 and ctl[3] == n_add
+
+
+def test_mt19937_index_stream_vs_numpy_golden(ops, golden):
+    """np.random.randint index streams (buffers.py:113,309), incl. upper == 1 (consumes nothing),
+    non-power-of-two bounds and back-to-back calls: int64 indices and final (key, pos) bit-exact."""
+    g = golden("mt19937_randint_kat.npz")
+    for ci in range(int(g["n_cases"])):
+        calls = g[f"c{ci}_calls"]
+        if len(calls) % 2 or calls.max() >= 2**32 - 1 or (calls[0::2, 1] != calls[1::2, 1]).any():
+            continue  # the device sampler draws (rows, envs) pairs of equal batch on the 32-bit path
+        mt = th.zeros(625, dtype=th.int32, device="cuda")
+        ops.mt19937_seed(mt, int(g[f"c{ci}_seed"]))
+        got = []
+        for (upper, B), (n_envs, _) in zip(calls[0::2], calls[1::2]):
+            upper, B, n_envs = int(upper), int(B), int(n_envs)
+            ring = _mk_ring(ops, max(upper, 1), n_envs, 4) if upper * n_envs <= 1 << 22 else None
+            if ring is None:
+                got = None
+                break
+            ring.ctl[0] = upper % ring.rows
+            ring.ctl[1] = int(upper == ring.rows)
+            bi, ei = th.empty(B, dtype=th.int64, device="cuda"), th.empty(B, dtype=th.int64, device="cuda")
+            outs = [th.empty(B, 4, device="cuda"), th.empty(B, 2, device="cuda"), th.empty(B, 4, device="cuda"),
+                    th.empty(B, 1, device="cuda"), th.empty(B, 1, device="cuda")]
+            ops.replay_sample(ring, mt, B, *outs, bi, ei)
+            got += [bi.cpu().numpy(), ei.cpu().numpy()]
+        if got is None:
+            continue
+        np.testing.assert_array_equal(np.concatenate(got), g[f"c{ci}_out"], err_msg=f"case {ci}")
+        st = mt.cpu().numpy().view(np.uint32)
+        np.testing.assert_array_equal(st[:624], g[f"c{ci}_key"])
+        assert int(st[624]) == int(g[f"c{ci}_pos"])
+
+
+@pytest.mark.parametrize("seed,R,N,B", [(0, 244, 4096, 256), (4095, 244, 4096, 256), (7, 976, 1024, 256),
+                                        (11, 3, 5, 1), (12, 1000, 7, 4099), (13, 61, 33, 16384)])
+def test_sampler_vs_oracle_random_fill(ops, seed, R, N, B):
+    """Seeded random rings at BASELINE sizes: device (indices, gathered batch, MT state) == oracle, 20 calls."""
+    rng = np.random.default_rng(seed)
+    D = 4
+    ring, oring = _mk_ring(ops, R, N, D), orc.ReplayRing(R, N, D, 2)
+    n_add = min(R + 3, 40)
+    for k in range(n_add):
+        f = [rng.uniform(-1, 1, (N, D)).astype(np.float32), rng.uniform(-1, 1, (N, D)).astype(np.float32),
+             rng.uniform(-1, 1, (N, 2)).astype(np.float32), rng.uniform(-8, 0, N).astype(np.float32),
+             (rng.uniform(size=N) < 0.3).astype(np.float32), (rng.uniform(size=N) < 0.2).astype(np.float32)]
+        oring.add(*f)
+        ops.replay_add(ring, *[dev(x) for x in f])
+    mt, omt = th.zeros(625, dtype=th.int32, device="cuda"), orc.MT19937(seed + N - 1)
+    ops.mt19937_seed(mt, seed + N - 1)  # effective stream seed of an end-to-end run (SURVEY a-6)
+    bi, ei = th.empty(B, dtype=th.int64, device="cuda"), th.empty(B, dtype=th.int64, device="cuda")
+    outs = [th.empty(B, D, device="cuda"), th.empty(B, 2, device="cuda"), th.empty(B, D, device="cuda"),
+            th.empty(B, 1, device="cuda"), th.empty(B, 1, device="cuda")]
+    for call in range(20):
+        ops.replay_sample(ring, mt, B, *outs, bi, ei)
+        exp, (ebi, eei) = oring.sample(omt, B)
+        np.testing.assert_array_equal(bi.cpu().numpy(), ebi, err_msg=f"row idx, call {call}")
+        np.testing.assert_array_equal(ei.cpu().numpy(), eei, err_msg=f"env idx, call {call}")
+        for t, e in zip(outs, exp):
+            np.testing.assert_array_equal(t.cpu().numpy(), e)
+    st = mt.cpu().numpy().view(np.uint32)
+    np.testing.assert_array_equal(st[:624], omt.key)
+    assert int(st[624]) == omt.pos
+
+
+# --------------------------------------------------------------------------------- fused collect
+@pytest.mark.parametrize("d,integ", [(4, "euler"), (8, "euler"), (4, "rk4")])
+def test_collect_step_fused_equals_unfused_oracle(ops, d, integ):
+    """Fused scale-chain + step + auto-reset + ring write over 3 ring wraps, episodes ending at different
+    times, vs the oracle's action chain -> vec_step -> ring add. Index/flag/copy fields bit-exact."""
+    from core import _native as nv
+
+    rng = np.random.default_rng(5)
+    N, R, T = 777, 4, 13
+    low, high = np.array([-1, -1], np.float32), np.array([1, 1], np.float32)
+    obs = rng.uniform(-1, 1, (N, 4)).astype(np.float32)
+    steps = rng.integers(380, 400, N).astype(np.int32)
+    ring, oring = _mk_ring(ops, R, N, d), orc.ReplayRing(R, N, 4, 2)
+    env_obs = dev(obs if d == 4 else obs8(obs))
+    dsteps = dev(steps, th.int32)
+    rew_o, done_o = th.empty(N, device="cuda"), th.empty(N, device="cuda")
+    coef = nv.default_coef()
+    for k in range(T):
+        pol = np.tanh(rng.normal(0, 1.5, (N, 2))).astype(np.float32)
+        noise = None if k % 2 else rng.normal(0, 0.1, (N, 2)).astype(np.float32)
+        reset = rng.uniform(-1, 1, (N, 4)).astype(np.float32)
+        squashed = k % 3 != 0
+        ops.collect_step(coef, integ, ring, env_obs, dsteps, dev(pol), squashed, low, high,
+                         noise=None if noise is None else dev(noise), reset_obs=dev(reset if d == 4 else obs8(reset)),
+                         reward_out=rew_o, done_out=done_o)
+        buf_a, env_a = orc.action_scale_chain(pol, squashed, low, high)
+        if noise is not None:
+            buf_a = np.clip(buf_a + noise, -1, 1).astype(np.float32)
+            env_a = (low + (np.float32(0.5) * (buf_a + np.float32(1.0)) * (high - low))).astype(np.float32)
+        nxt, after, rew, done, tout, steps2 = orc.vec_step(obs, env_a, steps, reset, integrator=integ)
+        oring.add(obs, nxt, buf_a, rew, done, tout)
+        tol = 5e-7 if integ == "euler" else 2e-6
+        assert rel_err(env_obs.cpu().numpy()[:, :4], after, OBS_FLOOR) < tol
+        np.testing.assert_array_equal(dsteps.cpu().numpy(), steps2)
+        np.testing.assert_array_equal(done_o.cpu().numpy(), done)
+        assert rel_err(rew_o.cpu().numpy(), rew, 1.0) < 4 * tol
+        # follow the DEVICE trajectory so single-ulp expf differences cannot accumulate into flag flips
+        obs, steps = env_obs.cpu().numpy()[:, :4].copy(), steps2
+    tol = 5e-7 if integ == "euler" else 2e-6
+    np.testing.assert_array_equal(ring.actions.cpu().numpy(), oring.actions)
+    np.testing.assert_array_equal(ring.dones.cpu().numpy(), oring.dones)
+    np.testing.assert_array_equal(ring.timeouts.cpu().numpy(), oring.timeouts)
+    np.testing.assert_array_equal(ring.observations.cpu().numpy()[..., :4], oring.observations)
+    assert rel_err(ring.next_observations.cpu().numpy()[..., :4], oring.next_observations, OBS_FLOOR) < tol
+    assert rel_err(ring.rewards.cpu().numpy(), oring.rewards, 1.0) < 4 * tol
+    ctl = ring.ctl.cpu().numpy()
+    assert ctl[0] == T % R and ctl[1] == 1 and ctl[2] == 0 and ctl[3] == T
+    assert oring.dones.sum() > 0  # auto-reset was exercised
+
+
+def test_collect_step_device_reset_rng(ops):
+    """pcg_state reset source: finished envs restart from the faithful PCG64 draw, others untouched."""
+    from core import _native as nv
+
+    N, R = 300, 2
+    rng = np.random.default_rng(0)
+    obs = rng.uniform(-1, 1, (N, 4)).astype(np.float32)
+    steps = np.where(np.arange(N) % 3 == 0, 399, 5).astype(np.int32)
+    st = orc.pcg64_states_from_seeds(np.arange(N))
+    dst = dev(st.view(np.uint64).reshape(N, 4).view(np.int64))
+    ring = _mk_ring(ops, R, N, 4)
+    env_obs, dsteps = dev(obs), dev(steps, th.int32)
+    pol = rng.uniform(-1, 1, (N, 2)).astype(np.float32)
+    ops.collect_step(nv.default_coef(), "euler", ring, env_obs, dsteps, dev(pol), True,
+                     [-1, -1], [1, 1], pcg_state=dst)
+    fin = steps == 399
+    exp_reset = orc.reset_draw(st, fin.astype(np.uint8))
+    got = env_obs.cpu().numpy()
+    np.testing.assert_array_equal(got[fin], exp_reset[fin])
+    np.testing.assert_array_equal(dst.cpu().numpy().view(np.uint64).reshape(-1), st.view(np.uint64).reshape(-1))
+    np.testing.assert_array_equal(dsteps.cpu().numpy(), np.where(fin, 0, 6))
+    np.testing.assert_array_equal(ring.dones.cpu().numpy()[0], fin.astype(np.float32))
+
+
+# --------------------------------------------------------------------------------- element-wise
+@pytest.mark.parametrize("n", [1, 3, 256, 135682, 369704, 1 << 22])
+def test_polyak_bit_exact(ops, n):
+    """core/common/utils.py:478-481 on one flat arena: bit-identical to torch's two in-place ops."""
+    g = th.Generator().manual_seed(n)
+    p, t = th.randn(n, generator=g), th.randn(n, generator=g)
+    for tau in (0.005, 1.0):
+        exp = t.clone()
+        exp.mul_(1 - tau)
+        th.add(exp, p, alpha=tau, out=exp)
+        dp, dt = p.cuda(), t.clone().cuda()
+        ops.polyak(dp, dt, tau)
+        np.testing.assert_array_equal(dt.cpu().numpy(), exp.numpy())
+        np.testing.assert_array_equal(dt.cpu().numpy(), orc.polyak(p.numpy(), t.numpy(), tau))
+
+
+@pytest.mark.parametrize("n,sac", [(1, True), (256, True), (256, False), (100003, True)])
+def test_td_target_bit_exact(ops, n, sac):
+    g = th.Generator().manual_seed(n)
+    q1, q2, lp = th.randn(n, 1, generator=g) * 5, th.randn(n, 1, generator=g) * 5, th.randn(n, 1, generator=g)
+    rew, done = -th.rand(n, 1, generator=g) * 8, (th.rand(n, 1, generator=g) < 0.2).float()
+    ent = th.tensor([0.731])
+    out = th.empty(n, 1, device="cuda")
+    ops.td_target_min(q1.cuda(), q2.cuda(), lp.cuda() if sac else None, rew.cuda(), done.cuda(),
+                      ent.cuda() if sac else None, 0.99, out)
+    exp = orc.td_target_min(q1.numpy(), q2.numpy(), lp.numpy() if sac else None, rew.numpy(), done.numpy(), float(ent), 0.99)
+    np.testing.assert_array_equal(out.cpu().numpy().reshape(-1), exp)
+    # and the reference's torch expression (sac.py:250-254 / td3.py:174-176) evaluated on the CPU
+    nq, _ = th.min(th.cat((q1, q2), dim=1), dim=1, keepdim=True)
+    if sac:
+        nq = nq - ent * lp.reshape(-1, 1)
+    np.testing.assert_array_equal(out.cpu().numpy(), (rew + (1 - done) * 0.99 * nq).numpy())
+
+
+@pytest.mark.parametrize("n", [5, 1026, 68100, 135682])
+def test_adam_vs_torch_and_oracle(ops, n):
+    """torch.optim.Adam (reference optimiser) for 6 steps with a device-resident step counter."""
+    from core import _native as nv
+
+    g = th.Generator().manual_seed(n)
+    p0 = th.randn(n, generator=g)
+    ref = th.nn.Parameter(p0.clone())
+    opt = th.optim.Adam([ref], lr=3e-4)
+    p, m, v = p0.clone().cuda(), th.zeros(n, device="cuda"), th.zeros(n, device="cuda")
+    ctl = th.zeros(nv.ADAM_CTL_WORDS, dtype=th.int64, device="cuda")
+    lr = th.tensor([3e-4], dtype=th.float64, device="cuda")
+    op, om, ov = p0.numpy().copy(), np.zeros(n, np.float32), np.zeros(n, np.float32)
+    for step in range(1, 7):
+        grad = th.randn(n, generator=g) * (10.0 ** float(th.randint(-3, 2, (1,), generator=g)))
+        ref.grad = grad.clone()
+        opt.step()
+        ops.adam(p, grad.cuda(), m, v, ctl, lr)
+        op, om, ov = orc.adam_step(op, grad.numpy(), om, ov, step, 3e-4)
+        assert int(ctl[0]) == step and int(ctl[1]) == 0
+        # device pow()/sqrt() in f64 may differ from libm by an ulp before the f32 cast: <= 2 ulp, and
+        # 1e-6 relative against torch
+        for got, want in ((p, op), (m, om), (v, ov)):
+            u = np.abs(got.cpu().numpy().view(np.int32).astype(np.int64) - want.view(np.int32).astype(np.int64))
+            assert u.max() <= 4 and (u > 1).mean() < 1e-3
+        assert rel_err(p.cpu().numpy(), ref.detach().numpy(), 1e-3) < 1e-6
+    # grad_scale (data-parallel mean) folds 1/W into the update
+    p2, m2, v2 = p0.clone().cuda(), th.zeros(n, device="cuda"), th.zeros(n, device="cuda")
+    ctl2 = th.zeros(nv.ADAM_CTL_WORDS, dtype=th.int64, device="cuda")
+    p3, m3, v3 = p0.clone().cuda(), th.zeros(n, device="cuda"), th.zeros(n, device="cuda")
+    ctl3 = th.zeros(nv.ADAM_CTL_WORDS, dtype=th.int64, device="cuda")
+    gsum = th.randn(n, generator=g).cuda()
+    ops.adam(p2, gsum, m2, v2, ctl2, lr, grad_scale=0.125)
+    ops.adam(p3, gsum * 0.125, m3, v3, ctl3, lr)
+    assert th.equal(p2, p3) and th.equal(m2, m3) and th.equal(v2, v3)
+
+
+def test_ops_reject_bad_shapes(ops):
+    from core import _native as nv
+
+    n = 64
+    o = th.zeros(n, 4, device="cuda")
+    with pytest.raises(ValueError):
+        ops.vec_step(nv.default_coef(), "euler", o, th.zeros(n, 3, device="cuda"), th.zeros(n, dtype=th.int32, device="cuda"),
+                     o, o.clone(), o.clone(), *(th.zeros(n, device="cuda") for _ in range(3)))
+    with pytest.raises(ValueError):
+        ops.DeviceRing(4, 4, 5, 2, "cuda")
+    ring = ops.DeviceRing(4, 4, 4, 2, "cuda")
+    with pytest.raises(ValueError):
+        ops.replay_sample(ring, th.zeros(625, dtype=th.int32, device="cuda"), 1 << 15,
+                          *(th.zeros(1 << 15, k, device="cuda") for k in (4, 2, 4, 1, 1)))
