@@ -108,11 +108,15 @@ int cstr_replay_add_f32(const cstr_ring_t *ring, int64_t *ring_ctl, const float 
  *   act_low/act_high [2]    in : HOST pointers, bounds of the algorithm-facing action space
  *   noise      [N][2] or NULL  : added to the scaled action, then clip [-1,1] (off_policy_algorithm.py:401-402)
  *   reset_obs  [N][obs_dim] or NULL, pcg_state [N][4] or NULL: reset source (exactly one non-NULL)
- *   reward_out/done_out [N] or NULL: copies for episode statistics */
+ *   reward_out/done_out [N] or NULL: per-env copies (what VecEnv.step would have returned)
+ *   ep_return [N] + ep_stats double[4] = {episodes, sum of returns, sum of lengths, -} or both NULL: device-side
+ *                                episode statistics (Monitor's info["episode"], core/common/monitor.py:96-109; the
+ *                                counters behind _episode_num / rollout/ep_rew_mean) accumulated without a host sync */
 int cstr_collect_step_f32(const cstr_coef_t *coef, int integrator, const cstr_ring_t *ring, int64_t *ring_ctl,
                           float *env_obs, int32_t *step_count, const float *policy_out, int squashed,
                           const float *act_low, const float *act_high, const float *noise, const float *reset_obs,
-                          uint64_t *pcg_state, float *reward_out, float *done_out, cstr_stream_t stream);
+                          uint64_t *pcg_state, float *reward_out, float *done_out, float *ep_return, double *ep_stats,
+                          cstr_stream_t stream);
 
 /* np.random.seed(seed) for the device-resident legacy MT19937 state (core/common/utils.py:46;
  * twoseriescstr.py:164 reseeds the same global stream). */

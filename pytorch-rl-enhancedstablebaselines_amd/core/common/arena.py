@@ -1,0 +1,122 @@
+"""Flat parameter arenas: the learner-side HBM layout.
+
+Each optimiser group (actor, critic, ...) owns ONE contiguous fp32 buffer for its parameters, one for its
+gradients and two for the Adam moments; a target network owns a buffer with the identical layout. The
+nn.Module parameters are views into the arena, `.grad`s are views into the gradient buffer, so:
+
+  * `polyak_update` over a whole network is one HIP launch on two flat buffers
+    (reference: one mul_ + one add per tensor, core/common/utils.py:478-481),
+  * the optimiser step is one HIP launch (reference: torch.optim.Adam, core/common/policies.py:96-117),
+  * the data-parallel gradient exchange is one RCCL all-reduce per group on the flat gradient buffer, with
+    the 1/world scale folded into the Adam kernel.
+
+Tensors start on 256-byte boundaries inside the arena (GEMM-friendly); the padding stays zero under both
+kernels (0 grad, 0 moment -> 0 update).
+"""
+from typing import Iterable, List, Optional
+
+import torch as th
+from torch import nn
+
+from core import _native as nv
+from core.common import hip_ops
+
+_ALIGN = 64  # floats (256 B)
+
+
+class ParamArena:
+    def __init__(self, params: Iterable[nn.Parameter], device, with_grad: bool = True):
+        self.params: List[nn.Parameter] = list(params)
+        self.device = th.device(device)
+        self.offsets, off = [], 0
+        for p in self.params:
+            self.offsets.append(off)
+            off += -(-p.numel() // _ALIGN) * _ALIGN
+        self.numel = max(off, _ALIGN)
+        self.flat = th.zeros(self.numel, dtype=th.float32, device=self.device)
+        self.grad = th.zeros(self.numel, dtype=th.float32, device=self.device) if with_grad else None
+        with th.no_grad():
+            for p, o in zip(self.params, self.offsets):
+                view = self.flat[o:o + p.numel()].view(p.shape)
+                view.copy_(p.detach().to(self.device, th.float32))
+                p.data = view
+                if with_grad and p.requires_grad:
+                    p.grad = self.grad[o:o + p.numel()].view(p.shape)
+
+    def zero_grad(self) -> None:
+        """One memset; `.grad` views stay attached so autograd keeps accumulating in place."""
+        self.grad.zero_()
+        for p, o in zip(self.params, self.offsets):
+            if p.requires_grad and (p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * o):
+                p.grad = self.grad[o:o + p.numel()].view(p.shape)
+
+    def same_layout(self, other: "ParamArena") -> bool:
+        return self.offsets == other.offsets and self.numel == other.numel and \
+            [tuple(p.shape) for p in self.params] == [tuple(p.shape) for p in other.params]
+
+    def polyak_from(self, source: "ParamArena", tau: float) -> None:
+        """self (target) <- polyak(source, tau): reference core/common/utils.py:457-481, one launch."""
+        if not self.same_layout(source):
+            raise ValueError("Iterables have different lengths")  # zip_strict's error (utils.py:447)
+        with th.cuda.device(self.device):
+            hip_ops.polyak(source.flat, self.flat, tau)
+
+
+class FlatAdam:
+    """torch.optim.Adam (betas 0.9/0.999, eps 1e-8, no weight decay / amsgrad -- the reference's defaults) over one
+    `ParamArena`, one HIP launch per step, step counter and learning rate resident in HBM."""
+
+    def __init__(self, arena: ParamArena, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8):
+        self.arena = arena
+        self.defaults = dict(lr=lr, betas=betas, eps=eps)
+        self.param_groups = [dict(params=arena.params, lr=lr, betas=betas, eps=eps)]
+        dev = arena.device
+        self.exp_avg = th.zeros_like(arena.flat)
+        self.exp_avg_sq = th.zeros_like(arena.flat)
+        self.ctl = th.zeros(nv.ADAM_CTL_WORDS, dtype=th.int64, device=dev)
+        self.lr_dev = th.tensor([lr], dtype=th.float64, device=dev)
+        self._lr_on_device = float(lr)
+        self.grad_scale = 1.0  # 1 / world_size after a summing all-reduce
+
+    def zero_grad(self, set_to_none: bool = False) -> None:
+        self.arena.zero_grad()
+
+    def sync_lr(self) -> None:
+        """Push `param_groups[0]["lr"]` (set by update_learning_rate, reference core/common/utils.py:56-66) to HBM.
+        Called outside captured regions; a constant schedule never copies."""
+        lr = float(self.param_groups[0]["lr"])
+        if lr != self._lr_on_device:
+            self.lr_dev.fill_(lr)
+            self._lr_on_device = lr
+
+    def step(self, closure=None) -> None:
+        g = self.param_groups[0]
+        with th.cuda.device(self.arena.device):
+            hip_ops.adam(self.arena.flat, self.arena.grad, self.exp_avg, self.exp_avg_sq, self.ctl, self.lr_dev,
+                         g["betas"][0], g["betas"][1], g["eps"], self.grad_scale)
+
+    @property
+    def step_count(self) -> int:
+        return int(self.ctl[0])
+
+    def state_dict(self) -> dict:
+        return dict(exp_avg=self.exp_avg.clone(), exp_avg_sq=self.exp_avg_sq.clone(), step=int(self.ctl[0]),
+                    lr=float(self.param_groups[0]["lr"]))
+
+    def load_state_dict(self, sd: dict) -> None:
+        self.exp_avg.copy_(sd["exp_avg"])
+        self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        self.ctl[0] = int(sd["step"])
+        self.param_groups[0]["lr"] = float(sd["lr"])
+        self.sync_lr()
+
+
+def make_optimizer(module_params: Iterable[nn.Parameter], device, lr: float, optimizer_class=None,
+                   optimizer_kwargs: Optional[dict] = None):
+    """Default (optimizer_class None or torch.optim.Adam with default kwargs) -> arena + FlatAdam. Any other
+    optimiser class is honoured with the stock torch implementation on the arena's parameter views."""
+    optimizer_kwargs = dict(optimizer_kwargs or {})
+    arena = ParamArena(module_params, device)
+    if optimizer_class in (None, th.optim.Adam) and set(optimizer_kwargs) <= {"betas", "eps"}:
+        return arena, FlatAdam(arena, lr=lr, **optimizer_kwargs)
+    return arena, optimizer_class(arena.params, lr=lr, **optimizer_kwargs)

@@ -1,0 +1,154 @@
+"""`ReplayBuffer` with the reference's constructor, attributes and `add`/`sample` semantics
+(reference: core/common/buffers.py:27-340), stored in HBM and served by HIP kernels:
+
+  * field arrays `observations / next_observations / actions / rewards / dones / timeouts` keep the
+    reference's shapes `[rows, n_envs, ...]` and are device tensors (zero-copy views of the ring);
+  * `add` is one launch (row write at the device-resident position);
+  * `sample` draws `np.random.randint` indices from the device image of NumPy's legacy global MT19937
+    stream -- bit-identical to the reference's `batch_inds` / `env_indices` -- and gathers the five
+    fields in the same launch.
+"""
+from typing import Any, Optional, Union
+
+import numpy as np
+import torch as th
+
+from core.common import hip_ops, legacy_rng
+from core.common.spaces import as_box, get_action_dim, get_obs_shape
+from core.common.type_aliases import ReplayBufferSamples
+from core.common.utils import get_device
+
+
+class BaseBuffer:
+    """reference: core/common/buffers.py:27-156 (the parts the off-policy path uses)"""
+
+    def __init__(self, buffer_size: int, observation_space, action_space, device: Union[th.device, str] = "auto",
+                 n_envs: int = 1):
+        self.buffer_size = buffer_size
+        self.observation_space = as_box(observation_space)
+        self.action_space = as_box(action_space)
+        self.obs_shape = get_obs_shape(self.observation_space)
+        self.action_dim = get_action_dim(self.action_space)
+        self.device = get_device(device)
+        self.n_envs = n_envs
+        self._adds = 0  # host mirror of the device ring position (every add goes through this object)
+
+    @property
+    def pos(self) -> int:
+        return self._adds % self.buffer_size
+
+    @property
+    def full(self) -> bool:
+        return self._adds >= self.buffer_size
+
+    def size(self) -> int:
+        """reference: buffers.py:69-75"""
+        return self.buffer_size if self.full else self.pos
+
+    def reset(self) -> None:
+        raise NotImplementedError
+
+    def to_torch(self, array, copy: bool = True) -> th.Tensor:
+        """reference: buffers.py:128-140"""
+        if isinstance(array, th.Tensor):
+            return array.to(self.device, th.float32)
+        return th.tensor(array, device=self.device, dtype=th.float32) if copy else th.as_tensor(array, device=self.device, dtype=th.float32)
+
+
+class ReplayBuffer(BaseBuffer):
+    """reference: core/common/buffers.py:158-340.
+
+    :param buffer_size: max number of transitions; the ring has `max(buffer_size // n_envs, 1)` rows (:198)
+    :param sampler_stream: optional private MT19937 state (uint32[625] as int32, HBM); default = the device image of
+        NumPy's global legacy stream (`np.random.randint`, :113/:309)
+    """
+
+    def __init__(self, buffer_size: int, observation_space, action_space, device: Union[th.device, str] = "auto",
+                 n_envs: int = 1, optimize_memory_usage: bool = False, handle_timeout_termination: bool = True,
+                 sampler_stream: Optional[th.Tensor] = None):
+        super().__init__(buffer_size, observation_space, action_space, device, n_envs=n_envs)
+        self.buffer_size = max(buffer_size // n_envs, 1)  # :198
+        if optimize_memory_usage and handle_timeout_termination:
+            raise ValueError("ReplayBuffer does not support optimize_memory_usage = True "
+                             "and handle_timeout_termination = True simultaneously.")  # :206-210
+        if optimize_memory_usage:
+            raise NotImplementedError("optimize_memory_usage=True is not built (incompatible with timeout handling, "
+                                      "which the CSTR path needs; SURVEY a-9)")
+        self.optimize_memory_usage = optimize_memory_usage
+        self.handle_timeout_termination = handle_timeout_termination
+        if len(self.obs_shape) != 1:
+            raise ValueError(f"ReplayBuffer supports flat Box observations, got shape {self.obs_shape}")
+        with th.cuda.device(self.device):
+            self.ring = hip_ops.DeviceRing(self.buffer_size, n_envs, self.obs_shape[0], self.action_dim, self.device)
+        r = self.ring
+        self.observations, self.next_observations, self.actions = r.observations, r.next_observations, r.actions
+        self.rewards, self.dones, self.timeouts = r.rewards, r.dones, r.timeouts
+        self._stream = sampler_stream
+
+    # ---- sampler stream ---------------------------------------------------------------------------------
+    @property
+    def sampler_stream(self) -> th.Tensor:
+        return self._stream if self._stream is not None else legacy_rng.global_stream(self.device)
+
+    def seed_sampler(self, seed: int) -> None:
+        """Give this buffer a private stream = np.random.RandomState(seed) (data-parallel shards, tests)."""
+        self._stream = legacy_rng.new_stream(seed, self.device)
+
+    # ---- add --------------------------------------------------------------------------------------------
+    def _dev(self, x, shape) -> th.Tensor:
+        if isinstance(x, th.Tensor):
+            t = x.to(self.device, th.float32)
+        else:
+            t = th.as_tensor(np.ascontiguousarray(np.asarray(x), dtype=np.float32)).to(self.device)
+        return t.reshape(shape).contiguous()
+
+    def add(self, obs, next_obs, action, reward, done, infos: Optional[list]) -> None:
+        """reference: buffers.py:247-283. Accepts NumPy (compatibility) or device tensors. `infos` may be the
+        reference's list of dicts or a device/NumPy vector of timeout flags."""
+        n = self.n_envs
+        if infos is None or not self.handle_timeout_termination:
+            timeout = th.zeros(n, dtype=th.float32, device=self.device)
+        elif isinstance(infos, (th.Tensor, np.ndarray)):
+            timeout = self._dev(infos, (n,))
+        else:
+            timeout = self._dev(np.array([info.get("TimeLimit.truncated", False) for info in infos]), (n,))  # :277-278
+        with th.cuda.device(self.device):
+            hip_ops.replay_add(self.ring, self._dev(obs, (n, *self.obs_shape)), self._dev(next_obs, (n, *self.obs_shape)),
+                               self._dev(action, (n, self.action_dim)), self._dev(reward, (n,)), self._dev(done, (n,)),
+                               timeout)
+        self._adds += 1
+
+    def note_fused_add(self) -> None:
+        """The fused collect kernel wrote a row and advanced the device position; keep the host mirror in step."""
+        self._adds += 1
+
+    def reset(self) -> None:
+        self._adds = 0
+        self.ring.ctl.zero_()
+
+    # ---- sample -----------------------------------------------------------------------------------------
+    def alloc_batch(self, batch_size: int):
+        d, a, dev = self.obs_shape[0], self.action_dim, self.device
+        e = lambda *s: th.empty(*s, dtype=th.float32, device=dev)  # noqa: E731
+        return ReplayBufferSamples(e(batch_size, d), e(batch_size, a), e(batch_size, d), e(batch_size, 1), e(batch_size, 1))
+
+    def sample_into(self, out: ReplayBufferSamples, row_idx=None, env_idx=None) -> ReplayBufferSamples:
+        """`sample` into caller-owned (static, graph-capturable) tensors."""
+        if self.size() == 0:
+            raise ValueError("high <= 0")  # what np.random.randint(0, 0) raises in the reference (:113)
+        with th.cuda.device(self.device):
+            hip_ops.replay_sample(self.ring, self.sampler_stream, out.observations.shape[0], out.observations, out.actions,
+                                  out.next_observations, out.dones, out.rewards, row_idx, env_idx)
+        return out
+
+    def sample(self, batch_size: int, env: Any = None) -> ReplayBufferSamples:
+        """reference: buffers.py:106-115, :285-325. Returns fresh device tensors
+        (observations, actions, next_observations, dones, rewards)."""
+        if env is not None:
+            raise NotImplementedError("VecNormalize is out of scope for the CSTR path (SURVEY 2); pass env=None")
+        return self.sample_into(self.alloc_batch(batch_size))
+
+    def sample_with_indices(self, batch_size: int):
+        bi = th.empty(batch_size, dtype=th.int64, device=self.device)
+        ei = th.empty(batch_size, dtype=th.int64, device=self.device)
+        return self.sample_into(self.alloc_batch(batch_size), bi, ei), bi, ei

@@ -1,0 +1,73 @@
+"""Data-parallel plumbing: one process per GPU, `torch.distributed` (backend "nccl" = RCCL over xGMI on
+ROCm, "gloo" in CPU tests). The reference has no distributed code at all; the design is
+SURVEY 8e: every rank owns n_envs environments, its own replay ring and its own sampler stream; the only
+exchange is ONE summing all-reduce per optimiser step on that optimiser's flat gradient arena. The 1/world
+scale is folded into the Adam kernel (`grad_scale`), so gradient averaging costs no extra pass.
+
+Message sizes are tiny (SAC: 4 B, 543 KB, 272 KB per step): the collective is latency-bound, not xGMI
+link-bound, so the three dependent all-reduces are issued as-is on the training stream and RCCL picks its
+low-latency (tree / one-shot) protocol; no bucketing beyond the per-optimiser arena is useful.
+"""
+import os
+from typing import Optional, Tuple
+
+import torch as th
+import torch.distributed as dist
+
+
+def is_distributed() -> bool:
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def rank_world() -> Tuple[int, int]:
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
+    """Initialise from the torchrun environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*). Returns
+    (rank, local_rank, world). No-op for a single process."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend is None:
+            backend = "nccl" if th.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            th.cuda.set_device(local_rank)
+            dist.init_process_group(backend, rank=rank, world_size=world, device_id=th.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    return rank, local_rank, world
+
+
+def shard_seed(seed: Optional[int], rank: int, n_envs: int) -> Optional[int]:
+    """seed_r = seed + rank * n_envs: env i of rank r gets seed_r + i -- the globally unique seeds a single
+    process with world * n_envs envs would hand out (reference base_vec_env.py:308); the rank's sampler stream
+    ends up seeded seed_r + n_envs - 1 like an independent reference run with seed = seed_r."""
+    return None if seed is None else seed + rank * n_envs
+
+
+def allreduce_sum_(flat: th.Tensor) -> th.Tensor:
+    """In-place summing all-reduce of one flat gradient arena (no-op for world 1)."""
+    if is_distributed():
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    return flat
+
+
+def broadcast_(t: th.Tensor, src: int = 0) -> th.Tensor:
+    if is_distributed():
+        dist.broadcast(t, src=src)
+    return t
+
+
+def allreduce_mean_scalar(x: float) -> float:
+    if not is_distributed():
+        return x
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    t = th.tensor([x], dtype=th.float64, device=dev)
+    dist.all_reduce(t)
+    return float(t) / dist.get_world_size()

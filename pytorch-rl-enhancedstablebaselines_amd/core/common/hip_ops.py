@@ -79,13 +79,17 @@ def replay_add(ring: DeviceRing, obs, next_obs, act, rew, done, timeout):
 
 
 def collect_step(coef, integrator: str, ring: DeviceRing, env_obs, step_count, policy_out, squashed: bool, act_low,
-                 act_high, noise=None, reset_obs=None, pcg_state=None, reward_out=None, done_out=None):
+                 act_high, noise=None, reset_obs=None, pcg_state=None, reward_out=None, done_out=None, ep_return=None,
+                 ep_stats=None):
     n, d = ring.n_envs, ring.obs_dim
     _chk(env_obs, "env_obs", (n, d), th.float32), _chk(step_count, "step_count", (n,), th.int32)
     _chk(policy_out, "policy_out", (n, 2), th.float32)
     _opt(noise, "noise", (n, 2), th.float32), _opt(reset_obs, "reset_obs", (n, d), th.float32)
     _opt(pcg_state, "pcg_state", (n, nv.PCG_STATE_WORDS), th.int64)
     _opt(reward_out, "reward_out", (n,), th.float32), _opt(done_out, "done_out", (n,), th.float32)
+    _opt(ep_return, "ep_return", (n,), th.float32), _opt(ep_stats, "ep_stats", (4,), th.float64)
+    if (ep_return is None) != (ep_stats is None):
+        raise ValueError("ep_return and ep_stats go together")
     if (reset_obs is None) == (pcg_state is None):
         raise ValueError("collect_step needs exactly one reset source: reset_obs or pcg_state")
     lo = (C.c_float * 2)(float(act_low[0]), float(act_low[1]))
@@ -93,7 +97,7 @@ def collect_step(coef, integrator: str, ring: DeviceRing, env_obs, step_count, p
     check(nv.lib().cstr_collect_step_f32(C.byref(coef), C.c_int(INTEGRATORS[integrator]), C.byref(ring.c), ptr(ring.ctl),
                                          ptr(env_obs), ptr(step_count), ptr(policy_out), C.c_int(int(squashed)), lo, hi,
                                          ptr(noise), ptr(reset_obs), ptr(pcg_state), ptr(reward_out), ptr(done_out),
-                                         stream_ptr()), "cstr_collect_step_f32")
+                                         ptr(ep_return), ptr(ep_stats), stream_ptr()), "cstr_collect_step_f32")
 
 
 def mt19937_seed(mt_state, seed: int):

@@ -1,0 +1,62 @@
+"""Exploration noise (reference: core/common/noise.py:9-174). NumPy draws on the host, like the reference
+(`np.random.normal` on the global legacy stream, :44-45). NOTE: the device replay sampler owns the HBM image of
+that stream, so host draws here do NOT advance it -- bit-faithful interleaving of noise and index draws is the
+"next" row SURVEY 8f-3; SAC (action_noise=None) and TD3's class default are unaffected."""
+import copy
+from typing import Iterable, Optional
+
+import numpy as np
+
+
+class ActionNoise:
+    def reset(self) -> None:
+        pass
+
+    def __call__(self) -> np.ndarray:
+        raise NotImplementedError
+
+
+class NormalActionNoise(ActionNoise):
+    def __init__(self, mean: np.ndarray, sigma: np.ndarray, dtype=np.float32):
+        self._mu, self._sigma, self._dtype = mean, sigma, dtype
+
+    def __call__(self) -> np.ndarray:
+        return np.random.normal(self._mu, self._sigma).astype(self._dtype)
+
+    def __repr__(self) -> str:
+        return f"NormalActionNoise(mu={self._mu}, sigma={self._sigma})"
+
+
+class OrnsteinUhlenbeckActionNoise(ActionNoise):
+    def __init__(self, mean, sigma, theta: float = 0.15, dt: float = 1e-2, initial_noise: Optional[np.ndarray] = None,
+                 dtype=np.float32):
+        self._theta, self._mu, self._sigma, self._dt, self._dtype = theta, mean, sigma, dt, dtype
+        self.initial_noise = initial_noise
+        self.noise_prev = np.zeros_like(self._mu)
+        self.reset()
+
+    def __call__(self) -> np.ndarray:
+        noise = (self.noise_prev + self._theta * (self._mu - self.noise_prev) * self._dt
+                 + self._sigma * np.sqrt(self._dt) * np.random.normal(size=self._mu.shape))
+        self.noise_prev = noise
+        return noise.astype(self._dtype)
+
+    def reset(self) -> None:
+        self.noise_prev = self.initial_noise if self.initial_noise is not None else np.zeros_like(self._mu)
+
+
+class VectorizedActionNoise(ActionNoise):
+    """reference: noise.py:108-174 -- one independent noise process per env"""
+
+    def __init__(self, base_noise: ActionNoise, n_envs: int):
+        self.n_envs = int(n_envs)
+        assert self.n_envs > 0
+        self.base_noise = base_noise
+        self.noises = [copy.deepcopy(base_noise) for _ in range(self.n_envs)]
+
+    def reset(self, indices: Optional[Iterable[int]] = None) -> None:
+        for i in (range(len(self.noises)) if indices is None else indices):
+            self.noises[i].reset()
+
+    def __call__(self) -> np.ndarray:
+        return np.stack([noise() for noise in self.noises])

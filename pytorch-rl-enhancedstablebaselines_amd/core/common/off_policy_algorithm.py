@@ -1,0 +1,277 @@
+"""`OffPolicyAlgorithm`: the collect -> store -> sample -> train runtime
+(reference: core/common/off_policy_algorithm.py:27-605), rebuilt around a device-resident loop.
+
+Reference iteration (per vec-step): python loop over N envs, deepcopy of N info dicts, 5 H2D copies per
+sample, 4 `.item()` syncs per gradient step. Here, when the env is a `CSTRVecEnv` and the buffer is the HBM
+`ReplayBuffer`, one iteration is: actor forward (PyTorch-ROCm, no_grad) -> ONE fused HIP launch
+(action scaling chain + env step + auto-reset + ring row write + episode statistics) -> `train()`. Nothing
+returns to the host except, every `stats_sync_interval` vec-steps, four doubles of episode statistics.
+Any other VecEnv goes through the NumPy compatibility path with the reference's exact semantics.
+"""
+import sys
+import time
+from typing import Any, Optional, Union
+
+import numpy as np
+import torch as th
+
+from core.common import distributed as dist_util
+from core.common import hip_ops
+from core.common.base_class import BaseAlgorithm
+from core.common.buffers import ReplayBuffer
+from core.common.callbacks import BaseCallback, MaybeCallback
+from core.common.type_aliases import RolloutReturn, TrainFreq, TrainFrequencyUnit
+from core.common.utils import should_collect_more_steps
+from core.common.vec_env import CSTRVecEnv, VecEnv
+
+
+class OffPolicyAlgorithm(BaseAlgorithm):
+    def __init__(self, policy, env, learning_rate, buffer_size: int = 1_000_000, learning_starts: int = 100,
+                 batch_size: int = 256, tau: float = 0.005, gamma: float = 0.99, train_freq: Union[int, tuple] = (1, "step"),
+                 gradient_steps: int = 1, action_noise=None, replay_buffer_class=None, replay_buffer_kwargs: Optional[dict] = None,
+                 optimize_memory_usage: bool = False, policy_kwargs: Optional[dict] = None, stats_window_size: int = 100,
+                 tensorboard_log: Optional[str] = None, verbose: int = 0, device="auto", support_multi_env: bool = False,
+                 monitor_wrapper: bool = True, seed: Optional[int] = None, use_sde: bool = False, sde_sample_freq: int = -1,
+                 use_sde_at_warmup: bool = False, sde_support: bool = True, supported_action_spaces: Optional[tuple] = None):
+        super().__init__(policy=policy, env=env, learning_rate=learning_rate, policy_kwargs=policy_kwargs,
+                         stats_window_size=stats_window_size, tensorboard_log=tensorboard_log, verbose=verbose, device=device,
+                         support_multi_env=support_multi_env, monitor_wrapper=monitor_wrapper, seed=seed, use_sde=use_sde,
+                         sde_sample_freq=sde_sample_freq, supported_action_spaces=supported_action_spaces)
+        self.buffer_size = buffer_size
+        self.batch_size = batch_size
+        self.learning_starts = learning_starts
+        self.tau = tau
+        self.gamma = gamma
+        self.gradient_steps = gradient_steps
+        self.action_noise = action_noise
+        self.optimize_memory_usage = optimize_memory_usage
+        self.replay_buffer: Optional[ReplayBuffer] = None
+        self.replay_buffer_class = replay_buffer_class
+        self.replay_buffer_kwargs = replay_buffer_kwargs or {}
+        self.train_freq = train_freq
+        self.use_sde_at_warmup = use_sde_at_warmup
+        self.stats_sync_interval = 100   # vec-steps between host reads of the device episode counters
+        self._steps_since_sync = 0
+        self._episodes_at_last_dump = 0
+        self._ep_window = (0.0, 0.0, 0.0)
+
+    # ---- setup ----------------------------------------------------------------------------------------------------
+    def _convert_train_freq(self) -> None:
+        """reference: off_policy_algorithm.py:148-170"""
+        if not isinstance(self.train_freq, TrainFreq):
+            train_freq = self.train_freq
+            if not isinstance(train_freq, tuple):
+                train_freq = (train_freq, "step")
+            try:
+                train_freq = (train_freq[0], TrainFrequencyUnit(train_freq[1]))
+            except ValueError as e:
+                raise ValueError(f"The unit of the `train_freq` must be either 'step' or 'episode' not '{train_freq[1]}'!") from e
+            if not isinstance(train_freq[0], int):
+                raise ValueError(f"The frequency of `train_freq` must be an integer and not {train_freq[0]}")
+            self.train_freq = TrainFreq(*train_freq)
+
+    def _setup_model(self) -> None:
+        """reference: off_policy_algorithm.py:172-212"""
+        self._setup_lr_schedule()
+        if self.world_size > 1 and isinstance(self.env, CSTRVecEnv):
+            self.env.seed_offset = self.rank * self.n_envs  # seed_r = seed + rank * n_envs
+        self.set_random_seed(self.seed)
+        if self.replay_buffer_class is None:
+            self.replay_buffer_class = ReplayBuffer
+        if self.replay_buffer is None:
+            kw = dict(self.replay_buffer_kwargs)
+            self.replay_buffer = self.replay_buffer_class(self.buffer_size, self.observation_space, self.action_space,
+                                                          device=self.device, n_envs=self.n_envs,
+                                                          optimize_memory_usage=self.optimize_memory_usage, **kw)
+        # built on the CPU generator in the reference's construction order (same seed -> same initial weights),
+        # then moved into the HBM arenas by the policy itself
+        self.policy = self.policy_class(self.observation_space, self.action_space, self.lr_schedule, **self.policy_kwargs)
+        self.policy.to_device_arenas(self.device)
+        if self.world_size > 1:
+            self.policy.broadcast_from_rank0()
+            for opt in self.policy.flat_optimizers():
+                opt.grad_scale = 1.0 / self.world_size
+            if self.seed is not None:  # same init everywhere, different exploration noise per shard
+                th.manual_seed(self.seed + 1000003 * self.rank)
+        self._convert_train_freq()
+        n = self.n_envs
+        self._ep_return = th.zeros(n, dtype=th.float32, device=self.device)
+        self._ep_stats = th.zeros(4, dtype=th.float64, device=self.device)
+
+    def _fast_path(self) -> bool:
+        rb = self.replay_buffer
+        return (isinstance(self.env, CSTRVecEnv) and type(rb) is ReplayBuffer and rb.n_envs == self.env.num_envs
+                and rb.obs_shape[0] == self.env.obs_dim and self._vec_normalize_env is None)
+
+    # ---- learn ----------------------------------------------------------------------------------------------------
+    def _setup_learn(self, total_timesteps, callback=None, reset_num_timesteps=True, tb_log_name="run", progress_bar=False):
+        if self.action_noise is not None and self.env.num_envs > 1 and not hasattr(self.action_noise, "noises"):
+            from core.common.noise import VectorizedActionNoise
+
+            self.action_noise = VectorizedActionNoise(self.action_noise, self.env.num_envs)
+        return super()._setup_learn(total_timesteps, callback, reset_num_timesteps, tb_log_name, progress_bar)
+
+    def learn(self, total_timesteps: int, callback: MaybeCallback = None, log_interval: int = 4, tb_log_name: str = "run",
+              reset_num_timesteps: bool = True, progress_bar: bool = False):
+        """reference: off_policy_algorithm.py:309-355"""
+        total_timesteps, callback = self._setup_learn(total_timesteps, callback, reset_num_timesteps, tb_log_name, progress_bar)
+        callback.on_training_start(locals(), globals())
+        assert self.env is not None, "You must set the environment before calling learn()"
+        assert isinstance(self.train_freq, TrainFreq)
+        while self.num_timesteps < total_timesteps:
+            rollout = self.collect_rollouts(self.env, train_freq=self.train_freq, action_noise=self.action_noise,
+                                            callback=callback, learning_starts=self.learning_starts,
+                                            replay_buffer=self.replay_buffer, log_interval=log_interval)
+            if not rollout.continue_training:
+                break
+            if self.num_timesteps > 0 and self.num_timesteps > self.learning_starts:
+                gradient_steps = self.gradient_steps if self.gradient_steps >= 0 else rollout.episode_timesteps
+                if gradient_steps > 0:
+                    self.train(batch_size=self.batch_size, gradient_steps=gradient_steps)
+        if self._fast_path():
+            self._sync_episode_stats(log_interval, force=True)
+        callback.on_training_end()
+        return self
+
+    # ---- action selection -----------------------------------------------------------------------------------------
+    def _policy_out_device(self, obs: th.Tensor) -> th.Tensor:
+        """Actor output for the fused collect kernel: squashed ([-1,1]) action, device tensor [N, A], no grad."""
+        with th.no_grad():
+            return self.policy._predict(obs, deterministic=False).contiguous()
+
+    def _sample_action(self, learning_starts: int, action_noise=None, n_envs: int = 1):
+        """reference: off_policy_algorithm.py:364-411 (NumPy compatibility path)"""
+        if self.num_timesteps < learning_starts:
+            unscaled_action = self.action_space.sample_batch(n_envs)
+        else:
+            assert self._last_obs is not None, "self._last_obs was not set"
+            unscaled_action, _ = self.predict(self._last_obs, deterministic=False)
+        scaled_action = self.policy.scale_action(unscaled_action)
+        if action_noise is not None:
+            scaled_action = np.clip(scaled_action + action_noise(), -1, 1)
+        buffer_action = scaled_action
+        action = self.policy.unscale_action(scaled_action)
+        return action, buffer_action
+
+    # ---- logging ---------------------------------------------------------------------------------------------------
+    def _dump_logs(self) -> None:
+        """reference: off_policy_algorithm.py:413-438"""
+        time_elapsed = max((time.time_ns() - self.start_time) / 1e9, sys.float_info.epsilon)
+        fps = int((self.num_timesteps - self._num_timesteps_at_start) / time_elapsed)
+        if self.world_size > 1:
+            fps *= self.world_size  # whole-job env-steps/s: every rank advances n_envs per vec-step
+        self.logger.record("time/episodes", self._episode_num, exclude="tensorboard")
+        n_ep, ret_sum, len_sum = self._ep_window
+        if n_ep > 0:
+            self.logger.record("rollout/ep_rew_mean", ret_sum / n_ep)
+            self.logger.record("rollout/ep_len_mean", len_sum / n_ep)
+        self.logger.record("time/fps", fps)
+        self.logger.record("time/time_elapsed", int(time_elapsed), exclude="tensorboard")
+        self.logger.record("time/total_timesteps", self.num_timesteps, exclude="tensorboard")
+        self.logger.dump(step=self.num_timesteps)
+
+    def _sync_episode_stats(self, log_interval: Optional[int], force: bool = False) -> None:
+        """One blocking read of four doubles (episodes, sum of returns, sum of lengths). The reference learns about
+        finished episodes from the host-side `dones` every vec-step (:590-602); here the counters live in HBM."""
+        self._steps_since_sync += 1
+        if not force and self._steps_since_sync < self.stats_sync_interval:
+            return
+        self._steps_since_sync = 0
+        n_ep, ret_sum, len_sum, _ = self._ep_stats.cpu().tolist()
+        self._episode_num = int(n_ep)
+        done_since = self._episode_num - self._episodes_at_last_dump
+        if log_interval is not None and done_since >= log_interval:
+            w0, w1, w2 = getattr(self, "_ep_totals_at_dump", (0.0, 0.0, 0.0))
+            self._ep_window = (n_ep - w0, ret_sum - w1, len_sum - w2)
+            self._ep_totals_at_dump = (n_ep, ret_sum, len_sum)
+            self._episodes_at_last_dump = self._episode_num
+            self._dump_logs()
+
+    def _on_step(self) -> None:
+        pass
+
+    # ---- storage (compatibility path) ------------------------------------------------------------------------------
+    def _store_transition(self, replay_buffer, buffer_action, new_obs, reward, dones, infos) -> None:
+        """reference: off_policy_algorithm.py:445-508"""
+        next_obs = np.array(new_obs, copy=True)
+        for i, done in enumerate(dones):
+            if done and infos[i].get("terminal_observation") is not None:
+                next_obs[i] = infos[i]["terminal_observation"]
+        replay_buffer.add(self._last_obs, next_obs, buffer_action, reward, dones, infos)
+        self._last_obs = new_obs
+
+    # ---- rollouts --------------------------------------------------------------------------------------------------
+    def collect_rollouts(self, env: VecEnv, callback: BaseCallback, train_freq: TrainFreq, replay_buffer: ReplayBuffer,
+                         action_noise=None, learning_starts: int = 0, log_interval: Optional[int] = None) -> RolloutReturn:
+        """reference: off_policy_algorithm.py:510-605"""
+        self.policy.set_training_mode(False)
+        num_collected_steps, num_collected_episodes = 0, 0
+        assert train_freq.frequency > 0, "Should at least collect one step or episode."
+        if env.num_envs > 1:
+            assert train_freq.unit == TrainFrequencyUnit.STEP, "You must use only one env when doing episodic training."
+        fast = self._fast_path() and train_freq.unit == TrainFrequencyUnit.STEP
+        noop_cb = getattr(callback, "is_noop", False)
+        callback.on_rollout_start()
+        continue_training = True
+        while should_collect_more_steps(train_freq, num_collected_steps, num_collected_episodes):
+            if fast:
+                self._collect_one_fused(env, replay_buffer, action_noise, learning_starts)
+                new_obs, rewards, dones = env.obs, env._rew, env._done  # device tensors (for callbacks)
+                infos: Any = None
+            else:
+                if isinstance(self._last_obs, th.Tensor):
+                    self._last_obs = self._last_obs.cpu().numpy()
+                actions, buffer_actions = self._sample_action(learning_starts, action_noise, env.num_envs)
+                new_obs, rewards, dones, infos = env.step(actions)
+            self.num_timesteps += env.num_envs
+            num_collected_steps += 1
+            if not noop_cb:
+                callback.update_locals(locals())
+            if not callback.on_step():
+                return RolloutReturn(num_collected_steps * env.num_envs, num_collected_episodes, continue_training=False)
+            if not fast:
+                self._store_transition(replay_buffer, buffer_actions, new_obs, rewards, dones, infos)
+            self._update_current_progress_remaining(self.num_timesteps, self._total_timesteps)
+            self._on_step()
+            if fast:
+                self._sync_episode_stats(log_interval)
+            else:
+                for idx, done in enumerate(dones):
+                    if done:
+                        num_collected_episodes += 1
+                        self._episode_num += 1
+                        if action_noise is not None:
+                            kwargs = dict(indices=[idx]) if env.num_envs > 1 else {}
+                            action_noise.reset(**kwargs)
+                        if log_interval is not None and self._episode_num % log_interval == 0:
+                            self._dump_logs()
+        callback.on_rollout_end()
+        return RolloutReturn(num_collected_steps * env.num_envs, num_collected_episodes, continue_training)
+
+    def _collect_one_fused(self, env: CSTRVecEnv, rb: ReplayBuffer, action_noise, learning_starts: int) -> None:
+        """One vec-step entirely in HBM: reference statements :561 (_sample_action), :564 (env.step), :580
+        (_store_transition -> ReplayBuffer.add) in one HIP launch after the actor forward."""
+        n = env.num_envs
+        if self.num_timesteps < learning_starts:
+            # warm-up: uniform actions from the action space's own generator (:386-388); drawn on the host
+            pol = th.as_tensor(self.action_space.sample_batch(n)).to(self.device)
+            squashed = False
+        else:
+            pol = self._policy_out_device(env.obs)
+            squashed = True
+        noise = None
+        if action_noise is not None:
+            z = action_noise()
+            noise = z if isinstance(z, th.Tensor) else th.as_tensor(np.asarray(z, np.float32))
+            noise = noise.to(self.device, th.float32).reshape(n, -1).contiguous()
+        with th.cuda.device(self.device):
+            hip_ops.collect_step(env.coef, env.integrator, rb.ring, env.obs, env.step_count, pol, squashed,
+                                 self.action_space.low, self.action_space.high, noise=noise, pcg_state=env.pcg_state,
+                                 reward_out=env._rew, done_out=env._done, ep_return=self._ep_return, ep_stats=self._ep_stats)
+        rb.note_fused_add()
+        self._last_obs = env.obs
+
+    # ---- data-parallel helper used by train() ----------------------------------------------------------------------
+    def _allreduce_grads(self, arena) -> None:
+        if self.world_size > 1:
+            dist_util.allreduce_sum_(arena.grad)

@@ -1,0 +1,161 @@
+"""Soft Actor-Critic with the reference's constructor and `train()` arithmetic (reference: core/sac/sac.py:21-340).
+
+One gradient step = HIP sampler (bit-exact indices + gather) -> actor/critic MLP forward/backward on
+PyTorch-ROCm -> HIP `td_target_min` -> three one-launch Adam steps on flat arenas (RCCL all-reduce of each
+arena's gradient first when data-parallel) -> one-launch polyak. Losses stay on the device: the reference's
+four `.item()` syncs per step (:232, :236, :263, :276) are replaced by device-side running sums that the
+logger resolves only when it dumps.
+"""
+from typing import Optional, Union
+
+import numpy as np
+import torch as th
+from torch.nn import functional as F
+
+from core.common import hip_ops
+from core.common.arena import FlatAdam, ParamArena
+from core.common.logger import DeviceMean
+from core.common.off_policy_algorithm import OffPolicyAlgorithm
+from core.sac.policies import MlpPolicy, SACPolicy
+
+
+class SAC(OffPolicyAlgorithm):
+    policy_aliases = {"MlpPolicy": MlpPolicy}
+
+    def __init__(self, policy, env, learning_rate=3e-4, buffer_size: int = 1_000_000, learning_starts: int = 100,
+                 batch_size: int = 256, tau: float = 0.005, gamma: float = 0.99, train_freq: Union[int, tuple] = 1,
+                 gradient_steps: int = 1, action_noise=None, replay_buffer_class=None, replay_buffer_kwargs: Optional[dict] = None,
+                 optimize_memory_usage: bool = False, ent_coef: Union[str, float] = "auto", target_update_interval: int = 1,
+                 target_entropy: Union[str, float] = "auto", use_sde: bool = False, sde_sample_freq: int = -1,
+                 use_sde_at_warmup: bool = False, stats_window_size: int = 100, tensorboard_log: Optional[str] = None,
+                 policy_kwargs: Optional[dict] = None, verbose: int = 0, seed: Optional[int] = None, device="auto",
+                 _init_setup_model: bool = True):
+        super().__init__(policy, env, learning_rate, buffer_size, learning_starts, batch_size, tau, gamma, train_freq,
+                         gradient_steps, action_noise, replay_buffer_class=replay_buffer_class,
+                         replay_buffer_kwargs=replay_buffer_kwargs, policy_kwargs=policy_kwargs,
+                         stats_window_size=stats_window_size, tensorboard_log=tensorboard_log, verbose=verbose, device=device,
+                         seed=seed, use_sde=use_sde, sde_sample_freq=sde_sample_freq, use_sde_at_warmup=use_sde_at_warmup,
+                         optimize_memory_usage=optimize_memory_usage, supported_action_spaces=(object,), support_multi_env=True)
+        self.target_entropy = target_entropy
+        self.log_ent_coef: Optional[th.Tensor] = None
+        self.ent_coef = ent_coef
+        self.target_update_interval = target_update_interval
+        self.ent_coef_optimizer = None
+        self.debug_capture = False   # tests: keep target_q / current_q of the last gradient step
+        self.last_train_tensors: dict = {}
+        if _init_setup_model:
+            self._setup_model()
+
+    def _setup_model(self) -> None:
+        """reference: sac.py:159-192"""
+        super()._setup_model()
+        self._create_aliases()
+        if self.target_entropy == "auto":
+            self.target_entropy = float(-np.prod(self.env.action_space.shape).astype(np.float32))
+        else:
+            self.target_entropy = float(self.target_entropy)
+        if isinstance(self.ent_coef, str) and self.ent_coef.startswith("auto"):
+            init_value = 1.0
+            if "_" in self.ent_coef:
+                init_value = float(self.ent_coef.split("_")[1])
+                assert init_value > 0.0, "The initial value of ent_coef must be greater than 0"
+            p = th.nn.Parameter(th.log(th.ones(1) * init_value))
+            self._ent_arena = ParamArena([p], self.device)
+            self.log_ent_coef = p
+            self.ent_coef_optimizer = FlatAdam(self._ent_arena, lr=self.lr_schedule(1))
+            if self.world_size > 1:
+                self.ent_coef_optimizer.grad_scale = 1.0 / self.world_size
+        else:
+            self.ent_coef_tensor = th.tensor(float(self.ent_coef), device=self.device)
+        z = lambda: th.zeros((), dtype=th.float32, device=self.device)  # noqa: E731
+        self._loss_sums = dict(actor=z(), critic=z(), ent_coef_loss=z(), ent_coef=z())
+        self._static_batch = None
+
+    def _create_aliases(self) -> None:
+        self.actor = self.policy.actor
+        self.critic = self.policy.critic
+        self.critic_target = self.policy.critic_target
+
+    def _batch(self, batch_size: int):
+        if self._static_batch is None or self._static_batch.observations.shape[0] != batch_size:
+            self._static_batch = self.replay_buffer.alloc_batch(batch_size)
+            self._target_q = th.empty(batch_size, 1, dtype=th.float32, device=self.device)
+        return self._static_batch
+
+    def train(self, gradient_steps: int, batch_size: int = 64) -> None:
+        """reference: sac.py:199-296"""
+        self.policy.set_training_mode(True)
+        optimizers = [self.actor.optimizer, self.critic.optimizer]
+        if self.ent_coef_optimizer is not None:
+            optimizers += [self.ent_coef_optimizer]
+        self._update_learning_rate(optimizers)
+        for v in self._loss_sums.values():
+            v.zero_()
+        for gradient_step in range(gradient_steps):
+            self._gradient_step(batch_size, gradient_step)
+        self._n_updates += gradient_steps
+        s = self._loss_sums
+        self.logger.record("train/n_updates", self._n_updates, exclude="tensorboard")
+        self.logger.record("train/ent_coef", DeviceMean(s["ent_coef"].clone(), gradient_steps))
+        self.logger.record("train/actor_loss", DeviceMean(s["actor"].clone(), gradient_steps))
+        self.logger.record("train/critic_loss", DeviceMean(s["critic"].clone(), gradient_steps))
+        if self.ent_coef_optimizer is not None:
+            self.logger.record("train/ent_coef_loss", DeviceMean(s["ent_coef_loss"].clone(), gradient_steps))
+
+    def _gradient_step(self, batch_size: int, gradient_step: int) -> None:
+        s = self._loss_sums
+        replay_data = self.replay_buffer.sample_into(self._batch(batch_size))  # :215
+
+        actions_pi, log_prob = self.actor.action_log_prob(replay_data.observations)  # :222
+        log_prob = log_prob.reshape(-1, 1)
+
+        if self.ent_coef_optimizer is not None and self.log_ent_coef is not None:
+            ent_coef = th.exp(self.log_ent_coef.detach())  # :230
+            ent_coef_loss = -(self.log_ent_coef * (log_prob + self.target_entropy).detach()).mean()
+            s["ent_coef_loss"] += ent_coef_loss.detach()
+            self.ent_coef_optimizer.zero_grad()  # :240-243
+            ent_coef_loss.backward()
+            self._allreduce_grads(self._ent_arena)
+            self.ent_coef_optimizer.step()
+        else:
+            ent_coef = self.ent_coef_tensor.reshape(1)
+        s["ent_coef"] += ent_coef.reshape(())
+
+        with th.no_grad():  # :245-254
+            next_actions, next_log_prob = self.actor.action_log_prob(replay_data.next_observations)
+            q1_t, q2_t = self.critic_target(replay_data.next_observations, next_actions)[:2]
+            if len(self.critic_target.q_networks) != 2:
+                raise NotImplementedError("td_target_min kernel is built for n_critics=2 (the reference default)")
+            target_q_values = self._target_q
+            hip_ops.td_target_min(q1_t.contiguous(), q2_t.contiguous(), next_log_prob.reshape(-1, 1).contiguous(),
+                                  replay_data.rewards, replay_data.dones, ent_coef.contiguous(), self.gamma, target_q_values)
+
+        current_q_values = self.critic(replay_data.observations, replay_data.actions)  # :258
+        critic_loss = 0.5 * sum(F.mse_loss(current_q, target_q_values) for current_q in current_q_values)  # :261
+        s["critic"] += critic_loss.detach()
+        self.critic.optimizer.zero_grad()  # :266-268
+        critic_loss.backward()
+        self._allreduce_grads(self.policy.critic_arena)
+        self.critic.optimizer.step()
+
+        q_values_pi = th.cat(self.critic(replay_data.observations, actions_pi), dim=1)  # :273-275
+        min_qf_pi, _ = th.min(q_values_pi, dim=1, keepdim=True)
+        actor_loss = (ent_coef * log_prob - min_qf_pi).mean()
+        s["actor"] += actor_loss.detach()
+        self.actor.optimizer.zero_grad()  # :279-281
+        actor_loss.backward()
+        self._allreduce_grads(self.policy.actor_arena)
+        self.actor.optimizer.step()
+
+        if gradient_step % self.target_update_interval == 0:  # :284-287 (no batch-norm stats in MLPs)
+            self.policy.critic_target_arena.polyak_from(self.policy.critic_arena, self.tau)
+
+        if self.debug_capture:
+            self.last_train_tensors = dict(target_q=target_q_values.clone(), current_q=[q.detach().clone() for q in current_q_values],
+                                           critic_loss=critic_loss.detach().clone(), actor_loss=actor_loss.detach().clone(),
+                                           ent_coef=ent_coef.detach().clone(), log_prob=log_prob.detach().clone())
+
+    def learn(self, total_timesteps: int, callback=None, log_interval: int = 4, tb_log_name: str = "SAC",
+              reset_num_timesteps: bool = True, progress_bar: bool = False):
+        return super().learn(total_timesteps=total_timesteps, callback=callback, log_interval=log_interval,
+                             tb_log_name=tb_log_name, reset_num_timesteps=reset_num_timesteps, progress_bar=progress_bar)

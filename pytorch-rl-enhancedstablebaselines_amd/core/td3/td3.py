@@ -1,0 +1,122 @@
+"""TD3 (and DDPG as its special case) with the reference's constructor and `train()` arithmetic
+(reference: core/td3/td3.py:19-240, core/ddpg/ddpg.py:14-130)."""
+from typing import List, Optional, Union
+
+import torch as th
+from torch.nn import functional as F
+
+from core.common import hip_ops
+from core.common.logger import DeviceMean
+from core.common.off_policy_algorithm import OffPolicyAlgorithm
+from core.td3.policies import MlpPolicy
+
+
+class TD3(OffPolicyAlgorithm):
+    policy_aliases = {"MlpPolicy": MlpPolicy}
+
+    def __init__(self, policy, env, learning_rate=1e-3, buffer_size: int = 1_000_000, learning_starts: int = 100,
+                 batch_size: int = 256, tau: float = 0.005, gamma: float = 0.99, train_freq: Union[int, tuple] = 1,
+                 gradient_steps: int = 1, action_noise=None, replay_buffer_class=None, replay_buffer_kwargs: Optional[dict] = None,
+                 optimize_memory_usage: bool = False, policy_delay: int = 2, target_policy_noise: float = 0.2,
+                 target_noise_clip: float = 0.5, stats_window_size: int = 100, tensorboard_log: Optional[str] = None,
+                 policy_kwargs: Optional[dict] = None, verbose: int = 0, seed: Optional[int] = None, device="auto",
+                 _init_setup_model: bool = True):
+        super().__init__(policy, env, learning_rate, buffer_size, learning_starts, batch_size, tau, gamma, train_freq,
+                         gradient_steps, action_noise=action_noise, replay_buffer_class=replay_buffer_class,
+                         replay_buffer_kwargs=replay_buffer_kwargs, policy_kwargs=policy_kwargs,
+                         stats_window_size=stats_window_size, tensorboard_log=tensorboard_log, verbose=verbose, device=device,
+                         seed=seed, sde_support=False, optimize_memory_usage=optimize_memory_usage,
+                         supported_action_spaces=(object,), support_multi_env=True)
+        self.policy_delay = policy_delay
+        self.target_noise_clip = target_noise_clip
+        self.target_policy_noise = target_policy_noise
+        self.debug_capture = False
+        self.last_train_tensors: dict = {}
+        self.noise_queue: List[th.Tensor] = []  # teacher-forcing hook for the target-smoothing noise (td3.py:169)
+        if _init_setup_model:
+            self._setup_model()
+
+    def _setup_model(self) -> None:
+        super()._setup_model()
+        self.actor, self.actor_target = self.policy.actor, self.policy.actor_target
+        self.critic, self.critic_target = self.policy.critic, self.policy.critic_target
+        z = lambda: th.zeros((), dtype=th.float32, device=self.device)  # noqa: E731
+        self._loss_sums = dict(actor=z(), critic=z())
+        self._static_batch = None
+
+    def _batch(self, batch_size: int):
+        if self._static_batch is None or self._static_batch.observations.shape[0] != batch_size:
+            self._static_batch = self.replay_buffer.alloc_batch(batch_size)
+            self._target_q = th.empty(batch_size, 1, dtype=th.float32, device=self.device)
+        return self._static_batch
+
+    def train(self, gradient_steps: int, batch_size: int = 100) -> None:
+        """reference: td3.py:154-211"""
+        self.policy.set_training_mode(True)
+        self._update_learning_rate([self.actor.optimizer, self.critic.optimizer])
+        for v in self._loss_sums.values():
+            v.zero_()
+        n_actor = 0
+        for _ in range(gradient_steps):
+            self._n_updates += 1
+            replay_data = self.replay_buffer.sample_into(self._batch(batch_size))
+            with th.no_grad():
+                if self.noise_queue:
+                    noise = self.noise_queue.pop(0).to(self.device)
+                else:
+                    noise = replay_data.actions.clone().normal_(0, self.target_policy_noise)  # :169
+                noise = noise.clamp(-self.target_noise_clip, self.target_noise_clip)
+                next_actions = (self.actor_target(replay_data.next_observations) + noise).clamp(-1, 1)
+                qs = self.critic_target(replay_data.next_observations, next_actions)
+                q1_t, q2_t = qs[0], qs[-1]  # n_critics == 1 (DDPG): min over one network
+                hip_ops.td_target_min(q1_t.contiguous(), q2_t.contiguous(), None, replay_data.rewards, replay_data.dones,
+                                      None, self.gamma, self._target_q)
+                target_q_values = self._target_q
+            current_q_values = self.critic(replay_data.observations, replay_data.actions)
+            critic_loss = sum(F.mse_loss(current_q, target_q_values) for current_q in current_q_values)  # no 0.5 (:182)
+            self._loss_sums["critic"] += critic_loss.detach()
+            self.critic.optimizer.zero_grad()
+            critic_loss.backward()
+            self._allreduce_grads(self.policy.critic_arena)
+            self.critic.optimizer.step()
+            actor_loss = None
+            if self._n_updates % self.policy_delay == 0:  # :192-206
+                actor_loss = -self.critic.q1_forward(replay_data.observations, self.actor(replay_data.observations)).mean()
+                self._loss_sums["actor"] += actor_loss.detach()
+                n_actor += 1
+                self.actor.optimizer.zero_grad()
+                actor_loss.backward()
+                self._allreduce_grads(self.policy.actor_arena)
+                self.actor.optimizer.step()
+                self.policy.critic_target_arena.polyak_from(self.policy.critic_arena, self.tau)
+                self.policy.actor_target_arena.polyak_from(self.policy.actor_arena, self.tau)
+            if self.debug_capture:
+                self.last_train_tensors = dict(target_q=target_q_values.clone(), current_q=[q.detach().clone() for q in current_q_values],
+                                               critic_loss=critic_loss.detach().clone(),
+                                               actor_loss=None if actor_loss is None else actor_loss.detach().clone())
+        self.logger.record("train/n_updates", self._n_updates, exclude="tensorboard")
+        if n_actor > 0:
+            self.logger.record("train/actor_loss", DeviceMean(self._loss_sums["actor"].clone(), n_actor))
+        self.logger.record("train/critic_loss", DeviceMean(self._loss_sums["critic"].clone(), gradient_steps))
+
+    def learn(self, total_timesteps: int, callback=None, log_interval: int = 4, tb_log_name: str = "TD3",
+              reset_num_timesteps: bool = True, progress_bar: bool = False):
+        return super().learn(total_timesteps=total_timesteps, callback=callback, log_interval=log_interval,
+                             tb_log_name=tb_log_name, reset_num_timesteps=reset_num_timesteps, progress_bar=progress_bar)
+
+
+class DDPG(TD3):
+    """reference: core/ddpg/ddpg.py:14-130 -- TD3 with policy_delay 1, one critic, no target smoothing."""
+
+    def __init__(self, policy, env, learning_rate=1e-3, buffer_size: int = 1_000_000, learning_starts: int = 100,
+                 batch_size: int = 256, tau: float = 0.005, gamma: float = 0.99, train_freq: Union[int, tuple] = 1,
+                 gradient_steps: int = 1, action_noise=None, replay_buffer_class=None, replay_buffer_kwargs=None,
+                 optimize_memory_usage: bool = False, tensorboard_log: Optional[str] = None, policy_kwargs: Optional[dict] = None,
+                 verbose: int = 0, seed: Optional[int] = None, device="auto", _init_setup_model: bool = True):
+        policy_kwargs = dict(policy_kwargs or {})
+        policy_kwargs.setdefault("n_critics", 1)
+        super().__init__(policy, env, learning_rate, buffer_size, learning_starts, batch_size, tau, gamma, train_freq,
+                         gradient_steps, action_noise, replay_buffer_class, replay_buffer_kwargs, optimize_memory_usage,
+                         policy_delay=1, target_policy_noise=0.0, target_noise_clip=0.0, tensorboard_log=tensorboard_log,
+                         policy_kwargs=policy_kwargs, verbose=verbose, seed=seed, device=device,
+                         _init_setup_model=_init_setup_model)

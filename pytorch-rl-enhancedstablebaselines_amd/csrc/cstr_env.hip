@@ -243,7 +243,8 @@ __global__ void collect_step_kernel(const cstr_coef_t k, const cstr_ring_t ring,
                                     const float *__restrict__ policy_out, const int squashed, const float lo0,
                                     const float hi0, const float lo1, const float hi1, const float *__restrict__ noise,
                                     const float *__restrict__ reset_obs, uint64_t *__restrict__ pcg,
-                                    float *__restrict__ reward_out, float *__restrict__ done_out)
+                                    float *__restrict__ reward_out, float *__restrict__ done_out,
+                                    float *__restrict__ ep_return, double *__restrict__ ep_stats)
 {
     const int64_t n = ring.n_envs;
     const int64_t pos = ring_ctl[0];  // wave-uniform scalar load
@@ -279,6 +280,15 @@ __global__ void collect_step_kernel(const cstr_coef_t k, const cstr_ring_t ring,
         ring.timeout[row + i] = trunc ? 1.0f : 0.0f;
         if (reward_out) reward_out[i] = r;
         if (done_out) done_out[i] = d ? 1.0f : 0.0f;
+        if (ep_return) {  // Monitor semantics: return/length of the episode that ends here
+            const float ret = ep_return[i] + r;
+            ep_return[i] = d ? 0.0f : ret;
+            if (d) {
+                atomicAdd(ep_stats + 0, 1.0);
+                atomicAdd(ep_stats + 1, (double)ret);
+                atomicAdd(ep_stats + 2, (double)st);
+            }
+        }
 
         // env state for the next iteration (dummy_vec_env.py:68-72)
         if (d) {
@@ -394,12 +404,13 @@ extern "C" int cstr_collect_step_f32(const cstr_coef_t *coef, int integrator, co
                                      float *env_obs, int32_t *step_count, const float *policy_out, int squashed,
                                      const float *act_low, const float *act_high, const float *noise,
                                      const float *reset_obs, uint64_t *pcg_state, float *reward_out, float *done_out,
-                                     cstr_stream_t stream)
+                                     float *ep_return, double *ep_stats, cstr_stream_t stream)
 {
     int rc = check_ring(ring);
     if (rc) return rc;
     if (!coef || !ring_ctl || !env_obs || !step_count || !policy_out || !act_low || !act_high) return CSTR_E_BADARG;
     if ((reset_obs == nullptr) == (pcg_state == nullptr)) return CSTR_E_BADARG;  // exactly one reset source
+    if ((ep_return == nullptr) != (ep_stats == nullptr)) return CSTR_E_BADARG;
     if (integrator != CSTR_INTEGRATOR_EULER && integrator != CSTR_INTEGRATOR_RK4) return CSTR_E_UNSUPPORTED;
     if (!aligned16(env_obs) || !aligned8(policy_out) || (noise && !aligned8(noise)) || (reset_obs && !aligned16(reset_obs)) ||
         (pcg_state && !aligned16(pcg_state)))
@@ -410,6 +421,6 @@ extern "C" int cstr_collect_step_f32(const cstr_coef_t *coef, int integrator, co
     int block, grid;
     env_launch_shape(ring->n_envs, block, grid);
     DISPATCH_D_INTEG(collect_step_kernel, *coef, *ring, ring_ctl, env_obs, step_count, policy_out, squashed, act_low[0],
-                     act_high[0], act_low[1], act_high[1], noise, reset_obs, pcg_state, reward_out, done_out);
+                     act_high[0], act_low[1], act_high[1], noise, reset_obs, pcg_state, reward_out, done_out, ep_return, ep_stats);
     return (int)hipGetLastError();
 }

@@ -301,9 +301,16 @@ def test_collect_step_device_reset_rng(ops):
     ring = _mk_ring(ops, R, N, 4)
     env_obs, dsteps = dev(obs), dev(steps, th.int32)
     pol = rng.uniform(-1, 1, (N, 2)).astype(np.float32)
+    ep_ret, ep_stats = dev(np.full(N, -3.0, np.float32)), th.zeros(4, dtype=th.float64, device="cuda")
     ops.collect_step(nv.default_coef(), "euler", ring, env_obs, dsteps, dev(pol), True,
-                     [-1, -1], [1, 1], pcg_state=dst)
+                     [-1, -1], [1, 1], pcg_state=dst, ep_return=ep_ret, ep_stats=ep_stats)
     fin = steps == 399
+    # device-side episode statistics (Monitor semantics): count, sum of returns, sum of lengths
+    rew0 = ring.rewards.cpu().numpy()[0].astype(np.float64)
+    es = ep_stats.cpu().numpy()
+    assert es[0] == fin.sum() and es[2] == 400 * fin.sum()
+    assert abs(es[1] - (rew0[fin] - 3.0).sum()) < 1e-3
+    np.testing.assert_allclose(ep_ret.cpu().numpy(), np.where(fin, 0.0, rew0 - 3.0), rtol=1e-6)
     exp_reset = orc.reset_draw(st, fin.astype(np.uint8))
     got = env_obs.cpu().numpy()
     np.testing.assert_array_equal(got[fin], exp_reset[fin])

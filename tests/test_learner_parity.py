@@ -1,0 +1,236 @@
+"""GPU parity of the learner against the reference's own train() outputs (teacher-forced).
+
+Golden vectors (tests/golden/sac_train_kat_*.npz, td3_train_kat.npz) were produced by the unmodified
+reference `SAC.train` / `TD3.train` on the CPU (core/sac/sac.py:199-296, core/td3/td3.py:154-211) with the
+Normal eps draws and the mse_loss arguments recorded. Here the same weights, ring contents, sampler seed
+and eps are injected into the MI355X stack and one gradient step at a time is compared:
+  * sampled batch: BIT-EXACT (same MT19937 indices, same gather),
+  * Q-values / TD targets / losses: 1e-5 relative (north_star's bound; fp32 GEMM summation order differs),
+  * weights after the steps: 2e-5 of the tensor's scale + 1e-4 relative (Adam divides by sqrt(v)+eps, so
+    near-zero gradients amplify GEMM rounding noise into the update).
+"""
+import numpy as np
+import pytest
+import torch as th
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _load_ring(model, g):
+    rb = model.replay_buffer
+    for name, key in (("observations", "ring_obs"), ("next_observations", "ring_next_obs"), ("actions", "ring_act"),
+                      ("rewards", "ring_rew"), ("dones", "ring_done"), ("timeouts", "ring_timeout")):
+        getattr(rb, name).copy_(th.as_tensor(g[key]))
+    pos, full = int(g["ring_pos"]), bool(g["ring_full"])
+    rb._adds = pos + (rb.buffer_size if full else 0)
+    rb.ring.ctl[0], rb.ring.ctl[1] = pos, int(full)
+
+
+def _load_weights(model, g, prefix, modules):
+    for nm in modules:
+        sd = getattr(model, nm).state_dict()
+        for k, v in sd.items():
+            v.copy_(th.as_tensor(g[f"{prefix}/{nm}/{k}"]))
+
+
+def _check_weights(model, g, prefix, modules, digest=False):
+    worst = 0.0
+    for nm in modules:
+        for k, v in getattr(model, nm).state_dict().items():
+            got = v.detach().cpu().numpy()
+            key = f"{prefix}/{nm}/{k}"
+            if key in g:
+                want = g[key]
+                scale = max(float(np.abs(want).max()), 1e-3)
+                err = np.abs(got - want) / (2e-5 * scale + 1e-4 * np.abs(want))
+                worst = max(worst, float(err.max()))
+            elif digest:  # big tensors of the default-size fixture are stored as digests
+                np.testing.assert_allclose(got.reshape(-1)[:64], g[key + "#head"], rtol=1e-4, atol=2e-5 * float(np.abs(got).max()))
+                assert abs(got.astype(np.float64).sum() - float(g[key + "#sum"])) < 1e-4 * float(g[key + "#abs"]) + 1e-4
+    assert worst < 1.0, worst
+
+
+def _make_env(n=4):
+    from core.common.vec_env import CSTRVecEnv
+
+    return CSTRVecEnv(n)
+
+
+@pytest.mark.parametrize("tag", ["small", "default"])
+def test_sac_train_teacher_forced(golden, tag):
+    from core.common import legacy_rng
+    from core.sac import SAC
+
+    g = golden(f"sac_train_kat_{tag}.npz")
+    gamma, tau, target_entropy, lr, B, n_steps = g["hyper"]
+    B, n_steps = int(B), int(n_steps)
+    kw = dict(policy_kwargs=dict(net_arch=[64, 64])) if tag == "small" else {}
+    model = SAC("MlpPolicy", _make_env(4), seed=0, batch_size=B, buffer_size=64 * 4, **kw)
+    assert model.gamma == gamma and model.tau == tau and model.target_entropy == target_entropy and model.lr_schedule(1) == lr
+    mods = ["actor", "critic", "critic_target"]
+    if tag == "small":
+        # same seed -> same initial weights as the reference (construction order = RNG order): bit-exact
+        for nm in mods:
+            for k, v in getattr(model, nm).state_dict().items():
+                np.testing.assert_array_equal(v.cpu().numpy(), g[f"before/{nm}/{k}"], err_msg=f"init {nm}/{k}")
+    assert float(model.log_ent_coef) == float(g["before/log_ent_coef"][0])
+    _load_ring(model, g)
+    legacy_rng.seed(int(g["np_seed"]), model.device)
+    model.debug_capture = True
+    for k in range(n_steps):
+        model.actor.action_dist.eps_queue = [th.as_tensor(g[f"step{k}/eps_pi"]), th.as_tensor(g[f"step{k}/eps_next"])]
+        model.train(gradient_steps=1, batch_size=B)
+        assert not model.actor.action_dist.eps_queue
+        b = model._static_batch
+        for name in ("observations", "actions", "next_observations", "dones", "rewards"):
+            np.testing.assert_array_equal(getattr(b, name).cpu().numpy(), g[f"step{k}/batch_{name}"], err_msg=f"step {k} batch {name}")
+        t = model.last_train_tensors
+        # Q-values and TD targets: 1e-5 relative (north_star)
+        assert rel_err(t["target_q"].cpu().numpy(), g[f"step{k}/target_q"], 1e-2) < 1e-5, f"target_q step {k}"
+        assert rel_err(t["current_q"][0].cpu().numpy(), g[f"step{k}/current_q1"], 1e-2) < 1e-5, f"q1 step {k}"
+        assert rel_err(t["current_q"][1].cpu().numpy(), g[f"step{k}/current_q2"], 1e-2) < 1e-5, f"q2 step {k}"
+        lv = model.logger.name_to_value
+        for key in ("critic_loss", "actor_loss", "ent_coef_loss", "ent_coef"):
+            assert rel_err(float(lv[f"train/{key}"]), float(g[f"step{k}/{key}"]), 1e-3) < 1e-5, f"{key} step {k}"
+    assert model._n_updates == n_steps
+    _check_weights(model, g, "after", mods, digest=(tag == "default"))
+    assert abs(float(model.log_ent_coef) - float(g["after/log_ent_coef"][0])) < 1e-6
+    assert model.actor.optimizer.step_count == n_steps and model.critic.optimizer.step_count == n_steps
+
+
+def test_td3_train_teacher_forced(golden):
+    from core.common import legacy_rng
+    from core.td3 import TD3
+
+    g = golden("td3_train_kat.npz")
+    gamma, tau, tpn, tnc, delay, lr, B, n_steps = g["hyper"]
+    B, n_steps = int(B), int(n_steps)
+    model = TD3("MlpPolicy", _make_env(4), seed=0, batch_size=B, buffer_size=64 * 4, policy_kwargs=dict(net_arch=[48, 32]))
+    assert (model.gamma, model.tau, model.target_policy_noise, model.target_noise_clip, model.policy_delay) == (gamma, tau, tpn, tnc, int(delay))
+    assert model.lr_schedule(1) == lr
+    mods = ["actor", "actor_target", "critic", "critic_target"]
+    for nm in mods:
+        for k, v in getattr(model, nm).state_dict().items():
+            np.testing.assert_array_equal(v.cpu().numpy(), g[f"before/{nm}/{k}"], err_msg=f"init {nm}/{k}")
+    _load_ring(model, g)
+    legacy_rng.seed(int(g["np_seed"]), model.device)
+    model.debug_capture = True
+    for k in range(n_steps):
+        model.noise_queue = [th.as_tensor(g[f"step{k}/noise_raw"])]
+        model.train(gradient_steps=1, batch_size=B)
+        b = model._static_batch
+        for name in ("observations", "actions", "next_observations", "dones", "rewards"):
+            np.testing.assert_array_equal(getattr(b, name).cpu().numpy(), g[f"step{k}/batch_{name}"])
+        t = model.last_train_tensors
+        assert rel_err(t["target_q"].cpu().numpy(), g[f"step{k}/target_q"], 1e-2) < 1e-5
+        assert rel_err(t["current_q"][0].cpu().numpy(), g[f"step{k}/current_q1"], 1e-2) < 1e-5
+        assert rel_err(t["current_q"][1].cpu().numpy(), g[f"step{k}/current_q2"], 1e-2) < 1e-5
+        lv = model.logger.name_to_value
+        assert rel_err(float(lv["train/critic_loss"]), float(g[f"step{k}/critic_loss"]), 1e-3) < 1e-5
+        if f"step{k}/actor_loss" in g:  # delayed policy update: every 2nd step
+            assert rel_err(float(lv["train/actor_loss"]), float(g[f"step{k}/actor_loss"]), 1e-3) < 1e-5
+            assert t["actor_loss"] is not None
+        else:
+            assert t["actor_loss"] is None
+    _check_weights(model, g, "after", mods)
+    assert model.critic.optimizer.step_count == n_steps and model.actor.optimizer.step_count == n_steps // 2
+
+
+def test_policy_init_matches_reference_on_device(golden):
+    """Default-size nets, seeds 0 and 5: per-tensor sum and head of the reference's initial weights."""
+    from core.sac import SAC
+    from core.td3 import TD3
+
+    g = golden("policy_init_kat.npz")
+    for name, cls in (("sac", SAC), ("td3", TD3)):
+        for seed in (0, 5):
+            model = cls("MlpPolicy", _make_env(2), seed=seed)
+            mods = ["actor", "critic", "critic_target"] + (["actor_target"] if name == "td3" else [])
+            for nm in mods:
+                for k, v in getattr(model, nm).state_dict().items():
+                    a = v.cpu().numpy()
+                    assert tuple(a.shape) == tuple(g[f"{name}{seed}/{nm}/{k}#shape"])
+                    np.testing.assert_array_equal(a.reshape(-1)[:16], g[f"{name}{seed}/{nm}/{k}#head"])
+                    assert a.astype(np.float64).sum() == float(g[f"{name}{seed}/{nm}/{k}#sum"])
+
+
+@pytest.mark.parametrize("algo", ["sac", "td3"])
+def test_learn_end_to_end_index_stream_and_bookkeeping(algo):
+    """A seeded learn() run: the device sampler must leave the legacy MT19937 stream exactly where the
+    reference's np.random calls would (seed + n_envs - 1, one randint pair per gradient step with
+    upper = rows written so far), and the host mirrors (pos/full/num_timesteps/_n_updates) must agree
+    with the device control words."""
+    from core.common import legacy_rng
+    from core.common.vec_env import CSTRVecEnv
+    from core.sac import SAC
+    from core.td3 import TD3
+    from oracle import cstr_oracle as orc
+
+    N, B, seed, iters = 64, 32, 3, 45
+    env = CSTRVecEnv(N)
+    cls = SAC if algo == "sac" else TD3
+    model = cls("MlpPolicy", env, seed=seed, batch_size=B, buffer_size=N * 20, learning_starts=100,
+                policy_kwargs=dict(net_arch=[32, 32]))
+    model.learn(N * iters)
+    assert model.num_timesteps == N * iters
+    rb = model.replay_buffer
+    ctl = rb.ring.ctl.cpu().numpy()
+    assert rb.buffer_size == 20 and ctl[3] == iters and ctl[0] == rb.pos == iters % 20 and ctl[1] == int(rb.full) == 1
+    # learning starts after the 2nd vec-step (num_timesteps 128 > 100): one gradient step per vec-step afterwards
+    n_train = iters - 1
+    assert model._n_updates == n_train
+    mt = orc.MT19937(seed + N - 1)
+    for k in range(2, iters + 1):
+        mt.randint(min(k, 20), B)
+        mt.randint(N, B)
+    st = legacy_rng.global_stream(model.device).cpu().numpy().view(np.uint32)
+    np.testing.assert_array_equal(st[:624], mt.key)
+    assert int(st[624]) == mt.pos
+    for p in model.policy.parameters():
+        assert th.isfinite(p).all()
+    # the env really advanced `iters` steps and nothing was reset yet
+    assert int(env.step_count.min()) == int(env.step_count.max()) == iters
+    assert model.critic.optimizer.step_count == n_train
+
+
+def test_episode_statistics_and_autoreset_in_learn():
+    from core.common.vec_env import CSTRVecEnv
+    from core.sac import SAC
+
+    N = 8
+    env = CSTRVecEnv(N)
+    model = SAC("MlpPolicy", env, seed=1, batch_size=16, buffer_size=N * 50, learning_starts=10**9,  # collect only
+                policy_kwargs=dict(net_arch=[16, 16]))
+    model.learn(N * 805)
+    assert model._episode_num == 2 * N
+    assert int(env.step_count.max()) == 5
+    n_ep, ret_sum, len_sum, _ = model._ep_stats.cpu().tolist()
+    assert n_ep == 2 * N and len_sum == 400 * 2 * N and ret_sum < 0
+    d = model.replay_buffer.dones.cpu().numpy()
+    t = model.replay_buffer.timeouts.cpu().numpy()
+    assert (d == t).all()  # CSTR episodes only ever end by truncation (twoseriescstr.py:435-438)
+
+
+def test_compat_numpy_vecenv_path_and_predict():
+    """The NumPy face of CSTRVecEnv (reset/step/infos) and policy.predict, as the reference's callers use them."""
+    from core.common.vec_env import CSTRVecEnv
+    from core.sac import SAC
+
+    env = CSTRVecEnv(3)
+    env.seed(7)
+    obs = env.reset()
+    assert obs.shape == (3, 4) and obs.dtype == np.float32 and np.all(np.abs(obs) <= 1)
+    env.set_state(obs, [398, 5, 399])
+    o2, r, d, infos = env.step(np.zeros((3, 2), np.float32))
+    assert d.dtype == bool and list(d) == [False, False, True] and r.dtype == np.float32
+    assert infos[2]["TimeLimit.truncated"] is True and "terminal_observation" in infos[2] and "terminal_observation" not in infos[0]
+    assert not np.array_equal(o2[2], infos[2]["terminal_observation"])  # reset obs returned, terminal obs in info
+    model = SAC("MlpPolicy", env, seed=0, policy_kwargs=dict(net_arch=[16, 16]))
+    a, state = model.predict(o2, deterministic=True)
+    assert a.shape == (3, 2) and a.dtype == np.float32 and state is None and np.all(np.abs(a) <= 1)
+    a1, _ = model.predict(o2[0], deterministic=True)
+    assert a1.shape == (2,)
+    with pytest.raises(ValueError, match="Policy .* unknown"):
+        SAC("CnnPolicy", env)
