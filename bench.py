@@ -1,0 +1,259 @@
+#!/usr/bin/env python3
+"""bench.py -- env-steps/sec of SAC on 4096 vectorised two-series CSTR envs per GPU (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]            (N > 1: launched by torch.distributed.run)
+
+A "step" is ONE iteration of `core.SAC("MlpPolicy", env).learn()` at the class defaults
+(reference: core/common/off_policy_algorithm.py:331-351): one vec-step of 4096 envs (actor forward + fused
+collect kernel) followed by one gradient step (HIP sampler, MLP fwd/bwd on PyTorch-ROCm, HIP td-target,
+three flat Adam launches, HIP polyak). Inputs are resident in HBM before the timed region. The timed region
+is bracketed by a barrier + torch.cuda.synchronize() on both sides; the MAX over ranks is reported.
+
+Extra objects on the JSON line:
+  roofline      dominant hand-written kernel (the fused collect step: 104 algorithmic B per env-step)
+                at the WORKLOAD size, timed live with HIP events on the launch stream (back-to-back launches
+                right after the timed region). At N=4096 the launch moves 426 KB and is latency-bound.
+  roofline_stream  the same kernel at N = 2^22 envs (436 MB per launch, far above every cache): what the kernel
+                reaches when it is actually bandwidth-bound. Never to be confused with the end-to-end figure.
+  kernels       per-kernel average launch duration / algorithmic GB/s for the other HIP kernels of the step
+  cpu_baseline  the oracle port (C env step + ring add + MT19937 sampler with OpenMP, torch-CPU SAC step)
+                timed on this box's host cores on a bounded sample of the same workload (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "pytorch-rl-enhancedstablebaselines_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np  # noqa: E402
+import torch as th  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s measured achievable)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--algo", default="sac", choices=["sac", "td3"])
+    ap.add_argument("--n-envs", type=int, default=4096)
+    ap.add_argument("--obs-dim", type=int, default=4, choices=[4, 8])
+    ap.add_argument("--integrator", default="euler", choices=["euler", "rk4"])
+    ap.add_argument("--graph", type=int, default=int(os.environ.get("CSTR_BENCH_GRAPH", "1")))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def event_time_us(fn, n_launch, stream):
+    """Average duration of `fn` (one kernel launch) over n_launch back-to-back launches, HIP events on `stream`."""
+    for _ in range(5):
+        fn()
+    e0, e1 = th.cuda.Event(enable_timing=True), th.cuda.Event(enable_timing=True)
+    stream.synchronize()
+    e0.record(stream)
+    for _ in range(n_launch):
+        fn()
+    e1.record(stream)
+    e1.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / n_launch
+
+
+def roofline_collect(n_envs, obs_dim, integrator, n_launch):
+    """Fused collect kernel alone on its own synthetic state (the training state is untouched): C in U[0.05,0.45],
+    T in U[280,380] normalised, policy output U[-1,1]."""
+    from core import _native as nv
+    from core.common import hip_ops
+
+    dev = th.device("cuda", th.cuda.current_device())
+    g = th.Generator(device=dev).manual_seed(1)
+    lo = th.tensor([0.0, 273.15, 0.0, 273.15], device=dev)
+    hi = th.tensor([0.7, 400.0, 0.7, 400.0], device=dev)
+    u = th.rand(n_envs, 4, device=dev, generator=g)
+    raw = th.stack([0.05 + 0.4 * u[:, 0], 280 + 100 * u[:, 1], 0.05 + 0.4 * u[:, 2], 280 + 100 * u[:, 3]], dim=1)
+    obs4 = 2.0 * (raw - lo) / (hi - lo) - 1.0
+    obs = (obs4 if obs_dim == 4 else th.cat([obs4, raw], dim=1)).contiguous()
+    steps = th.zeros(n_envs, dtype=th.int32, device=dev)
+    pcg = th.randint(1, 2**62, (n_envs, 4), dtype=th.int64, device=dev, generator=g) | 1
+    ring = hip_ops.DeviceRing(2, n_envs, obs_dim, 2, dev)
+    pol = (th.rand(n_envs, 2, device=dev, generator=g) * 2 - 1).contiguous()
+    coef = nv.default_coef()
+    stream = th.cuda.current_stream()
+
+    def launch():
+        hip_ops.collect_step(coef, integrator, ring, obs, steps, pol, True, [-1, -1], [1, 1], pcg_state=pcg)
+
+    us = event_time_us(launch, n_launch, stream)
+    bytes_per_env = 2 * (2 * 4 * obs_dim + 8 + 12)  # 104 B (D=4) / 168 B (D=8): SURVEY 8d
+    alg = bytes_per_env * n_envs
+    gbs = alg / us / 1e3
+    return dict(bound="hbm", kernel="collect_step_kernel", achieved=round(gbs, 2), peak=HBM_PEAK_GBS, unit="GB/s",
+                frac=round(gbs / HBM_PEAK_GBS, 5), traffic=None, launch_us=round(us, 3), n_envs=n_envs,
+                algorithmic_bytes_per_launch=alg)
+
+
+def other_kernels(model, batch):
+    """Average launch time of the remaining hand-written kernels at the workload's sizes."""
+    from core.common import hip_ops
+
+    stream = th.cuda.current_stream()
+    pol = model.policy
+    out = {}
+    n = pol.critic_arena.numel
+    tgt = pol.critic_target_arena.flat.clone()
+    us = event_time_us(lambda: hip_ops.polyak(pol.critic_arena.flat, tgt, 0.005), 200, stream)
+    out["polyak_kernel"] = dict(launch_us=round(us, 3), n_params=n, gbs=round(12 * n / us / 1e3, 2))
+    p, g = pol.critic_arena.flat.clone(), th.randn_like(pol.critic_arena.flat)
+    m, v = th.zeros_like(p), th.zeros_like(p)
+    ctl = th.zeros(2, dtype=th.int64, device=p.device)
+    lr = th.tensor([3e-4], dtype=th.float64, device=p.device)
+    us = event_time_us(lambda: hip_ops.adam(p, g, m, v, ctl, lr), 200, stream)
+    out["adam_kernel"] = dict(launch_us=round(us, 3), n_params=n, gbs=round(28 * n / us / 1e3, 2))
+    rb = model.replay_buffer
+    b = rb.alloc_batch(batch)
+    mt = th.zeros(625, dtype=th.int32, device=p.device)
+    hip_ops.mt19937_seed(mt, 1)
+    us = event_time_us(lambda: hip_ops.replay_sample(rb.ring, mt, batch, b.observations, b.actions, b.next_observations,
+                                                     b.dones, b.rewards), 200, stream)
+    d = rb.obs_shape[0]
+    out["replay_sample_kernel"] = dict(launch_us=round(us, 3), batch=batch, gbs=round(2 * batch * (8 * d + 20) / us / 1e3, 3))
+    q = th.randn(batch, 1, device=p.device)
+    o = th.empty_like(q)
+    ent = th.ones(1, device=p.device)
+    us = event_time_us(lambda: hip_ops.td_target_min(q, q, q, q, q, ent, 0.99, o), 200, stream)
+    out["td_target_min_kernel"] = dict(launch_us=round(us, 3), batch=batch, gbs=round(24 * batch / us / 1e3, 3))
+    return out
+
+
+def cpu_baseline(n_envs, batch, seconds):
+    """Oracle port of one learn() iteration on the host cores: C env step + ring add (OpenMP over envs), C MT19937
+    sampler + gather, torch-CPU actor forward and SAC gradient step (oracle/sac_cpu.py). Bounded sample."""
+    from oracle import cstr_oracle as orc
+    from oracle import sac_cpu
+
+    cores = os.cpu_count() or 1
+    th.set_num_threads(cores)
+    rng = np.random.default_rng(0)
+    rows = max(1_000_000 // n_envs, 1)
+    ring = orc.ReplayRing(rows, n_envs, 4, 2)
+    obs = rng.uniform(-0.5, 0.5, (n_envs, 4)).astype(np.float32)
+    steps = np.zeros(n_envs, np.int32)
+    reset = rng.uniform(-0.5, 0.5, (n_envs, 4)).astype(np.float32)
+    learner = sac_cpu.SacCpu(sac_cpu.init_params(4, 2, [256, 256], seed=0))
+    mt = orc.MT19937(n_envs - 1)
+    low, high = np.array([-1, -1], np.float32), np.array([1, 1], np.float32)
+
+    def iteration():
+        nonlocal obs, steps
+        a = learner.act(th.from_numpy(obs)).numpy()
+        buf_a, env_a = orc.action_scale_chain(a, True, low, high)
+        nxt, after, rew, done, tout, steps = orc.vec_step(obs, env_a, steps, reset, n_threads=cores)
+        ring.add(obs, nxt, buf_a, rew, done, tout)
+        obs = after
+        (o, ac, no, d, r), _ = ring.sample(mt, batch)
+        learner.train_step(*(th.from_numpy(x) for x in (o, ac, no, d, r)))
+
+    for _ in range(3):
+        iteration()
+    t0, n = time.perf_counter(), 0
+    while time.perf_counter() - t0 < seconds:
+        iteration()
+        n += 1
+    dt = time.perf_counter() - t0
+    t1 = time.perf_counter()
+    k = 50
+    orc.collect_loop(ring, obs.copy(), np.zeros((n_envs, 2), np.float32), steps.copy(), reset, k, cores)
+    env_only = k * n_envs / (time.perf_counter() - t1)
+    return dict(value=round(n * n_envs / dt, 1), unit="env-steps/s", cores=cores, kind="port",
+                sample=f"{n} learn() iterations of {n_envs} envs + 1 gradient step (batch {batch}) in {dt:.1f} s: C oracle env step/ring/"
+                       f"MT19937 sampler (OpenMP, {cores} threads) + torch-CPU SAC step ({cores} threads)",
+                env_only_value=round(env_only, 1), ms_per_iteration=round(1e3 * dt / n, 3))
+
+
+def main():
+    args = parse()
+    from core.common import distributed as dist_util
+
+    rank, local_rank, world = dist_util.init_from_env()
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    assert th.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
+    th.cuda.set_device(local_rank)
+    from core import _native as nv
+    from core.common.callbacks import NoopCallback
+    from core.common.vec_env import CSTRVecEnv
+    from core.sac import SAC
+    from core.td3 import TD3
+
+    nv.lib()
+    N, B = args.n_envs, 256
+    env = CSTRVecEnv(N, obs_dim=args.obs_dim, integrator=args.integrator, device=f"cuda:{local_rank}")
+    cls = SAC if args.algo == "sac" else TD3
+    model = cls("MlpPolicy", env, seed=0, device=f"cuda:{local_rank}")  # class defaults: buffer 1e6 -> 244 rows x 4096
+    total = (args.warmup + args.steps) * N
+    _, callback = model._setup_learn(total, NoopCallback(), True, "bench", False)
+    use_graph = bool(args.graph) and hasattr(model, "enable_graph_capture")
+    if use_graph:
+        model.enable_graph_capture()
+
+    def iteration():  # exactly the body of OffPolicyAlgorithm.learn()'s while loop
+        model.collect_rollouts(env, callback, model.train_freq, model.replay_buffer, model.action_noise,
+                               model.learning_starts, None)
+        if model.num_timesteps > model.learning_starts:
+            model.train(batch_size=model.batch_size, gradient_steps=model.gradient_steps)
+
+    def barrier():
+        th.cuda.synchronize()
+        if world > 1:
+            th.distributed.barrier()
+        th.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        iteration()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        iteration()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = th.tensor([dt], dtype=th.float64, device="cuda")
+        th.distributed.all_reduce(t, op=th.distributed.ReduceOp.MAX)
+        dt = float(t)
+    value = args.steps * N * world / dt
+    line = {
+        "metric": "env-steps/sec (SAC, two-series CSTR, 4096 vec-envs) at 1/2/4/8 GPUs" if args.algo == "sac" else
+                  "env-steps/sec (TD3, two-series CSTR, 4096 vec-envs)",
+        "value": round(value, 1), "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{args.algo.upper()} MlpPolicy class defaults on {N} vectorised two-series CSTR envs per GPU "
+                               f"(obs {args.obs_dim}/act 2, {args.integrator}, batch 256, ring 244x{N}, 1 gradient step per vec-step)",
+                   "n_envs_per_gpu": N, "global_batch": B * world, "parallelism": f"dp{world}", "hip_graph": use_graph,
+                   "n_updates": model._n_updates},
+    }
+    if rank == 0:
+        if not args.no_roofline:
+            line["roofline"] = roofline_collect(N, args.obs_dim, args.integrator, 500)
+            line["roofline"]["note"] = ("workload size: 4096 envs x 104 B = 426 KB per launch, cache-resident and launch-latency-"
+                                        "bound; see roofline_stream for the bandwidth-bound regime of the same kernel")
+            line["roofline_stream"] = roofline_collect(1 << 22, args.obs_dim, args.integrator, 30)
+            line["kernels"] = other_kernels(model, B)
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(N, B, args.cpu_seconds)
+            line["speedup_vs_cpu_port"] = round(value / line["cpu_baseline"]["value"], 2)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        th.distributed.barrier()
+        th.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
