@@ -46,10 +46,30 @@ def parse():
     ap.add_argument("--obs-dim", type=int, default=4, choices=[4, 8])
     ap.add_argument("--integrator", default="euler", choices=["euler", "rk4"])
     ap.add_argument("--graph", type=int, default=int(os.environ.get("CSTR_BENCH_GRAPH", "1")))
+    ap.add_argument("--tunable", type=int, default=int(os.environ.get("CSTR_BENCH_TUNABLE", "0")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
+
+
+def host_cores() -> int:
+    """CPU share of this process: min(affinity, cgroup quota); the GPU box reports all 256 host threads in
+    os.cpu_count() but a 1-GPU job owns 16 of them (oversubscribing OpenMP/torch wrecks the CPU baseline)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // p))
+        except (OSError, ValueError):
+            pass
+    return int(os.environ.get("CSTR_CPU_CORES", min(n, 16)))
 
 
 def event_time_us(fn, n_launch, stream):
@@ -138,7 +158,7 @@ def cpu_baseline(n_envs, batch, seconds):
     from oracle import cstr_oracle as orc
     from oracle import sac_cpu
 
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     th.set_num_threads(cores)
     rng = np.random.default_rng(0)
     rows = max(1_000_000 // n_envs, 1)
@@ -199,15 +219,15 @@ def main():
     model = cls("MlpPolicy", env, seed=0, device=f"cuda:{local_rank}")  # class defaults: buffer 1e6 -> 244 rows x 4096
     total = (args.warmup + args.steps) * N
     _, callback = model._setup_learn(total, NoopCallback(), True, "bench", False)
-    use_graph = bool(args.graph) and hasattr(model, "enable_graph_capture")
-    if use_graph:
-        model.enable_graph_capture()
+    use_graph = bool(args.graph) and world == 1
+    model.enable_graph_capture(use_graph)
+    if args.tunable:
+        th.cuda.tunable.enable(True)
+        th.cuda.tunable.tuning_enable(True)
+        th.cuda.tunable.set_filename(os.path.join(ROOT, "gpurun_out", "tunableop_results.csv"))
 
     def iteration():  # exactly the body of OffPolicyAlgorithm.learn()'s while loop
-        model.collect_rollouts(env, callback, model.train_freq, model.replay_buffer, model.action_noise,
-                               model.learning_starts, None)
-        if model.num_timesteps > model.learning_starts:
-            model.train(batch_size=model.batch_size, gradient_steps=model.gradient_steps)
+        model._learn_iteration(callback, None)
 
     def barrier():
         th.cuda.synchronize()

@@ -50,6 +50,7 @@ class OffPolicyAlgorithm(BaseAlgorithm):
         self.replay_buffer_kwargs = replay_buffer_kwargs or {}
         self.train_freq = train_freq
         self.use_sde_at_warmup = use_sde_at_warmup
+        self._graph_enabled, self._graph, self._graph_key = False, None, None
         self.stats_sync_interval = 100   # vec-steps between host reads of the device episode counters
         self._steps_since_sync = 0
         self._episodes_at_last_dump = 0
@@ -119,19 +120,90 @@ class OffPolicyAlgorithm(BaseAlgorithm):
         assert self.env is not None, "You must set the environment before calling learn()"
         assert isinstance(self.train_freq, TrainFreq)
         while self.num_timesteps < total_timesteps:
-            rollout = self.collect_rollouts(self.env, train_freq=self.train_freq, action_noise=self.action_noise,
-                                            callback=callback, learning_starts=self.learning_starts,
-                                            replay_buffer=self.replay_buffer, log_interval=log_interval)
-            if not rollout.continue_training:
+            if not self._learn_iteration(callback, log_interval):
                 break
-            if self.num_timesteps > 0 and self.num_timesteps > self.learning_starts:
-                gradient_steps = self.gradient_steps if self.gradient_steps >= 0 else rollout.episode_timesteps
-                if gradient_steps > 0:
-                    self.train(batch_size=self.batch_size, gradient_steps=gradient_steps)
         if self._fast_path():
             self._sync_episode_stats(log_interval, force=True)
         callback.on_training_end()
         return self
+
+    def _learn_iteration(self, callback: BaseCallback, log_interval: Optional[int]) -> bool:
+        """Body of the reference's `while` loop (off_policy_algorithm.py:331-351): one rollout, then train.
+        When the iteration is eligible it is replayed from a captured hipGraph instead (same launches, same
+        order, one host call)."""
+        if self._graph_enabled and self._graph_eligible(callback):
+            self._graph_iteration(log_interval)
+            return True
+        rollout = self.collect_rollouts(self.env, train_freq=self.train_freq, action_noise=self.action_noise,
+                                        callback=callback, learning_starts=self.learning_starts,
+                                        replay_buffer=self.replay_buffer, log_interval=log_interval)
+        if not rollout.continue_training:
+            return False
+        if self.num_timesteps > 0 and self.num_timesteps > self.learning_starts:
+            gradient_steps = self.gradient_steps if self.gradient_steps >= 0 else rollout.episode_timesteps
+            if gradient_steps > 0:
+                self.train(batch_size=self.batch_size, gradient_steps=gradient_steps)
+        return True
+
+    # ---- hipGraph capture of the steady-state iteration ------------------------------------------------------------
+    def enable_graph_capture(self, enabled: bool = True) -> None:
+        """Replay the steady-state iteration (actor forward, fused collect, `gradient_steps` gradient steps) from a
+        captured hipGraph: ~250 launches become one host call. Every per-call control word the kernels need (ring
+        position, Adam step, MT19937 stream, learning rate, env / RNG state) lives in HBM, so a replay is exact.
+        Falls back to the eager path whenever the iteration is not capturable (warm-up, callbacks, action noise,
+        data-parallel all-reduce, episodic train_freq)."""
+        self._graph_enabled = enabled
+        if not enabled:
+            self._graph = None
+
+    def _graph_eligible(self, callback: BaseCallback) -> bool:
+        return (self._fast_path() and getattr(callback, "is_noop", False) and self.action_noise is None
+                and self.world_size == 1 and self.train_freq == TrainFreq(1, TrainFrequencyUnit.STEP)
+                and self.gradient_steps >= 1 and self.num_timesteps >= self.learning_starts
+                and self.num_timesteps + self.n_envs > self.learning_starts and not getattr(self, "debug_capture", False))
+
+    def _graph_body(self) -> None:
+        env, rb = self.env, self.replay_buffer
+        self.policy.set_training_mode(False)
+        pol = self._policy_out_device(env.obs)
+        hip_ops.collect_step(env.coef, env.integrator, rb.ring, env.obs, env.step_count, pol, True, self.action_space.low,
+                             self.action_space.high, pcg_state=env.pcg_state, reward_out=env._rew, done_out=env._done,
+                             ep_return=self._ep_return, ep_stats=self._ep_stats)
+        self.policy.set_training_mode(True)
+        self._train_device_only(self.gradient_steps, self.batch_size)
+
+    def _graph_host_bookkeeping(self, log_interval: Optional[int]) -> None:
+        self.replay_buffer.note_fused_add()
+        self._last_obs = self.env.obs
+        self.num_timesteps += self.n_envs
+        self._update_current_progress_remaining(self.num_timesteps, self._total_timesteps)
+        self._train_host_only(self.gradient_steps)
+        self._sync_episode_stats(log_interval)
+
+    def _graph_iteration(self, log_interval: Optional[int]) -> None:
+        key = (id(self.env.coef), self.batch_size, self.gradient_steps)
+        if self._graph is None or self._graph_key != key:
+            # side-stream warm-up (these are REAL iterations: they advance env, ring, RNG and optimiser state)
+            self._graph, self._graph_key, self._graph_warm = None, key, getattr(self, "_graph_warm", 0)
+            if self._graph_warm < 3:
+                self._train_host_pre()
+                side = th.cuda.Stream(device=self.device)
+                side.wait_stream(th.cuda.current_stream(self.device))
+                with th.cuda.stream(side):
+                    self._graph_body()
+                th.cuda.current_stream(self.device).wait_stream(side)
+                self._graph_warm += 1
+                self._graph_host_bookkeeping(log_interval)
+                return
+            g = th.cuda.CUDAGraph()
+            self._train_host_pre()
+            th.cuda.synchronize(self.device)
+            with th.cuda.graph(g):  # records the launches; nothing executes here
+                self._graph_body()
+            self._graph = g
+        self._train_host_pre()
+        self._graph.replay()
+        self._graph_host_bookkeeping(log_interval)
 
     # ---- action selection -----------------------------------------------------------------------------------------
     def _policy_out_device(self, obs: th.Tensor) -> th.Tensor:

@@ -83,24 +83,33 @@ class SAC(OffPolicyAlgorithm):
         return self._static_batch
 
     def train(self, gradient_steps: int, batch_size: int = 64) -> None:
-        """reference: sac.py:199-296"""
+        """reference: sac.py:199-296 = host prologue (lr schedule) + device work + host epilogue (logger)."""
         self.policy.set_training_mode(True)
+        self._train_host_pre()
+        self._train_device_only(gradient_steps, batch_size)
+        self._train_host_only(gradient_steps)
+
+    def _train_host_pre(self) -> None:
         optimizers = [self.actor.optimizer, self.critic.optimizer]
         if self.ent_coef_optimizer is not None:
             optimizers += [self.ent_coef_optimizer]
-        self._update_learning_rate(optimizers)
+        self._update_learning_rate(optimizers)  # :208
+
+    def _train_device_only(self, gradient_steps: int, batch_size: int) -> None:
         for v in self._loss_sums.values():
             v.zero_()
         for gradient_step in range(gradient_steps):
             self._gradient_step(batch_size, gradient_step)
+
+    def _train_host_only(self, gradient_steps: int) -> None:
         self._n_updates += gradient_steps
-        s = self._loss_sums
+        s = self._loss_sums  # device-side sums of this train() call; resolved lazily when the logger dumps
         self.logger.record("train/n_updates", self._n_updates, exclude="tensorboard")
-        self.logger.record("train/ent_coef", DeviceMean(s["ent_coef"].clone(), gradient_steps))
-        self.logger.record("train/actor_loss", DeviceMean(s["actor"].clone(), gradient_steps))
-        self.logger.record("train/critic_loss", DeviceMean(s["critic"].clone(), gradient_steps))
+        self.logger.record("train/ent_coef", DeviceMean(s["ent_coef"], gradient_steps))
+        self.logger.record("train/actor_loss", DeviceMean(s["actor"], gradient_steps))
+        self.logger.record("train/critic_loss", DeviceMean(s["critic"], gradient_steps))
         if self.ent_coef_optimizer is not None:
-            self.logger.record("train/ent_coef_loss", DeviceMean(s["ent_coef_loss"].clone(), gradient_steps))
+            self.logger.record("train/ent_coef_loss", DeviceMean(s["ent_coef_loss"], gradient_steps))
 
     def _gradient_step(self, batch_size: int, gradient_step: int) -> None:
         s = self._loss_sums

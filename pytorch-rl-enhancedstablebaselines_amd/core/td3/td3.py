@@ -53,12 +53,32 @@ class TD3(OffPolicyAlgorithm):
     def train(self, gradient_steps: int, batch_size: int = 100) -> None:
         """reference: td3.py:154-211"""
         self.policy.set_training_mode(True)
+        self._train_host_pre()
+        self._train_device_only(gradient_steps, batch_size)
+        self._train_host_only(gradient_steps)
+
+    def _train_host_pre(self) -> None:
         self._update_learning_rate([self.actor.optimizer, self.critic.optimizer])
+
+    def _graph_eligible(self, callback) -> bool:
+        # the delayed policy update makes consecutive iterations differ unless a whole delay period is one iteration
+        return super()._graph_eligible(callback) and self.gradient_steps % self.policy_delay == 0 and \
+            self._n_updates % self.policy_delay == 0 and not self.noise_queue
+
+    def _train_host_only(self, gradient_steps: int) -> None:
+        n_actor = (self._n_updates + gradient_steps) // self.policy_delay - self._n_updates // self.policy_delay
+        self._n_updates += gradient_steps
+        self.logger.record("train/n_updates", self._n_updates, exclude="tensorboard")
+        if n_actor > 0:
+            self.logger.record("train/actor_loss", DeviceMean(self._loss_sums["actor"], n_actor))
+        self.logger.record("train/critic_loss", DeviceMean(self._loss_sums["critic"], gradient_steps))
+
+    def _train_device_only(self, gradient_steps: int, batch_size: int) -> None:
         for v in self._loss_sums.values():
             v.zero_()
-        n_actor = 0
+        n_updates = self._n_updates  # host counter advances in _train_host_only
         for _ in range(gradient_steps):
-            self._n_updates += 1
+            n_updates += 1
             replay_data = self.replay_buffer.sample_into(self._batch(batch_size))
             with th.no_grad():
                 if self.noise_queue:
@@ -80,10 +100,9 @@ class TD3(OffPolicyAlgorithm):
             self._allreduce_grads(self.policy.critic_arena)
             self.critic.optimizer.step()
             actor_loss = None
-            if self._n_updates % self.policy_delay == 0:  # :192-206
+            if n_updates % self.policy_delay == 0:  # :192-206
                 actor_loss = -self.critic.q1_forward(replay_data.observations, self.actor(replay_data.observations)).mean()
                 self._loss_sums["actor"] += actor_loss.detach()
-                n_actor += 1
                 self.actor.optimizer.zero_grad()
                 actor_loss.backward()
                 self._allreduce_grads(self.policy.actor_arena)
@@ -94,10 +113,6 @@ class TD3(OffPolicyAlgorithm):
                 self.last_train_tensors = dict(target_q=target_q_values.clone(), current_q=[q.detach().clone() for q in current_q_values],
                                                critic_loss=critic_loss.detach().clone(),
                                                actor_loss=None if actor_loss is None else actor_loss.detach().clone())
-        self.logger.record("train/n_updates", self._n_updates, exclude="tensorboard")
-        if n_actor > 0:
-            self.logger.record("train/actor_loss", DeviceMean(self._loss_sums["actor"].clone(), n_actor))
-        self.logger.record("train/critic_loss", DeviceMean(self._loss_sums["critic"].clone(), gradient_steps))
 
     def learn(self, total_timesteps: int, callback=None, log_interval: int = 4, tb_log_name: str = "TD3",
               reset_num_timesteps: bool = True, progress_bar: bool = False):

@@ -241,3 +241,41 @@ def test_compat_numpy_vecenv_path_and_predict():
     assert a1.shape == (2,)
     with pytest.raises(ValueError, match="Policy .* unknown"):
         SAC("CnnPolicy", env)
+
+
+def test_hipgraph_iteration_equals_eager():
+    """The captured-graph iteration must be the eager iteration: same launches in the same order. Two seeded
+    models, 12 iterations each (3 side-stream warm-ups + capture + replays on the graph side): the sampler's
+    MT19937 stream, the ring, env state and step counters must be bit-identical; weights agree to fp32 noise."""
+    from core.common import legacy_rng
+    from core.common.callbacks import NoopCallback
+    from core.common.vec_env import CSTRVecEnv
+    from core.sac import SAC
+
+    N, B, seed, iters = 128, 64, 9, 12
+    results = []
+    for use_graph in (False, True):
+        env = CSTRVecEnv(N)
+        model = SAC("MlpPolicy", env, seed=seed, batch_size=B, buffer_size=N * 6, learning_starts=100,
+                    policy_kwargs=dict(net_arch=[64, 64]))
+        model.enable_graph_capture(use_graph)
+        model.learn(N * iters)
+        assert model._n_updates == iters and model.num_timesteps == N * iters
+        if use_graph:
+            assert model._graph is not None, "the steady-state iteration was never captured"
+        th.cuda.synchronize()
+        results.append(dict(
+            mt=legacy_rng.global_stream(model.device).cpu().numpy().copy(), ctl=model.replay_buffer.ring.ctl.cpu().numpy(),
+            steps=env.step_count.cpu().numpy(), adam=model.critic.optimizer.step_count,
+            actor=model.policy.actor_arena.flat.cpu().numpy(), critic=model.policy.critic_arena.flat.cpu().numpy(),
+            target=model.policy.critic_target_arena.flat.cpu().numpy(), obs=env.obs.cpu().numpy(),
+            ring_act=model.replay_buffer.actions.cpu().numpy(), alpha=float(model.log_ent_coef.detach())))
+    e, g = results
+    np.testing.assert_array_equal(e["mt"], g["mt"])
+    np.testing.assert_array_equal(e["ctl"], g["ctl"])
+    np.testing.assert_array_equal(e["steps"], g["steps"])
+    assert e["adam"] == g["adam"] == iters
+    # same torch seed -> same exploration noise -> same trajectories up to fp32 GEMM noise
+    for k in ("actor", "critic", "target", "obs", "ring_act"):
+        np.testing.assert_allclose(e[k], g[k], rtol=2e-3, atol=2e-4, err_msg=k)
+    assert abs(e["alpha"] - g["alpha"]) < 1e-5
