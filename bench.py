@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--obs-dim", type=int, default=4, choices=[4, 8])
     ap.add_argument("--integrator", default="euler", choices=["euler", "rk4"])
     ap.add_argument("--graph", type=int, default=int(os.environ.get("CSTR_BENCH_GRAPH", "1")))
+    ap.add_argument("--blas", default=os.environ.get("CSTR_BLAS", "rocblas"), choices=["rocblas", "hipblaslt", "default"])
     ap.add_argument("--tunable", type=int, default=int(os.environ.get("CSTR_BENCH_TUNABLE", "0")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -213,6 +214,9 @@ def main():
     from core.td3 import TD3
 
     nv.lib()
+    from core.common import blas
+
+    blas.configure(args.blas)
     N, B = args.n_envs, 256
     env = CSTRVecEnv(N, obs_dim=args.obs_dim, integrator=args.integrator, device=f"cuda:{local_rank}")
     cls = SAC if args.algo == "sac" else TD3
@@ -256,7 +260,7 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.algo.upper()} MlpPolicy class defaults on {N} vectorised two-series CSTR envs per GPU "
                                f"(obs {args.obs_dim}/act 2, {args.integrator}, batch 256, ring 244x{N}, 1 gradient step per vec-step)",
-                   "n_envs_per_gpu": N, "global_batch": B * world, "parallelism": f"dp{world}", "hip_graph": use_graph,
+                   "n_envs_per_gpu": N, "global_batch": B * world, "parallelism": f"dp{world}", "hip_graph": use_graph, "blas": args.blas,
                    "n_updates": model._n_updates},
     }
     if rank == 0:

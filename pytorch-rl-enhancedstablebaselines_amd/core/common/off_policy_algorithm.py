@@ -15,6 +15,7 @@ from typing import Any, Optional, Union
 import numpy as np
 import torch as th
 
+from core.common import blas
 from core.common import distributed as dist_util
 from core.common import hip_ops
 from core.common.base_class import BaseAlgorithm
@@ -74,6 +75,7 @@ class OffPolicyAlgorithm(BaseAlgorithm):
     def _setup_model(self) -> None:
         """reference: off_policy_algorithm.py:172-212"""
         self._setup_lr_schedule()
+        blas.configure()
         if self.world_size > 1 and isinstance(self.env, CSTRVecEnv):
             self.env.seed_offset = self.rank * self.n_envs  # SURVEY 8e: seed_r = seed + rank * n_envs
         self.set_random_seed(self.seed)
