@@ -116,8 +116,20 @@ def roofline_collect(n_envs, obs_dim, integrator, n_launch):
     alg = bytes_per_env * n_envs
     gbs = alg / us / 1e3
     return dict(bound="hbm", kernel="collect_step_kernel", achieved=round(gbs, 2), peak=HBM_PEAK_GBS, unit="GB/s",
-                frac=round(gbs / HBM_PEAK_GBS, 5), traffic=None, launch_us=round(us, 3), n_envs=n_envs,
-                algorithmic_bytes_per_launch=alg)
+                frac=round(gbs / HBM_PEAK_GBS, 5), traffic=pmc_traffic(n_envs, obs_dim, integrator), launch_us=round(us, 3),
+                n_envs=n_envs, algorithmic_bytes_per_launch=alg)
+
+
+def pmc_traffic(n_envs, obs_dim, integrator):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r01_collect_pmc.json: separate
+    FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 FETCH correction) -- counters cannot be read from inside the bench."""
+    if obs_dim != 4 or integrator != "euler":
+        return None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_collect_pmc.json")) as fh:
+            return json.load(fh)["collect_step_kernel<4,0>"][str(n_envs)]["traffic_bytes"]
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def other_kernels(model, batch):
