@@ -103,8 +103,11 @@ int cstr_replay_add_f32(const cstr_ring_t *ring, int64_t *ring_ctl, const float 
  * (core/common/off_policy_algorithm.py:396-406, :564, :477-496; buffers.py:247-283) in ONE pass over the envs:
  * reads state + policy output once, writes the ring row once, updates the env state in place.
  *   env_obs    [N][obs_dim] i/o: VecEnv state (_last_obs); replaced by the post-reset observation
- *   policy_out [N][2]       in : actor output; squashed != 0: tanh output in [-1,1] (predict() then unscales it,
- *                                core/common/policies.py:375); squashed == 0: an action already in [low, high]
+ *   policy_out [N][2]       in : actor output. `squashed` is a bit field: bit 0 set = tanh output in [-1,1] that
+ *                                predict() first unscales (core/common/policies.py:375), clear = an action already in
+ *                                [low, high] (warm-up sample); bit 1 set = the multi-agent algorithms' behaviour
+ *                                (core/common/multiagent_policy_algorithm.py:369, :391-392): no scale/unscale round
+ *                                trip and no noise, buffer_action = env action = that value
  *   act_low/act_high [2]    in : HOST pointers, bounds of the algorithm-facing action space
  *   noise      [N][2] or NULL  : added to the scaled action, then clip [-1,1] (off_policy_algorithm.py:401-402)
  *   reset_obs  [N][obs_dim] or NULL, pcg_state [N][4] or NULL: reset source (exactly one non-NULL)

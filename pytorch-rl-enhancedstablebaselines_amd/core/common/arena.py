@@ -62,6 +62,30 @@ class ParamArena:
             hip_ops.polyak(source.flat, self.flat, tau)
 
 
+class ArenaSlice:
+    """A contiguous run of whole tensors inside a `ParamArena` (one agent's parameters inside the arena that holds
+    every agent's): same duck type as ParamArena for FlatAdam and the gradient all-reduce."""
+
+    def __init__(self, arena: ParamArena, params: Iterable[nn.Parameter]):
+        params = list(params)
+        idx = [next(i for i, q in enumerate(arena.params) if q is p) for p in params]
+        if idx != list(range(idx[0], idx[0] + len(idx))):
+            raise ValueError("ArenaSlice needs consecutive arena tensors")
+        start = arena.offsets[idx[0]]
+        end = arena.offsets[idx[-1] + 1] if idx[-1] + 1 < len(arena.params) else arena.numel
+        self.parent, self.params, self.device = arena, params, arena.device
+        self.offsets = [arena.offsets[i] - start for i in idx]
+        self.numel = end - start
+        self.flat = arena.flat[start:end]
+        self.grad = arena.grad[start:end]
+
+    def zero_grad(self) -> None:
+        self.grad.zero_()
+        for p, o in zip(self.params, self.offsets):
+            if p.requires_grad and (p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * o):
+                p.grad = self.grad[o:o + p.numel()].view(p.shape)
+
+
 class FlatAdam:
     """torch.optim.Adam (betas 0.9/0.999, eps 1e-8, no weight decay / amsgrad -- the reference's defaults) over one
     `ParamArena`, one HIP launch per step, step counter and learning rate resident in HBM."""

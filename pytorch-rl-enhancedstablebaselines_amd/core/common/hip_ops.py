@@ -78,7 +78,7 @@ def replay_add(ring: DeviceRing, obs, next_obs, act, rew, done, timeout):
                                        ptr(done), ptr(timeout), stream_ptr()), "cstr_replay_add_f32")
 
 
-def collect_step(coef, integrator: str, ring: DeviceRing, env_obs, step_count, policy_out, squashed: bool, act_low,
+def collect_step(coef, integrator: str, ring: DeviceRing, env_obs, step_count, policy_out, squashed, act_low,
                  act_high, noise=None, reset_obs=None, pcg_state=None, reward_out=None, done_out=None, ep_return=None,
                  ep_stats=None):
     n, d = ring.n_envs, ring.obs_dim

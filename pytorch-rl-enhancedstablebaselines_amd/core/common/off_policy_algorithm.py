@@ -168,8 +168,8 @@ class OffPolicyAlgorithm(BaseAlgorithm):
         env, rb = self.env, self.replay_buffer
         self.policy.set_training_mode(False)
         pol = self._policy_out_device(env.obs)
-        hip_ops.collect_step(env.coef, env.integrator, rb.ring, env.obs, env.step_count, pol, True, self.action_space.low,
-                             self.action_space.high, pcg_state=env.pcg_state, reward_out=env._rew, done_out=env._done,
+        hip_ops.collect_step(env.coef, env.integrator, rb.ring, env.obs, env.step_count, pol, self._action_mode(False),
+                             self.action_space.low, self.action_space.high, pcg_state=env.pcg_state, reward_out=env._rew, done_out=env._done,
                              ep_return=self._ep_return, ep_stats=self._ep_stats)
         self.policy.set_training_mode(True)
         self._train_device_only(self.gradient_steps, self.batch_size)
@@ -208,6 +208,11 @@ class OffPolicyAlgorithm(BaseAlgorithm):
         self._graph_host_bookkeeping(log_interval)
 
     # ---- action selection -----------------------------------------------------------------------------------------
+    def _action_mode(self, warmup: bool) -> int:
+        """`squashed` bit field of cstr_collect_step_f32: bit 0 = the input is the actor's tanh output (predict()
+        unscales it first); bit 1 = multi-agent behaviour (no scale/unscale round trip, no noise)."""
+        return 0 if warmup else 1
+
     def _policy_out_device(self, obs: th.Tensor) -> th.Tensor:
         """Actor output for the fused collect kernel: squashed ([-1,1]) action, device tensor [N, A], no grad."""
         with th.no_grad():
@@ -329,10 +334,10 @@ class OffPolicyAlgorithm(BaseAlgorithm):
         if self.num_timesteps < learning_starts:
             # warm-up: uniform actions from the action space's own generator (:386-388); drawn on the host
             pol = th.as_tensor(self.action_space.sample_batch(n)).to(self.device)
-            squashed = False
+            squashed = self._action_mode(warmup=True)
         else:
             pol = self._policy_out_device(env.obs)
-            squashed = True
+            squashed = self._action_mode(warmup=False)
         noise = None
         if action_noise is not None:
             z = action_noise()

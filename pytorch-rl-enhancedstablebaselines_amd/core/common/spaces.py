@@ -74,16 +74,24 @@ class IndexedBox(Box):
 
     def __init__(self, low, high, indices, dtype=np.float32):
         super().__init__(low=low, high=high, dtype=dtype)
-        self.indices = list(indices)
+        self.indices = np.array(indices)
+
+    def map_to_original(self, values):
+        values = np.array(values) if isinstance(values, list) else values
+        assert values.shape == self.shape, f"value shape {values.shape} does not match space shape {self.shape}"
+        return self.indices, values
 
 
-def split_spaces(space: Box, splits) -> list:
-    """reference: core/common/envs/multi_agent_envs.py:32-61"""
-    out = []
-    for idx in splits:
-        idx = list(idx)
-        out.append(IndexedBox(np.asarray(space.low)[idx], np.asarray(space.high)[idx], idx, dtype=space.dtype))
-    return out
+def split_spaces(observation_space: Box, action_space: Box, observation_splits, action_splits) -> tuple:
+    """reference: core/common/envs/multi_agent_envs.py:32-61 -> (obs_subspaces, action_subspaces)"""
+    def cut(space, splits):
+        out = []
+        for idx in splits:
+            idx = np.array(idx)
+            out.append(IndexedBox(np.asarray(space.low)[idx], np.asarray(space.high)[idx], idx, dtype=space.dtype))
+        return out
+
+    return cut(observation_space, observation_splits), cut(action_space, action_splits)
 
 
 def as_box(space) -> Box:

@@ -1,0 +1,239 @@
+"""MADDPG with the reference's REAL constructor signature -- `n_agents` is the first positional and
+`learning_rate_list` must be a list of length n_agents (reference: core/maddpg/maddpg.py:34-63,
+core/common/base_class.py:931-934) -- and the reference's train() arithmetic (:117-191), quirks included:
+
+  Q1  `_sample_action` applies neither action scaling nor action noise: buffer_action = action = predict()
+      (core/common/multiagent_policy_algorithm.py:369, :391-392);
+  Q2  the actor update evaluates EVERY agent's actor on agent `agent_id`'s observation slice (:169-171), so all
+      agents' observation slices must have the same width;
+  Q3  polyak runs INSIDE the per-agent loop: n_agents passes over all agents' parameters per delayed step (:181-185);
+  Q4  `_update_learning_rate` is called per agent with [actor_opt_i, critic_opt_i] and indexes that 2-list by
+      schedule number: actor optimisers follow schedule 0, critic optimisers schedule 1 (base_class.py:1120-1134).
+
+Each quirk is reproduced (the golden vectors come from the unmodified reference) and can be switched off with
+`faithful_quirks=False`, which gives the textbook behaviour.
+"""
+from typing import List, Optional, Union
+
+import numpy as np
+import torch as th
+from torch.nn import functional as F
+
+from core.common import blas, hip_ops
+from core.common.buffers import ReplayBuffer
+from core.common.logger import DeviceMean
+from core.common.off_policy_algorithm import OffPolicyAlgorithm
+from core.common.spaces import split_spaces
+from core.common.utils import get_schedule_fn, update_learning_rate
+from core.common.vec_env import CSTRVecEnv
+from core.maddpg.policies import MADDPGPolicy, MlpPolicy
+
+
+class MADDPG(OffPolicyAlgorithm):
+    policy_aliases = {"MlpPolicy": MlpPolicy}
+
+    def __init__(self, n_agents: int, policy, env, observation_splits: List[List[int]], action_splits: List[List[int]],
+                 learning_rate_list=1e-3, buffer_size: int = 1_000_000, learning_starts: int = 100, batch_size: int = 256,
+                 tau: float = 0.005, gamma: float = 0.99, train_freq: Union[int, tuple] = 1, gradient_steps: int = 1,
+                 action_noise=None, replay_buffer_class=None, replay_buffer_kwargs: Optional[dict] = None,
+                 optimize_memory_usage: bool = False, policy_delay: int = 2, target_policy_noise: float = 0.2,
+                 target_noise_clip: float = 0.5, stats_window_size: int = 100, tensorboard_log: Optional[str] = None,
+                 policy_kwargs: Optional[dict] = None, verbose: int = 0, seed: Optional[int] = None, device="auto",
+                 _init_setup_model: bool = True, faithful_quirks: bool = True):
+        self.n_agents = n_agents
+        if not hasattr(learning_rate_list, "__len__"):
+            raise TypeError(f"object of type '{type(learning_rate_list).__name__}' has no len()")  # the declared default 1e-3 fails
+        if n_agents != len(learning_rate_list):
+            raise ValueError(f"In a multi-agent scenario, the number of [n_agents, len(learning_rates)]  must be consistent, "
+                             f"now they are [{n_agents}, {len(learning_rate_list)}], respectively.")
+        self.learning_rate_list = learning_rate_list
+        super().__init__(policy, env, learning_rate_list[0], buffer_size, learning_starts, batch_size, tau, gamma, train_freq,
+                         gradient_steps, action_noise=action_noise, replay_buffer_class=replay_buffer_class,
+                         replay_buffer_kwargs=replay_buffer_kwargs, policy_kwargs=policy_kwargs,
+                         stats_window_size=stats_window_size, tensorboard_log=tensorboard_log, verbose=verbose, device=device,
+                         seed=seed, sde_support=False, optimize_memory_usage=optimize_memory_usage,
+                         supported_action_spaces=(object,), support_multi_env=True)
+        self.observation_splits, self.action_splits = observation_splits, action_splits
+        self.observation_space_list, self.action_space_list = split_spaces(self.observation_space, self.action_space,
+                                                                           observation_splits, action_splits)
+        if len(self.observation_space_list) != n_agents or len(self.action_space_list) != n_agents:
+            raise ValueError("observation_splits / action_splits must have one entry per agent")
+        self.policy_delay, self.target_noise_clip, self.target_policy_noise = policy_delay, target_noise_clip, target_policy_noise
+        self.faithful_quirks = faithful_quirks
+        self.debug_capture = False
+        self.last_train_tensors: dict = {}
+        self.noise_queue: List[th.Tensor] = []  # teacher forcing: one tensor per agent per gradient step (maddpg.py:137)
+        if _init_setup_model:
+            self._setup_model()
+
+    # ---- setup ----------------------------------------------------------------------------------------------------
+    def _setup_lr_schedule(self) -> None:
+        self.lr_schedule_list = [get_schedule_fn(lr) for lr in self.learning_rate_list]
+        self.lr_schedule = self.lr_schedule_list[0]
+
+    def _setup_model(self) -> None:
+        """reference: multiagent_policy_algorithm.py:172-212"""
+        self._setup_lr_schedule()
+        blas.configure()
+        if self.world_size > 1 and isinstance(self.env, CSTRVecEnv):
+            self.env.seed_offset = self.rank * self.n_envs
+        self.set_random_seed(self.seed)
+        if self.replay_buffer_class is None:
+            self.replay_buffer_class = ReplayBuffer
+        if self.replay_buffer is None:
+            self.replay_buffer = self.replay_buffer_class(self.buffer_size, self.observation_space, self.action_space,
+                                                          device=self.device, n_envs=self.n_envs,
+                                                          optimize_memory_usage=self.optimize_memory_usage, **self.replay_buffer_kwargs)
+        self.policy = self.policy_class(self.n_agents, self.observation_space, self.action_space, self.observation_space_list,
+                                        self.action_space_list, self.lr_schedule_list, **self.policy_kwargs)
+        self.policy.to_device_arenas(self.device)
+        if self.world_size > 1:
+            self.policy.broadcast_from_rank0()
+            for opt in self.policy.flat_optimizers():
+                opt.grad_scale = 1.0 / self.world_size
+            if self.seed is not None:
+                th.manual_seed(self.seed + 1000003 * self.rank)
+        self._convert_train_freq()
+        self._ep_return = th.zeros(self.n_envs, dtype=th.float32, device=self.device)
+        self._ep_stats = th.zeros(4, dtype=th.float64, device=self.device)
+        self.actor, self.actor_target = self.policy.actor, self.policy.actor_target
+        self.critic, self.critic_target = self.policy.critic, self.policy.critic_target
+        z = lambda: th.zeros((), dtype=th.float32, device=self.device)  # noqa: E731
+        self._loss_sums = {f"{k}{i}": z() for k in ("actor", "critic") for i in range(self.n_agents)}
+        self._static_batch = None
+        if self.faithful_quirks:
+            widths = {len(s) for s in self.observation_splits}
+            if len(widths) != 1:
+                raise ValueError("MADDPG (reference behaviour Q2) needs equally wide observation slices for all agents; "
+                                 "pass faithful_quirks=False for per-agent slices")
+
+    # ---- acting ---------------------------------------------------------------------------------------------------
+    def _action_mode(self, warmup: bool) -> int:
+        if not self.faithful_quirks:
+            return super()._action_mode(warmup)
+        return 2 if warmup else 3  # Q1: no scale/unscale round trip, no noise
+
+    def _sample_action(self, learning_starts: int, action_noise=None, n_envs: int = 1):
+        """reference: multiagent_policy_algorithm.py:346-396 (NumPy compatibility path), quirk Q1"""
+        if not self.faithful_quirks:
+            return super()._sample_action(learning_starts, action_noise, n_envs)
+        if self.num_timesteps < learning_starts:
+            unscaled_action = self.action_space.sample_batch(n_envs)
+        else:
+            unscaled_action, _ = self.predict(self._last_obs, deterministic=False)
+        return unscaled_action, unscaled_action
+
+    # ---- training -------------------------------------------------------------------------------------------------
+    def _update_agent_learning_rates(self, agent_id: int) -> None:
+        """reference: base_class.py:1109-1140 as called at maddpg.py:122 (quirk Q4)."""
+        optimizers = [self.actor.optimizer_list[agent_id], self.critic.optimizer_list[agent_id]]
+        for i, sched in enumerate(self.lr_schedule_list):
+            lr = sched(self._current_progress_remaining)
+            self.logger.record(f"train/agent_{i}_learning_rate", lr)
+            if self.faithful_quirks:
+                opt = optimizers[i] if i < len(optimizers) else None
+                targets = [] if opt is None else [opt]
+            else:
+                targets = optimizers if i == agent_id else []
+            for opt in targets:
+                update_learning_rate(opt, lr)
+                opt.sync_lr()
+
+    def _batch(self, batch_size: int):
+        if self._static_batch is None or self._static_batch.observations.shape[0] != batch_size:
+            self._static_batch = self.replay_buffer.alloc_batch(batch_size)
+            self._target_q = [th.empty(batch_size, 1, dtype=th.float32, device=self.device) for _ in range(self.n_agents)]
+        return self._static_batch
+
+    def train(self, gradient_steps: int, batch_size: int) -> None:
+        """reference: maddpg.py:117-191"""
+        self.policy.set_training_mode(True)
+        self._train_host_pre()
+        self._train_device_only(gradient_steps, batch_size)
+        self._train_host_only(gradient_steps)
+
+    def _train_host_pre(self) -> None:
+        for agent_id in range(self.n_agents):
+            self._update_agent_learning_rates(agent_id)
+
+    def _graph_eligible(self, callback) -> bool:
+        return super()._graph_eligible(callback) and self.gradient_steps % self.policy_delay == 0 and \
+            self._n_updates % self.policy_delay == 0 and not self.noise_queue
+
+    def _train_host_only(self, gradient_steps: int) -> None:
+        n_actor = (self._n_updates + gradient_steps) // self.policy_delay - self._n_updates // self.policy_delay
+        self._n_updates += gradient_steps
+        self.logger.record("train/n_updates", self._n_updates, exclude="tensorboard")
+        for i in range(self.n_agents):
+            if n_actor > 0:
+                self.logger.record(f"train/agent_{i}_actor_loss", DeviceMean(self._loss_sums[f"actor{i}"], n_actor))
+            self.logger.record(f"train/agent_{i}_critic_loss", DeviceMean(self._loss_sums[f"critic{i}"], gradient_steps))
+
+    def _train_device_only(self, gradient_steps: int, batch_size: int) -> None:
+        for v in self._loss_sums.values():
+            v.zero_()
+        n_updates = self._n_updates
+        A, C = self.actor, self.critic
+        for _ in range(gradient_steps):
+            n_updates += 1
+            rd = self.replay_buffer.sample_into(self._batch(batch_size))
+            next_actions_list = []
+            with th.no_grad():
+                for i in range(self.n_agents):  # :131-142
+                    agent_next_obs = A._agent_obs_tensor_extract(i, rd.next_observations)
+                    agent_action = A._agent_action_tensor_extract(i, rd.actions)
+                    if self.noise_queue:
+                        noise = self.noise_queue.pop(0).to(self.device)
+                    else:
+                        noise = agent_action.clone().normal_(0, self.target_policy_noise)
+                    noise = noise.clamp(-self.target_noise_clip, self.target_noise_clip)
+                    next_actions_list.append((self.actor_target.mu_list[i](agent_next_obs) + noise).clamp(-1, 1))
+                next_actions = th.cat(next_actions_list, dim=-1)  # :144
+            captured = []
+            for i in range(self.n_agents):
+                agent_obs = A._agent_obs_tensor_extract(i, rd.observations)
+                with th.no_grad():  # :148-151
+                    qs = self.critic_target(rd.next_observations, next_actions)[i]
+                    hip_ops.td_target_min(qs[0].contiguous(), qs[-1].contiguous(), None, rd.rewards, rd.dones, None, self.gamma,
+                                          self._target_q[i])
+                    target_q = self._target_q[i]
+                current_q = C(rd.observations, rd.actions)[i]  # :154
+                critic_loss = sum(F.mse_loss(q, target_q) for q in current_q)  # :157
+                self._loss_sums[f"critic{i}"] += critic_loss.detach()
+                C.optimizer_list[i].zero_grad()  # :162-164
+                critic_loss.backward()
+                self._allreduce_grads(self.policy.critic_slices[i])
+                C.optimizer_list[i].step()
+                actor_loss = None
+                if n_updates % self.policy_delay == 0:  # :167-185
+                    if self.faithful_quirks:  # Q2: every agent's actor sees agent i's observation slice
+                        actions = th.cat([A.mu_list[j](agent_obs) for j in range(self.n_agents)], dim=-1)
+                    else:
+                        actions = A(rd.observations)
+                    actor_loss = -C.q1_forward(rd.observations, actions)[i].mean()
+                    self._loss_sums[f"actor{i}"] += actor_loss.detach()
+                    A.optimizer_list[i].zero_grad()
+                    actor_loss.backward()
+                    self._allreduce_grads(self.policy.actor_slices[i])
+                    A.optimizer_list[i].step()
+                    if self.faithful_quirks:  # Q3: polyak inside the agent loop
+                        self.policy.critic_target_arena.polyak_from(self.policy.critic_arena, self.tau)
+                        self.policy.actor_target_arena.polyak_from(self.policy.actor_arena, self.tau)
+                if self.debug_capture:
+                    captured.append(dict(target_q=target_q.clone(), current_q=[q.detach().clone() for q in current_q],
+                                         critic_loss=critic_loss.detach().clone(),
+                                         actor_loss=None if actor_loss is None else actor_loss.detach().clone()))
+            if not self.faithful_quirks and n_updates % self.policy_delay == 0:
+                self.policy.critic_target_arena.polyak_from(self.policy.critic_arena, self.tau)
+                self.policy.actor_target_arena.polyak_from(self.policy.actor_arena, self.tau)
+            if self.debug_capture:
+                self.last_train_tensors = dict(agents=captured)
+
+    def learn(self, total_timesteps: int, callback=None, log_interval: int = 4, tb_log_name: str = "MADDPG",
+              reset_num_timesteps: bool = True, progress_bar: bool = False):
+        return super().learn(total_timesteps=total_timesteps, callback=callback, log_interval=log_interval,
+                             tb_log_name=tb_log_name, reset_num_timesteps=reset_num_timesteps, progress_bar=progress_bar)
+
+
+def _unused(_: Optional[np.ndarray] = None) -> MADDPGPolicy:  # keeps the policy class importable from this module
+    return MADDPGPolicy

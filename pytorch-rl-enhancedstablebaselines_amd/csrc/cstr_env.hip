@@ -254,19 +254,28 @@ __global__ void collect_step_kernel(const cstr_coef_t k, const cstr_ring_t ring,
         load_obs<D>(env_obs, i, o, oraw);
         const float2 p = *reinterpret_cast<const float2 *>(policy_out + 2 * i);
         float u0 = p.x, u1 = p.y;
-        if (squashed) {  // predict(): unscale_action (core/common/policies.py:375, :413)
+        if (squashed & 1) {  // predict(): unscale_action (core/common/policies.py:375, :413)
             u0 = lo0 + (0.5f * (u0 + 1.0f) * (hi0 - lo0));
             u1 = lo1 + (0.5f * (u1 + 1.0f) * (hi1 - lo1));
         }
-        float s0 = 2.0f * ((u0 - lo0) / (hi0 - lo0)) - 1.0f;  // scale_action (policies.py:402)
-        float s1 = 2.0f * ((u1 - lo1) / (hi1 - lo1)) - 1.0f;
-        if (noise) {  // off_policy_algorithm.py:401-402
-            const float2 z = *reinterpret_cast<const float2 *>(noise + 2 * i);
-            s0 = fminf(fmaxf(s0 + z.x, -1.0f), 1.0f);
-            s1 = fminf(fmaxf(s1 + z.y, -1.0f), 1.0f);
+        float s0, s1, a0, a1;
+        if (squashed & 2) {
+            // multi-agent algorithms: `isinstance(any(...), spaces.Box)` is always False in the reference, so neither
+            // scaling nor action noise is applied and buffer_action = action = predict() output
+            // (core/common/multiagent_policy_algorithm.py:369, :391-392)
+            s0 = a0 = u0;
+            s1 = a1 = u1;
+        } else {
+            s0 = 2.0f * ((u0 - lo0) / (hi0 - lo0)) - 1.0f;  // scale_action (policies.py:402)
+            s1 = 2.0f * ((u1 - lo1) / (hi1 - lo1)) - 1.0f;
+            if (noise) {  // off_policy_algorithm.py:401-402
+                const float2 z = *reinterpret_cast<const float2 *>(noise + 2 * i);
+                s0 = fminf(fmaxf(s0 + z.x, -1.0f), 1.0f);
+                s1 = fminf(fmaxf(s1 + z.y, -1.0f), 1.0f);
+            }
+            a0 = lo0 + (0.5f * (s0 + 1.0f) * (hi0 - lo0));  // unscale_action (:406)
+            a1 = lo1 + (0.5f * (s1 + 1.0f) * (hi1 - lo1));
         }
-        const float a0 = lo0 + (0.5f * (s0 + 1.0f) * (hi0 - lo0));  // unscale_action (:406)
-        const float a1 = lo1 + (0.5f * (s1 + 1.0f) * (hi1 - lo1));
         int32_t st = step_count[i];
         const bool trunc = cstr_step_lane<INTEG>(k, o, a0, a1, st, on, raw, r);
         const bool d = trunc;

@@ -279,3 +279,74 @@ def test_hipgraph_iteration_equals_eager():
     for k in ("actor", "critic", "target", "obs", "ring_act"):
         np.testing.assert_allclose(e[k], g[k], rtol=2e-3, atol=2e-4, err_msg=k)
     assert abs(e["alpha"] - g["alpha"]) < 1e-5
+
+
+def test_maddpg_train_teacher_forced(golden):
+    """MADDPG on the natural 2-agent split of the CSTR env vs the unmodified reference (core/maddpg/maddpg.py:117-191),
+    quirks Q1-Q4 included: per-agent Q-values / TD targets / losses at 1e-5, weights after 4 steps."""
+    from core.common import legacy_rng
+    from core.maddpg import MADDPG
+
+    g = golden("maddpg_train_kat.npz")
+    gamma, tau, tpn, tnc, delay, lr, B, n_steps, n_agents = g["hyper"]
+    B, n_steps, n_agents = int(B), int(n_steps), int(n_agents)
+    model = MADDPG(n_agents, "MlpPolicy", _make_env(4), [[0, 1], [2, 3]], [[0], [1]], learning_rate_list=[lr, lr], seed=0,
+                   batch_size=B, buffer_size=64 * 4, policy_kwargs=dict(net_arch=[[32, 24], [32, 24]]))
+    assert (model.gamma, model.tau, model.target_policy_noise, model.target_noise_clip, model.policy_delay) == (gamma, tau, tpn, tnc, int(delay))
+    mods = ["actor", "actor_target", "critic", "critic_target"]
+    for nm in mods:  # seeded init == reference (construction order = RNG order)
+        sd = getattr(model, nm).state_dict()
+        assert set(sd) == {k.split("/", 2)[2] for k in g.files if k.startswith(f"before/{nm}/")}
+        for k, v in sd.items():
+            np.testing.assert_array_equal(v.cpu().numpy(), g[f"before/{nm}/{k}"], err_msg=f"init {nm}/{k}")
+    # quirk Q1: predict() output goes to the env and the buffer unchanged
+    pred, _ = model.predict(g["sa_obs"], deterministic=False)
+    np.testing.assert_allclose(pred, g["sa_predict"], rtol=1e-5, atol=1e-6)
+    model._last_obs = g["sa_obs"]
+    model.num_timesteps = 10**6
+    act, buf = model._sample_action(0, None, 4)
+    assert np.array_equal(act, buf) and np.array_equal(g["sa_action"], g["sa_buffer_action"])
+    model.num_timesteps = 0
+    _load_ring(model, g)
+    legacy_rng.seed(int(g["np_seed"]), model.device)
+    model.debug_capture = True
+    for k in range(n_steps):
+        model.noise_queue = [th.as_tensor(g[f"step{k}/noise_raw_agent{a}"]) for a in range(n_agents)]
+        model.train(gradient_steps=1, batch_size=B)
+        assert not model.noise_queue
+        b = model._static_batch
+        for name in ("observations", "actions", "next_observations", "dones", "rewards"):
+            np.testing.assert_array_equal(getattr(b, name).cpu().numpy(), g[f"step{k}/batch_{name}"])
+        lv = model.logger.name_to_value
+        for a in range(n_agents):
+            t = model.last_train_tensors["agents"][a]
+            assert q_err(t["target_q"].cpu().numpy(), g[f"step{k}/agent{a}_target_q"]) < 1e-5, (k, a)
+            assert q_err(t["current_q"][0].cpu().numpy(), g[f"step{k}/agent{a}_current_q1"]) < 1e-5, (k, a)
+            assert q_err(t["current_q"][1].cpu().numpy(), g[f"step{k}/agent{a}_current_q2"]) < 1e-5, (k, a)
+            assert rel_err(float(lv[f"train/agent_{a}_critic_loss"]), float(g[f"step{k}/agent{a}_critic_loss"]), 1e-3) < 1e-5
+            if f"step{k}/agent{a}_actor_loss" in g:
+                assert rel_err(float(lv[f"train/agent_{a}_actor_loss"]), float(g[f"step{k}/agent{a}_actor_loss"]), 1e-3) < 1e-5
+    _check_weights(model, g, "after", mods)
+    assert model._n_updates == n_steps
+
+
+def test_maddpg_signature_errors_and_learn():
+    from core.common.vec_env import CSTRVecEnv
+    from core.maddpg import MADDPG
+
+    env = CSTRVecEnv(32)
+    with pytest.raises(TypeError):  # the reference's declared default learning_rate_list=1e-3 has no len()
+        MADDPG(2, "MlpPolicy", env, [[0, 1], [2, 3]], [[0], [1]])
+    with pytest.raises(ValueError, match="must be consistent"):
+        MADDPG(2, "MlpPolicy", env, [[0, 1], [2, 3]], [[0], [1]], learning_rate_list=[1e-3])
+    model = MADDPG(2, "MlpPolicy", env, [[0, 1], [2, 3]], [[0], [1]], learning_rate_list=[1e-3, 5e-4], seed=2, batch_size=32,
+                   buffer_size=32 * 16, policy_kwargs=dict(net_arch=[[32, 32], [32, 32]]))
+    model.learn(32 * 30)
+    assert model.num_timesteps == 32 * 30 and model._n_updates == 26  # 128 > 100 after the 4th vec-step
+    assert model.actor.optimizer_list[0].step_count == 13 and model.critic.optimizer_list[1].step_count == 26
+    # quirk Q4: actor optimisers follow schedule 0, critic optimisers schedule 1
+    assert model.actor.optimizer_list[1].param_groups[0]["lr"] == 1e-3 and model.critic.optimizer_list[0].param_groups[0]["lr"] == 5e-4
+    for p in model.policy.parameters():
+        assert th.isfinite(p).all()
+    # buffer_action == env action (quirk Q1): the ring's actions are the actor outputs, inside [-1, 1]
+    assert float(model.replay_buffer.actions.abs().max()) <= 1.0

@@ -438,6 +438,91 @@ def gen_td3():
     save("td3_train_kat.npz", **out)
 
 
+def gen_maddpg():
+    """MADDPG on the natural 2-agent split of the CSTR env: agent 0 = reactor 1 ([C1,T1] -> F1), agent 1 = reactor 2."""
+    import torch.nn.functional as F_real
+
+    import core.maddpg.maddpg as mmod
+    from core.common.logger import Logger
+    from core.maddpg.maddpg import MADDPG
+
+    rec = _Recorder()
+
+    class FProxy:
+        def __getattr__(self, name):
+            return getattr(F_real, name)
+
+        @staticmethod
+        def mse_loss(a, b, *args, **kw):
+            rec.mse.append((a.detach().clone(), b.detach().clone()))
+            return F_real.mse_loss(a, b, *args, **kw)
+
+    N, D, A, B, n_steps, n_agents = 4, 4, 2, 64, 4, 2
+    venv = _make_venv(N)
+    model = MADDPG(n_agents, "MlpPolicy", venv, [[0, 1], [2, 3]], [[0], [1]], learning_rate_list=[1e-3, 1e-3], seed=0, device="cpu",
+                   batch_size=B, buffer_size=64 * N, policy_kwargs=dict(net_arch=[[32, 24], [32, 24]]))
+    model.set_logger(Logger(folder=None, output_formats=[]))
+    rng = np.random.default_rng(2718)
+    _fill_buffer(model, rng, 40, N, D, A)
+    out = {}
+    for nm in ("actor", "actor_target", "critic", "critic_target"):
+        out.update(_flat_sd(f"before/{nm}", getattr(model, nm).state_dict()))
+    rb = model.replay_buffer
+    out.update(ring_obs=rb.observations.copy(), ring_next_obs=rb.next_observations.copy(), ring_act=rb.actions.copy(),
+               ring_rew=rb.rewards.copy(), ring_done=rb.dones.copy(), ring_timeout=rb.timeouts.copy(),
+               ring_pos=np.int64(rb.pos), ring_full=np.uint8(rb.full))
+    np.random.seed(777)
+    orig_sample = rb.sample
+    batches = []
+
+    def rec_sample(batch_size, env=None):
+        s = orig_sample(batch_size, env=env)
+        batches.append([x.numpy().copy() for x in s])
+        return s
+
+    rb.sample = rec_sample
+    mmod.F = FProxy()
+    try:
+        for k in range(n_steps):
+            th.manual_seed(2000 + k)
+            g = th.Generator().manual_seed(2000 + k)
+            for a in range(n_agents):  # maddpg.py:137: one normal_ draw per agent, in agent order
+                out[f"step{k}/noise_raw_agent{a}"] = th.empty(B, 1).normal_(0, model.target_policy_noise, generator=g).numpy()
+            model.train(gradient_steps=1, batch_size=B)
+            lv = model.logger.name_to_value
+            for a in range(n_agents):
+                out[f"step{k}/agent{a}_critic_loss"] = np.float32(lv[f"train/agent_{a}_critic_loss"])
+                if model._n_updates % model.policy_delay == 0:
+                    out[f"step{k}/agent{a}_actor_loss"] = np.float32(lv[f"train/agent_{a}_actor_loss"])
+    finally:
+        mmod.F = F_real
+        rb.sample = orig_sample
+    assert len(rec.mse) == 2 * n_agents * n_steps, len(rec.mse)
+    for k in range(n_steps):
+        for fi, fname in enumerate(["observations", "actions", "next_observations", "dones", "rewards"]):
+            out[f"step{k}/batch_{fname}"] = batches[k][fi]
+        for a in range(n_agents):
+            base = 2 * n_agents * k + 2 * a
+            out[f"step{k}/agent{a}_current_q1"] = rec.mse[base][0].numpy()
+            out[f"step{k}/agent{a}_current_q2"] = rec.mse[base + 1][0].numpy()
+            out[f"step{k}/agent{a}_target_q"] = rec.mse[base][1].numpy()
+    for nm in ("actor", "actor_target", "critic", "critic_target"):
+        out.update(_flat_sd(f"after/{nm}", getattr(model, nm).state_dict()))
+    out["hyper"] = np.array([model.gamma, model.tau, model.target_policy_noise, model.target_noise_clip, model.policy_delay,
+                             1e-3, B, n_steps, n_agents], np.float64)
+    out["np_seed"] = np.int64(777)
+    # the reference's _sample_action for multi-agent algos: no scaling, no noise (multiagent_policy_algorithm.py:369, 391-392)
+    obs = rng.uniform(-1, 1, (N, D)).astype(np.float32)
+    model._last_obs = obs
+    model.num_timesteps = 10**6
+    from core.common.noise import NormalActionNoise
+
+    act, buf_act = model._sample_action(0, NormalActionNoise(np.zeros(1), np.ones(1)), N)
+    pred, _ = model.predict(obs, deterministic=False)
+    out.update(sa_obs=obs, sa_action=act, sa_buffer_action=buf_act, sa_predict=pred)
+    save("maddpg_train_kat.npz", **out)
+
+
 def gen_init():
     """Initial weights of the reference policies for seed 0 (construction order = RNG order)."""
     from core.sac.sac import SAC
@@ -466,7 +551,7 @@ def gen_init():
 
 
 GENS = {"env": gen_env, "vecenv": gen_vecenv, "sampler": gen_sampler, "replay": gen_replay, "sac": gen_sac,
-        "td3": gen_td3, "init": gen_init}
+        "td3": gen_td3, "init": gen_init, "maddpg": gen_maddpg}
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
