@@ -342,8 +342,8 @@ def test_maddpg_signature_errors_and_learn():
     model = MADDPG(2, "MlpPolicy", env, [[0, 1], [2, 3]], [[0], [1]], learning_rate_list=[1e-3, 5e-4], seed=2, batch_size=32,
                    buffer_size=32 * 16, policy_kwargs=dict(net_arch=[[32, 32], [32, 32]]))
     model.learn(32 * 30)
-    assert model.num_timesteps == 32 * 30 and model._n_updates == 26  # 128 > 100 after the 4th vec-step
-    assert model.actor.optimizer_list[0].step_count == 13 and model.critic.optimizer_list[1].step_count == 26
+    assert model.num_timesteps == 32 * 30 and model._n_updates == 27  # 128 > 100 after the 4th vec-step: steps 4..30
+    assert model.actor.optimizer_list[0].step_count == 13 and model.critic.optimizer_list[1].step_count == 27
     # quirk Q4: actor optimisers follow schedule 0, critic optimisers schedule 1
     assert model.actor.optimizer_list[1].param_groups[0]["lr"] == 1e-3 and model.critic.optimizer_list[0].param_groups[0]["lr"] == 5e-4
     for p in model.policy.parameters():
