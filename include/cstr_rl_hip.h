@@ -150,6 +150,49 @@ int cstr_adam_f32(float *param, const float *grad, float *exp_avg, float *exp_av
                   const double *lr, double beta1, double beta2, double eps, float grad_scale, int64_t n,
                   cstr_stream_t stream);
 
+/* ---- learner glue around the PyTorch-ROCm GEMMs (csrc/cstr_mlp.hip) --------------------------------------------- */
+
+#define CSTR_ACT_NONE 0
+#define CSTR_ACT_RELU 1
+#define CSTR_ACT_TANH 2
+
+/* nn.Linear's bias add + the activation create_mlp puts behind it (core/common/torch_layers.py:110-183), in place on
+ * the GEMM output y[m][n]. */
+int cstr_bias_act_fwd_f32(float *y, const float *bias, int act, int64_t m, int64_t n, cstr_stream_t stream);
+
+/* Backward of the same: gz = gy * act'(y) and gbias[n] = sum_m gz[m][n] (autograd's threshold/tanh backward + the
+ * bias gradient's batch sum). gbias may be NULL; with act == NONE and gz == gy nothing is copied. */
+int cstr_bias_act_bwd_f32(const float *gy, const float *y, int act, float *gz, float *gbias, int64_t m, int64_t n,
+                          cstr_stream_t stream);
+
+/* SquashedDiagGaussianDistribution (core/common/distributions.py:161-260) with SAC's log_std clamp
+ * (core/sac/policies.py:20-22, :162-164): u = mean + exp(clamp(log_std_raw, -20, 2)) * eps, action = tanh(u),
+ * logp = sum_j Normal.log_prob(u_j) - sum_j log(1 - action_j^2 + 1e-6). logp may be NULL (acting only). */
+int cstr_squashed_gaussian_fwd_f32(const float *mean, const float *log_std_raw, const float *eps, float *action, float *logp,
+                                   int64_t batch, int act_dim, cstr_stream_t stream);
+/* Its analytic backward: (g_action [B][A] or NULL, g_logp [B] or NULL) -> g_mean, g_log_std_raw. */
+int cstr_squashed_gaussian_bwd_f32(const float *g_action, const float *g_logp, const float *action, const float *log_std_raw,
+                                   const float *eps, float *g_mean, float *g_log_std_raw, int64_t batch, int act_dim,
+                                   cstr_stream_t stream);
+
+/* SAC entropy coefficient (core/sac/sac.py:230-243): ent_coef_out = exp(log_alpha); grad_out = d/dlog_alpha of
+ * -mean(log_alpha * (logp + target_entropy)) = -mean(logp + target_entropy). loss_sum / ent_coef_sum (device scalars,
+ * may be NULL) accumulate the values train() logs (:232, :236) without a host sync. */
+int cstr_sac_alpha_f32(const float *log_alpha, const float *logp, float target_entropy, float *grad_out, float *ent_coef_out,
+                       float *loss_sum, float *ent_coef_sum, int64_t batch, cstr_stream_t stream);
+
+/* Twin-critic loss as a backward root: loss = scale * (mse(q1, t) + mse(q2, t)) (scale 0.5: core/sac/sac.py:261;
+ * scale 1: core/td3/td3.py:182, core/maddpg/maddpg.py:157); gq_k = d loss / d q_k. */
+int cstr_twin_q_loss_f32(const float *q1, const float *q2, const float *target, float scale, float *gq1, float *gq2,
+                         float *loss_out, float *loss_sum, int64_t batch, cstr_stream_t stream);
+
+/* SAC actor loss as a backward root (core/sac/sac.py:273-275): loss = mean(ent_coef * logp - min(q1, q2)). */
+int cstr_sac_actor_loss_f32(const float *logp, const float *q1, const float *q2, const float *ent_coef, float *g_logp, float *gq1,
+                            float *gq2, float *loss_out, float *loss_sum, int64_t batch, cstr_stream_t stream);
+
+/* Deterministic-policy actor loss (core/td3/td3.py:194, core/maddpg/maddpg.py:174): loss = -mean(q), gq = -1/B. */
+int cstr_neg_mean_loss_f32(const float *q, float *gq, float *loss_out, float *loss_sum, int64_t batch, cstr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -22,11 +22,14 @@ class SquashedDiagGaussianDistribution:
         self.mean, self.log_std = mean_actions, log_std  # Normal(mean, log_std.exp()) (:161-165)
         return self
 
-    def _eps(self) -> th.Tensor:
+    def draw_eps(self, shape, device, dtype=th.float32) -> th.Tensor:
+        """Standard-normal draw of Normal.rsample (distributions.py:183), or the next teacher-forced tensor."""
         if self.eps_queue:
-            e = self.eps_queue.pop(0)
-            return e.to(self.mean.device, self.mean.dtype).reshape(self.mean.shape)
-        return th.randn(self.mean.shape, dtype=self.mean.dtype, device=self.mean.device)
+            return self.eps_queue.pop(0).to(device, dtype).reshape(shape)
+        return th.randn(shape, dtype=dtype, device=device)
+
+    def _eps(self) -> th.Tensor:
+        return self.draw_eps(self.mean.shape, self.mean.device, self.mean.dtype)
 
     def sample(self) -> th.Tensor:
         """rsample then tanh (:183, :236-239)"""

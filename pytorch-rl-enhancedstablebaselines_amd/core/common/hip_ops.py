@@ -152,3 +152,91 @@ def adam(param, grad, exp_avg, exp_avg_sq, adam_ctl, lr_dev, beta1=0.9, beta2=0.
     check(nv.lib().cstr_adam_f32(ptr(param), ptr(grad), ptr(exp_avg), ptr(exp_avg_sq), ptr(adam_ctl), ptr(lr_dev),
                                  C.c_double(beta1), C.c_double(beta2), C.c_double(eps), C.c_float(grad_scale),
                                  C.c_int64(n), stream_ptr()), "cstr_adam_f32")
+
+
+# ---- learner glue around the GEMMs (csrc/cstr_mlp.hip) ------------------------------------------------------------
+ACT = {"none": 0, "relu": 1, "tanh": 2}
+
+
+def _f32c(t, name):
+    if not (isinstance(t, th.Tensor) and t.is_cuda and t.dtype == th.float32 and t.is_contiguous()):
+        raise ValueError(f"{name}: needs a contiguous float32 device tensor")
+    return t
+
+
+def bias_act_fwd_(y, bias, act: int):
+    m, n = y.shape
+    _f32c(y, "y"), _chk(bias, "bias", (n,), th.float32)
+    check(nv.lib().cstr_bias_act_fwd_f32(ptr(y), ptr(bias), C.c_int(act), C.c_int64(m), C.c_int64(n), stream_ptr()),
+          "cstr_bias_act_fwd_f32")
+    return y
+
+
+def bias_act_bwd(gy, y, act: int, gz, gbias):
+    m, n = gy.shape
+    _f32c(gy, "gy"), _chk(gz, "gz", (m, n), th.float32)
+    if act != 0:
+        _chk(y, "y", (m, n), th.float32)
+    _opt(gbias, "gbias", (n,), th.float32)
+    check(nv.lib().cstr_bias_act_bwd_f32(ptr(gy), ptr(y), C.c_int(act), ptr(gz), ptr(gbias), C.c_int64(m), C.c_int64(n),
+                                         stream_ptr()), "cstr_bias_act_bwd_f32")
+
+
+def squashed_gaussian_fwd(mean, log_std_raw, eps, action, logp):
+    b, a = mean.shape
+    for t, nm in ((mean, "mean"), (log_std_raw, "log_std_raw"), (eps, "eps"), (action, "action")):
+        _chk(t, nm, (b, a), th.float32)
+    _opt(logp, "logp", (b,), th.float32)
+    check(nv.lib().cstr_squashed_gaussian_fwd_f32(ptr(mean), ptr(log_std_raw), ptr(eps), ptr(action), ptr(logp), C.c_int64(b),
+                                                  C.c_int(a), stream_ptr()), "cstr_squashed_gaussian_fwd_f32")
+
+
+def squashed_gaussian_bwd(g_action, g_logp, action, log_std_raw, eps, g_mean, g_log_std_raw):
+    b, a = action.shape
+    for t, nm in ((action, "action"), (log_std_raw, "log_std_raw"), (eps, "eps"), (g_mean, "g_mean"), (g_log_std_raw, "g_log_std_raw")):
+        _chk(t, nm, (b, a), th.float32)
+    _opt(g_action, "g_action", (b, a), th.float32)
+    if g_logp is not None and (g_logp.numel() != b or not g_logp.is_contiguous() or g_logp.dtype != th.float32):
+        raise ValueError("g_logp must be a contiguous float32 tensor with batch elements")
+    check(nv.lib().cstr_squashed_gaussian_bwd_f32(ptr(g_action), ptr(g_logp), ptr(action), ptr(log_std_raw), ptr(eps), ptr(g_mean),
+                                                  ptr(g_log_std_raw), C.c_int64(b), C.c_int(a), stream_ptr()),
+          "cstr_squashed_gaussian_bwd_f32")
+
+
+def _vec(t, name, n):
+    if not (isinstance(t, th.Tensor) and t.is_cuda and t.dtype == th.float32 and t.is_contiguous() and t.numel() == n):
+        raise ValueError(f"{name}: needs a contiguous float32 device tensor with {n} elements")
+    return t
+
+
+def sac_alpha(log_alpha, logp, target_entropy: float, grad_out, ent_coef_out, loss_sum=None, ent_coef_sum=None):
+    b = logp.numel()
+    _vec(logp, "logp", b)
+    for t, nm in ((log_alpha, "log_alpha"), (grad_out, "grad_out"), (ent_coef_out, "ent_coef_out")):
+        _vec(t, nm, 1)
+    check(nv.lib().cstr_sac_alpha_f32(ptr(log_alpha), ptr(logp), C.c_float(target_entropy), ptr(grad_out), ptr(ent_coef_out),
+                                      ptr(loss_sum), ptr(ent_coef_sum), C.c_int64(b), stream_ptr()), "cstr_sac_alpha_f32")
+
+
+def twin_q_loss(q1, q2, target, scale: float, gq1, gq2, loss_out=None, loss_sum=None):
+    b = q1.numel()
+    for t, nm in ((q1, "q1"), (q2, "q2"), (target, "target"), (gq1, "gq1"), (gq2, "gq2")):
+        _vec(t, nm, b)
+    check(nv.lib().cstr_twin_q_loss_f32(ptr(q1), ptr(q2), ptr(target), C.c_float(scale), ptr(gq1), ptr(gq2), ptr(loss_out),
+                                        ptr(loss_sum), C.c_int64(b), stream_ptr()), "cstr_twin_q_loss_f32")
+
+
+def sac_actor_loss(logp, q1, q2, ent_coef, g_logp, gq1, gq2, loss_out=None, loss_sum=None):
+    b = logp.numel()
+    for t, nm in ((logp, "logp"), (q1, "q1"), (q2, "q2"), (g_logp, "g_logp"), (gq1, "gq1"), (gq2, "gq2")):
+        _vec(t, nm, b)
+    _vec(ent_coef, "ent_coef", 1)
+    check(nv.lib().cstr_sac_actor_loss_f32(ptr(logp), ptr(q1), ptr(q2), ptr(ent_coef), ptr(g_logp), ptr(gq1), ptr(gq2),
+                                           ptr(loss_out), ptr(loss_sum), C.c_int64(b), stream_ptr()), "cstr_sac_actor_loss_f32")
+
+
+def neg_mean_loss(q, gq, loss_out=None, loss_sum=None):
+    b = q.numel()
+    _vec(q, "q", b), _vec(gq, "gq", b)
+    check(nv.lib().cstr_neg_mean_loss_f32(ptr(q), ptr(gq), ptr(loss_out), ptr(loss_sum), C.c_int64(b), stream_ptr()),
+          "cstr_neg_mean_loss_f32")

@@ -12,7 +12,7 @@ import numpy as np
 import torch as th
 from torch.nn import functional as F
 
-from core.common import hip_ops
+from core.common import fused, hip_ops
 from core.common.arena import FlatAdam, ParamArena
 from core.common.logger import DeviceMean
 from core.common.off_policy_algorithm import OffPolicyAlgorithm
@@ -67,9 +67,30 @@ class SAC(OffPolicyAlgorithm):
                 self.ent_coef_optimizer.grad_scale = 1.0 / self.world_size
         else:
             self.ent_coef_tensor = th.tensor(float(self.ent_coef), device=self.device)
-        z = lambda: th.zeros((), dtype=th.float32, device=self.device)  # noqa: E731
+        z = lambda: th.zeros(1, dtype=th.float32, device=self.device)  # noqa: E731
         self._loss_sums = dict(actor=z(), critic=z(), ent_coef_loss=z(), ent_coef=z())
+        self._loss_now = dict(actor=z(), critic=z())
+        self._ent_coef_buf = z()
         self._static_batch = None
+        # fused learner path (core/common/fused.py): GEMMs in rocBLAS, everything else hand-written HIP
+        self.fused_learner = self._fused_supported()
+        if self.fused_learner:
+            self._fast_actor = fused.FastSacActor(self.actor)
+            self._fast_critic = fused.FastTwinCritic(self.critic)
+            self._fast_critic_target = fused.FastTwinCritic(self.critic_target)
+
+    def _fused_supported(self) -> bool:
+        from core.common.arena import FlatAdam
+
+        return (len(self.critic.q_networks) == 2 and isinstance(self.actor.optimizer, FlatAdam)
+                and isinstance(self.critic.optimizer, FlatAdam) and fused.FastMLP.supported(self.actor.latent_pi)
+                and all(fused.FastMLP.supported(q) for q in self.critic.q_networks))
+
+    def _policy_out_device(self, obs: th.Tensor) -> th.Tensor:
+        if not self.fused_learner:
+            return super()._policy_out_device(obs)
+        with th.no_grad():
+            return self._fast_actor.action_log_prob(obs, train_params=False, want_logp=False)[0]
 
     def _create_aliases(self) -> None:
         self.actor = self.policy.actor
@@ -112,6 +133,61 @@ class SAC(OffPolicyAlgorithm):
             self.logger.record("train/ent_coef_loss", DeviceMean(s["ent_coef_loss"], gradient_steps))
 
     def _gradient_step(self, batch_size: int, gradient_step: int) -> None:
+        if self.fused_learner:
+            return self._gradient_step_fused(batch_size, gradient_step)
+        return self._gradient_step_aten(batch_size, gradient_step)
+
+    def _gradient_step_fused(self, batch_size: int, gradient_step: int) -> None:
+        """The same statements as `_gradient_step_aten` (sac.py:215-287), evaluated on the fused path: losses are
+        backward roots whose kernels emit d(loss)/d(inputs) directly; parameter gradients land in the arenas."""
+        s, pol = self._loss_sums, self.policy
+        rd = self.replay_buffer.sample_into(self._batch(batch_size))  # :215
+        B = rd.observations.shape[0]
+        if not hasattr(self, "_g_bufs") or self._g_bufs[0].shape[0] != B:
+            e = lambda *sh: th.empty(*sh, dtype=th.float32, device=self.device)  # noqa: E731
+            self._g_bufs = (e(B, 1), e(B, 1), e(B))
+        gq1, gq2, g_lp = self._g_bufs
+
+        actions_pi, log_prob = self._fast_actor.action_log_prob(rd.observations)  # :222
+
+        if self.ent_coef_optimizer is not None:  # :230-243
+            hip_ops.sac_alpha(self.log_ent_coef.detach(), log_prob.detach(), self.target_entropy, self._ent_arena.grad[0:1],
+                              self._ent_coef_buf, s["ent_coef_loss"], s["ent_coef"])
+            self._allreduce_grads(self._ent_arena)
+            self.ent_coef_optimizer.step()
+            ent_coef = self._ent_coef_buf
+        else:
+            ent_coef = self.ent_coef_tensor.reshape(1)
+            s["ent_coef"] += ent_coef
+
+        with th.no_grad():  # :245-254
+            next_actions, next_log_prob = self._fast_actor.action_log_prob(rd.next_observations, train_params=False)
+            q1_t, q2_t = self._fast_critic_target(rd.next_observations, next_actions, train_params=False)
+            hip_ops.td_target_min(q1_t, q2_t, next_log_prob, rd.rewards, rd.dones, ent_coef, self.gamma, self._target_q)
+
+        q1, q2 = self._fast_critic(rd.observations, rd.actions)  # :258
+        hip_ops.twin_q_loss(q1, q2, self._target_q, 0.5, gq1, gq2, self._loss_now["critic"], s["critic"])  # :261
+        th.autograd.backward([q1, q2], [gq1, gq2])  # :266-268
+        self._allreduce_grads(pol.critic_arena)
+        self.critic.optimizer.step()
+
+        q1_pi, q2_pi = self._fast_critic(rd.observations, actions_pi, train_params=False)  # :273-275 (critic weights frozen)
+        hip_ops.sac_actor_loss(log_prob, q1_pi, q2_pi, ent_coef, g_lp, gq1, gq2, self._loss_now["actor"], s["actor"])
+        th.autograd.backward([log_prob, q1_pi, q2_pi], [g_lp, gq1, gq2])  # :279-281
+        self._allreduce_grads(pol.actor_arena)
+        self.actor.optimizer.step()
+
+        if gradient_step % self.target_update_interval == 0:  # :284-287
+            pol.critic_target_arena.polyak_from(pol.critic_arena, self.tau)
+
+        if self.debug_capture:
+            self.last_train_tensors = dict(target_q=self._target_q.clone(), current_q=[q1.detach().clone(), q2.detach().clone()],
+                                           critic_loss=self._loss_now["critic"].clone(), actor_loss=self._loss_now["actor"].clone(),
+                                           ent_coef=ent_coef.detach().clone(), log_prob=log_prob.detach().clone())
+
+    def _gradient_step_aten(self, batch_size: int, gradient_step: int) -> None:
+        """Stock-ATen evaluation of the step (nn.Module forwards, autograd losses): the fallback for configurations the
+        fused path does not cover (custom activations / optimisers / n_critics) and the A/B reference in tests."""
         s = self._loss_sums
         replay_data = self.replay_buffer.sample_into(self._batch(batch_size))  # :215
 
@@ -128,7 +204,7 @@ class SAC(OffPolicyAlgorithm):
             self.ent_coef_optimizer.step()
         else:
             ent_coef = self.ent_coef_tensor.reshape(1)
-        s["ent_coef"] += ent_coef.reshape(())
+        s["ent_coef"] += ent_coef.reshape(1)
 
         with th.no_grad():  # :245-254
             next_actions, next_log_prob = self.actor.action_log_prob(replay_data.next_observations)

@@ -5,7 +5,7 @@ from typing import List, Optional, Union
 import torch as th
 from torch.nn import functional as F
 
-from core.common import hip_ops
+from core.common import fused, hip_ops
 from core.common.logger import DeviceMean
 from core.common.off_policy_algorithm import OffPolicyAlgorithm
 from core.td3.policies import MlpPolicy
@@ -40,9 +40,23 @@ class TD3(OffPolicyAlgorithm):
         super()._setup_model()
         self.actor, self.actor_target = self.policy.actor, self.policy.actor_target
         self.critic, self.critic_target = self.policy.critic, self.policy.critic_target
-        z = lambda: th.zeros((), dtype=th.float32, device=self.device)  # noqa: E731
+        z = lambda: th.zeros(1, dtype=th.float32, device=self.device)  # noqa: E731
         self._loss_sums = dict(actor=z(), critic=z())
+        self._loss_now = dict(actor=z(), critic=z())
         self._static_batch = None
+        from core.common.arena import FlatAdam
+
+        self.fused_learner = (isinstance(self.actor.optimizer, FlatAdam) and isinstance(self.critic.optimizer, FlatAdam)
+                              and fused.FastMLP.supported(self.actor.mu) and all(fused.FastMLP.supported(q) for q in self.critic.q_networks))
+        if self.fused_learner:
+            self._fast_actor, self._fast_actor_target = fused.FastMLP(self.actor.mu), fused.FastMLP(self.actor_target.mu)
+            self._fast_critic, self._fast_critic_target = fused.FastTwinCritic(self.critic), fused.FastTwinCritic(self.critic_target)
+
+    def _policy_out_device(self, obs: th.Tensor) -> th.Tensor:
+        if not self.fused_learner:
+            return super()._policy_out_device(obs)
+        with th.no_grad():
+            return self._fast_actor(obs, train_params=False)
 
     def _batch(self, batch_size: int):
         if self._static_batch is None or self._static_batch.observations.shape[0] != batch_size:
@@ -79,6 +93,9 @@ class TD3(OffPolicyAlgorithm):
         n_updates = self._n_updates  # host counter advances in _train_host_only
         for _ in range(gradient_steps):
             n_updates += 1
+            if self.fused_learner:
+                self._gradient_step_fused(batch_size, n_updates)
+                continue
             replay_data = self.replay_buffer.sample_into(self._batch(batch_size))
             with th.no_grad():
                 if self.noise_queue:
@@ -113,6 +130,46 @@ class TD3(OffPolicyAlgorithm):
                 self.last_train_tensors = dict(target_q=target_q_values.clone(), current_q=[q.detach().clone() for q in current_q_values],
                                                critic_loss=critic_loss.detach().clone(),
                                                actor_loss=None if actor_loss is None else actor_loss.detach().clone())
+
+    def _gradient_step_fused(self, batch_size: int, n_updates: int) -> None:
+        """td3.py:161-206 on the fused path (core/common/fused.py)."""
+        s, pol = self._loss_sums, self.policy
+        rd = self.replay_buffer.sample_into(self._batch(batch_size))
+        B = rd.observations.shape[0]
+        if not hasattr(self, "_g_bufs") or self._g_bufs[0].shape[0] != B:
+            self._g_bufs = (th.empty(B, 1, device=self.device), th.empty(B, 1, device=self.device))
+        gq1, gq2 = self._g_bufs
+        with th.no_grad():  # :167-176
+            noise = self.noise_queue.pop(0).to(self.device) if self.noise_queue else rd.actions.clone().normal_(0, self.target_policy_noise)
+            noise = noise.clamp(-self.target_noise_clip, self.target_noise_clip)
+            next_actions = (self._fast_actor_target(rd.next_observations, train_params=False) + noise).clamp(-1, 1)
+            qs = self._fast_critic_target(rd.next_observations, next_actions, train_params=False)
+            hip_ops.td_target_min(qs[0], qs[-1], None, rd.rewards, rd.dones, None, self.gamma, self._target_q)
+        qs = self._fast_critic(rd.observations, rd.actions)  # :179
+        q1, q2 = qs[0], qs[-1]
+        # n_critics == 1 (DDPG): loss = mse(q1, t) -> scale 0.5 of the doubled term
+        hip_ops.twin_q_loss(q1, q2, self._target_q, 1.0 if len(qs) == 2 else 0.5, gq1, gq2, self._loss_now["critic"], s["critic"])
+        if len(qs) == 2:
+            th.autograd.backward([q1, q2], [gq1, gq2])
+        else:
+            th.autograd.backward([q1], [gq1 + gq2])
+        self._allreduce_grads(pol.critic_arena)
+        self.critic.optimizer.step()
+        actor_done = False
+        if n_updates % self.policy_delay == 0:  # :192-206
+            a = self._fast_actor(rd.observations)
+            (q1_pi,) = self._fast_critic(rd.observations, a, train_params=False, only_first=True)
+            hip_ops.neg_mean_loss(q1_pi, gq1, self._loss_now["actor"], s["actor"])
+            th.autograd.backward([q1_pi], [gq1])
+            self._allreduce_grads(pol.actor_arena)
+            self.actor.optimizer.step()
+            pol.critic_target_arena.polyak_from(pol.critic_arena, self.tau)
+            pol.actor_target_arena.polyak_from(pol.actor_arena, self.tau)
+            actor_done = True
+        if self.debug_capture:
+            self.last_train_tensors = dict(target_q=self._target_q.clone(), current_q=[q.detach().clone() for q in qs],
+                                           critic_loss=self._loss_now["critic"].clone(),
+                                           actor_loss=self._loss_now["actor"].clone() if actor_done else None)
 
     def learn(self, total_timesteps: int, callback=None, log_interval: int = 4, tb_log_name: str = "TD3",
               reset_num_timesteps: bool = True, progress_bar: bool = False):

@@ -1,0 +1,335 @@
+// cstr_mlp.hip -- element-wise / reduction glue of the learner for gfx950. The dense contractions stay in
+// PyTorch-ROCm (rocBLAS GEMMs, north_star); everything around them that the reference leaves to dozens of tiny
+// ATen kernels per step is fused here:
+//   * Linear epilogues: bias + activation forward; activation-gradient + bias-gradient (column sum) backward
+//   * SAC's squashed-Gaussian head: rsample -> tanh -> log-prob forward, analytic backward
+//   * loss heads that are backward ROOTS (upstream gradient == 1): the kernels emit the loss value AND d(loss)/d(Q),
+//     d(loss)/d(logp) directly, so no autograd nodes exist for the losses
+//   * SAC's entropy-coefficient loss/gradient
+// All latency-bound at batch 256; 64-wide waves, LDS tree reductions, deterministic (no atomics).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/cstr_rl_hip.h"
+#include "cstr_device.h"
+
+namespace {
+
+constexpr int ACT_NONE = 0, ACT_RELU = 1, ACT_TANH = 2;
+
+// ---- Linear epilogues --------------------------------------------------------------------------------
+
+// y[m][n] = act(y[m][n] + bias[n])   (nn.Linear + nn.ReLU / nn.Tanh of create_mlp, core/common/torch_layers.py:110-183)
+template <int ACT>
+__global__ void bias_act_fwd_kernel(float *__restrict__ y, const float *__restrict__ bias, const int64_t total, const int n)
+{
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        float v = y[i] + bias[i % n];
+        if (ACT == ACT_RELU) v = v > 0.0f ? v : 0.0f;
+        if (ACT == ACT_TANH) v = tanhf(v);
+        y[i] = v;
+    }
+}
+
+template <int ACT>
+__global__ void bias_act_fwd_vec4_kernel(float4 *__restrict__ y, const float4 *__restrict__ bias, const int64_t total4, const int n4)
+{
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
+        float4 v = y[i];
+        const float4 b = bias[i % n4];
+        v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+        if (ACT == ACT_RELU) { v.x = fmaxf(v.x, 0.0f); v.y = fmaxf(v.y, 0.0f); v.z = fmaxf(v.z, 0.0f); v.w = fmaxf(v.w, 0.0f); }
+        if (ACT == ACT_TANH) { v.x = tanhf(v.x); v.y = tanhf(v.y); v.z = tanhf(v.z); v.w = tanhf(v.w); }
+        y[i] = v;
+    }
+}
+
+// gz[m][n] = gy[m][n] * act'(y[m][n]);  gbias[n] = sum_m gz[m][n]   (threshold_backward / tanh_backward + the bias
+// gradient's sum over the batch). One workgroup owns 64 columns: lanes run along columns (coalesced rows), the four
+// waves stride over rows, LDS combines them; every gbias element is written exactly once -> deterministic.
+template <int ACT>
+__global__ __launch_bounds__(256) void bias_act_bwd_kernel(const float *__restrict__ gy, const float *__restrict__ y,
+                                                           float *__restrict__ gz, float *__restrict__ gbias, const int m,
+                                                           const int n)
+{
+    __shared__ float part[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + lane;
+    float acc = 0.0f;
+    if (col < n) {
+        for (int r = wave; r < m; r += 4) {
+            const int64_t i = (int64_t)r * n + col;
+            float g = gy[i];
+            if (ACT == ACT_RELU) g = y[i] > 0.0f ? g : 0.0f;
+            if (ACT == ACT_TANH) { const float t = y[i]; g = g * (1.0f - t * t); }
+            if (ACT != ACT_NONE || gz != gy) gz[i] = g;
+            acc += g;
+        }
+    }
+    part[wave][lane] = acc;
+    __syncthreads();
+    if (wave == 0 && col < n && gbias) gbias[col] = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+}
+
+// ---- block reduction helper ---------------------------------------------------------------------------
+
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ float block_sum_256(float v, float *sm)
+{
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) sm[wave] = v;
+    __syncthreads();
+    const float r = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+    __syncthreads();
+    return r;
+}
+
+// ---- squashed diagonal Gaussian (core/common/distributions.py:161-260) ----------------------------------
+
+constexpr float LOG_STD_MIN = -20.0f, LOG_STD_MAX = 2.0f;  // core/sac/policies.py:20-22
+
+// u = mean + exp(clamp(log_std)) * eps; a = tanh(u); logp = sum_j Normal.log_prob(u_j) - sum_j log(1 - a_j^2 + 1e-6)
+__global__ void squashed_gaussian_fwd_kernel(const float *__restrict__ mean, const float *__restrict__ log_std_raw,
+                                             const float *__restrict__ eps, float *__restrict__ action,
+                                             float *__restrict__ logp, const int64_t batch, const int act_dim)
+{
+    const float half_log_2pi = 0.91893853320467274178f;  // math.log(math.sqrt(2 * math.pi))
+    for (int64_t b = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; b < batch; b += (int64_t)gridDim.x * blockDim.x) {
+        float lp = 0.0f, corr = 0.0f;
+        for (int j = 0; j < act_dim; ++j) {
+            const int64_t i = b * act_dim + j;
+            const float mu = mean[i];
+            const float ls = fminf(fmaxf(log_std_raw[i], LOG_STD_MIN), LOG_STD_MAX);
+            const float s = expf(ls);
+            const float u = mu + s * eps[i];  // Normal.rsample
+            const float a = tanhf(u);
+            action[i] = a;
+            const float d = u - mu, var = s * s;
+            lp += -(d * d) / (2.0f * var) - logf(s) - half_log_2pi;  // torch Normal.log_prob
+            corr += logf(1.0f - a * a + 1e-6f);                      // distributions.py:232
+        }
+        if (logp) logp[b] = lp - corr;
+    }
+}
+
+// Analytic backward. With d = s*eps the Gaussian term is -eps^2/2 - ls - c, so
+//   dlogp/du_j = 2 a (1 - a^2) / (1 - a^2 + 1e-6),  da/du = 1 - a^2
+//   g_mean = G_u,  g_ls = G_u * eps * s - g_logp,  g_raw = g_ls inside the clamp range, 0 outside
+// (autograd through the reference's expression adds terms that cancel to rounding noise, ~1e-7 relative).
+__global__ void squashed_gaussian_bwd_kernel(const float *__restrict__ g_action, const float *__restrict__ g_logp,
+                                             const float *__restrict__ action, const float *__restrict__ log_std_raw,
+                                             const float *__restrict__ eps, float *__restrict__ g_mean,
+                                             float *__restrict__ g_log_std_raw, const int64_t batch, const int act_dim)
+{
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < batch * act_dim; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = i / act_dim;
+        const float a = action[i], raw = log_std_raw[i];
+        const float ls = fminf(fmaxf(raw, LOG_STD_MIN), LOG_STD_MAX);
+        const float s = expf(ls);
+        const float one_m = 1.0f - a * a;
+        const float gl = g_logp ? g_logp[b] : 0.0f;
+        const float ga = g_action ? g_action[i] : 0.0f;
+        const float gu = ga * one_m + gl * (2.0f * a * one_m / (one_m + 1e-6f));
+        g_mean[i] = gu;
+        const float gls = gu * eps[i] * s - gl;
+        g_log_std_raw[i] = (raw >= LOG_STD_MIN && raw <= LOG_STD_MAX) ? gls : 0.0f;
+    }
+}
+
+// ---- loss heads (single workgroup; batch <= 16384) -----------------------------------------------------
+
+// SAC entropy coefficient (core/sac/sac.py:230-243): ent_coef = exp(log_alpha); loss = -mean(log_alpha * (logp + H));
+// d loss / d log_alpha = -mean(logp + H). Writes the gradient straight into the alpha arena's gradient word.
+__global__ __launch_bounds__(256) void sac_alpha_kernel(const float *__restrict__ log_alpha, const float *__restrict__ logp,
+                                                        const float target_entropy, float *__restrict__ grad_out,
+                                                        float *__restrict__ ent_coef_out, float *__restrict__ loss_sum,
+                                                        float *__restrict__ ent_coef_sum, const int batch)
+{
+    __shared__ float sm[4];
+    float acc = 0.0f;
+    for (int b = threadIdx.x; b < batch; b += 256) acc += logp[b] + target_entropy;
+    const float mean = block_sum_256(acc, sm) / (float)batch;
+    if (threadIdx.x == 0) {
+        const float la = log_alpha[0], ec = expf(la);
+        grad_out[0] = -mean;
+        ent_coef_out[0] = ec;
+        if (loss_sum) loss_sum[0] += -(la * mean);
+        if (ent_coef_sum) ent_coef_sum[0] += ec;
+    }
+}
+
+// Twin-critic loss (SAC: scale 0.5, core/sac/sac.py:261; TD3/MADDPG: scale 1, core/td3/td3.py:182):
+// loss = scale * (mse(q1,t) + mse(q2,t));  d loss / d q_k = scale * 2 (q_k - t) / B
+__global__ __launch_bounds__(256) void twin_q_loss_kernel(const float *__restrict__ q1, const float *__restrict__ q2,
+                                                          const float *__restrict__ target, const float scale,
+                                                          float *__restrict__ gq1, float *__restrict__ gq2,
+                                                          float *__restrict__ loss_out, float *__restrict__ loss_sum, const int batch)
+{
+    __shared__ float sm[4];
+    const float k = scale * 2.0f / (float)batch;
+    float a1 = 0.0f, a2 = 0.0f;
+    for (int b = threadIdx.x; b < batch; b += 256) {
+        const float t = target[b], d1 = q1[b] - t, d2 = q2[b] - t;
+        gq1[b] = k * d1;
+        gq2[b] = k * d2;
+        a1 += d1 * d1;
+        a2 += d2 * d2;
+    }
+    const float s1 = block_sum_256(a1, sm), s2 = block_sum_256(a2, sm);
+    if (threadIdx.x == 0) {
+        const float loss = scale * (s1 / (float)batch + s2 / (float)batch);
+        if (loss_out) loss_out[0] = loss;
+        if (loss_sum) loss_sum[0] += loss;
+    }
+}
+
+// SAC actor loss (core/sac/sac.py:273-275): loss = mean(ent_coef * logp - min(q1, q2));
+// d/d logp = ent_coef / B;  d/d q_k = -1/B for the smaller one (first index on ties, like th.min), 0 for the other
+__global__ __launch_bounds__(256) void sac_actor_loss_kernel(const float *__restrict__ logp, const float *__restrict__ q1,
+                                                             const float *__restrict__ q2, const float *__restrict__ ent_coef,
+                                                             float *__restrict__ g_logp, float *__restrict__ gq1,
+                                                             float *__restrict__ gq2, float *__restrict__ loss_out,
+                                                             float *__restrict__ loss_sum, const int batch)
+{
+    __shared__ float sm[4];
+    const float ec = ent_coef[0], inv = 1.0f / (float)batch;
+    float acc = 0.0f;
+    for (int b = threadIdx.x; b < batch; b += 256) {
+        const float a = q1[b], c = q2[b];
+        const bool first = a <= c;
+        acc += ec * logp[b] - (first ? a : c);
+        g_logp[b] = ec * inv;
+        gq1[b] = first ? -inv : 0.0f;
+        gq2[b] = first ? 0.0f : -inv;
+    }
+    const float s = block_sum_256(acc, sm);
+    if (threadIdx.x == 0) {
+        const float loss = s * inv;
+        if (loss_out) loss_out[0] = loss;
+        if (loss_sum) loss_sum[0] += loss;
+    }
+}
+
+// Deterministic-policy actor loss (core/td3/td3.py:194, core/maddpg/maddpg.py:174): loss = -mean(q1); dq = -1/B
+__global__ __launch_bounds__(256) void neg_mean_loss_kernel(const float *__restrict__ q, float *__restrict__ gq,
+                                                            float *__restrict__ loss_out, float *__restrict__ loss_sum, const int batch)
+{
+    __shared__ float sm[4];
+    const float inv = 1.0f / (float)batch;
+    float acc = 0.0f;
+    for (int b = threadIdx.x; b < batch; b += 256) {
+        acc += q[b];
+        gq[b] = -inv;
+    }
+    const float s = block_sum_256(acc, sm);
+    if (threadIdx.x == 0) {
+        const float loss = -(s * inv);
+        if (loss_out) loss_out[0] = loss;
+        if (loss_sum) loss_sum[0] += loss;
+    }
+}
+
+}  // namespace
+
+// ---- C ABI ---------------------------------------------------------------------------------------------
+
+extern "C" int cstr_bias_act_fwd_f32(float *y, const float *bias, int act, int64_t m, int64_t n, cstr_stream_t stream)
+{
+    if (!y || !bias || m <= 0 || n <= 0) return CSTR_E_BADARG;
+    if (act < 0 || act > 2 || n > 0x7fffffff) return CSTR_E_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t total = m * n;
+    int block, grid;
+    if ((n & 3) == 0 && aligned16(y) && aligned16(bias)) {
+        flat_launch_shape(total / 4, block, grid);
+        float4 *y4 = reinterpret_cast<float4 *>(y);
+        const float4 *b4 = reinterpret_cast<const float4 *>(bias);
+        if (act == 0) bias_act_fwd_vec4_kernel<0><<<grid, block, 0, s>>>(y4, b4, total / 4, (int)(n / 4));
+        else if (act == 1) bias_act_fwd_vec4_kernel<1><<<grid, block, 0, s>>>(y4, b4, total / 4, (int)(n / 4));
+        else bias_act_fwd_vec4_kernel<2><<<grid, block, 0, s>>>(y4, b4, total / 4, (int)(n / 4));
+    } else {
+        flat_launch_shape(total, block, grid);
+        if (act == 0) bias_act_fwd_kernel<0><<<grid, block, 0, s>>>(y, bias, total, (int)n);
+        else if (act == 1) bias_act_fwd_kernel<1><<<grid, block, 0, s>>>(y, bias, total, (int)n);
+        else bias_act_fwd_kernel<2><<<grid, block, 0, s>>>(y, bias, total, (int)n);
+    }
+    return (int)hipGetLastError();
+}
+
+extern "C" int cstr_bias_act_bwd_f32(const float *gy, const float *y, int act, float *gz, float *gbias, int64_t m, int64_t n,
+                                     cstr_stream_t stream)
+{
+    if (!gy || !gz || m <= 0 || n <= 0 || (act != 0 && !y)) return CSTR_E_BADARG;
+    if (act < 0 || act > 2 || m > 0x7fffffff || n > 0x7fffffff) return CSTR_E_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    const int grid = (int)((n + 63) / 64);
+    if (act == 0) bias_act_bwd_kernel<0><<<grid, 256, 0, s>>>(gy, y, gz, gbias, (int)m, (int)n);
+    else if (act == 1) bias_act_bwd_kernel<1><<<grid, 256, 0, s>>>(gy, y, gz, gbias, (int)m, (int)n);
+    else bias_act_bwd_kernel<2><<<grid, 256, 0, s>>>(gy, y, gz, gbias, (int)m, (int)n);
+    return (int)hipGetLastError();
+}
+
+extern "C" int cstr_squashed_gaussian_fwd_f32(const float *mean, const float *log_std_raw, const float *eps, float *action,
+                                              float *logp, int64_t batch, int act_dim, cstr_stream_t stream)
+{
+    if (!mean || !log_std_raw || !eps || !action || batch <= 0 || act_dim <= 0) return CSTR_E_BADARG;
+    int block, grid;
+    flat_launch_shape(batch, block, grid);
+    squashed_gaussian_fwd_kernel<<<grid, block, 0, (hipStream_t)stream>>>(mean, log_std_raw, eps, action, logp, batch, act_dim);
+    return (int)hipGetLastError();
+}
+
+extern "C" int cstr_squashed_gaussian_bwd_f32(const float *g_action, const float *g_logp, const float *action,
+                                              const float *log_std_raw, const float *eps, float *g_mean, float *g_log_std_raw,
+                                              int64_t batch, int act_dim, cstr_stream_t stream)
+{
+    if (!action || !log_std_raw || !eps || !g_mean || !g_log_std_raw || batch <= 0 || act_dim <= 0) return CSTR_E_BADARG;
+    int block, grid;
+    flat_launch_shape(batch * act_dim, block, grid);
+    squashed_gaussian_bwd_kernel<<<grid, block, 0, (hipStream_t)stream>>>(g_action, g_logp, action, log_std_raw, eps, g_mean,
+                                                                          g_log_std_raw, batch, act_dim);
+    return (int)hipGetLastError();
+}
+
+extern "C" int cstr_sac_alpha_f32(const float *log_alpha, const float *logp, float target_entropy, float *grad_out,
+                                  float *ent_coef_out, float *loss_sum, float *ent_coef_sum, int64_t batch, cstr_stream_t stream)
+{
+    if (!log_alpha || !logp || !grad_out || !ent_coef_out || batch <= 0) return CSTR_E_BADARG;
+    if (batch > CSTR_MAX_SAMPLE_BATCH) return CSTR_E_UNSUPPORTED;
+    sac_alpha_kernel<<<1, 256, 0, (hipStream_t)stream>>>(log_alpha, logp, target_entropy, grad_out, ent_coef_out, loss_sum,
+                                                         ent_coef_sum, (int)batch);
+    return (int)hipGetLastError();
+}
+
+extern "C" int cstr_twin_q_loss_f32(const float *q1, const float *q2, const float *target, float scale, float *gq1, float *gq2,
+                                    float *loss_out, float *loss_sum, int64_t batch, cstr_stream_t stream)
+{
+    if (!q1 || !q2 || !target || !gq1 || !gq2 || batch <= 0) return CSTR_E_BADARG;
+    if (batch > CSTR_MAX_SAMPLE_BATCH) return CSTR_E_UNSUPPORTED;
+    twin_q_loss_kernel<<<1, 256, 0, (hipStream_t)stream>>>(q1, q2, target, scale, gq1, gq2, loss_out, loss_sum, (int)batch);
+    return (int)hipGetLastError();
+}
+
+extern "C" int cstr_sac_actor_loss_f32(const float *logp, const float *q1, const float *q2, const float *ent_coef, float *g_logp,
+                                       float *gq1, float *gq2, float *loss_out, float *loss_sum, int64_t batch, cstr_stream_t stream)
+{
+    if (!logp || !q1 || !q2 || !ent_coef || !g_logp || !gq1 || !gq2 || batch <= 0) return CSTR_E_BADARG;
+    if (batch > CSTR_MAX_SAMPLE_BATCH) return CSTR_E_UNSUPPORTED;
+    sac_actor_loss_kernel<<<1, 256, 0, (hipStream_t)stream>>>(logp, q1, q2, ent_coef, g_logp, gq1, gq2, loss_out, loss_sum, (int)batch);
+    return (int)hipGetLastError();
+}
+
+extern "C" int cstr_neg_mean_loss_f32(const float *q, float *gq, float *loss_out, float *loss_sum, int64_t batch, cstr_stream_t stream)
+{
+    if (!q || !gq || batch <= 0) return CSTR_E_BADARG;
+    if (batch > CSTR_MAX_SAMPLE_BATCH) return CSTR_E_UNSUPPORTED;
+    neg_mean_loss_kernel<<<1, 256, 0, (hipStream_t)stream>>>(q, gq, loss_out, loss_sum, (int)batch);
+    return (int)hipGetLastError();
+}

@@ -1,0 +1,156 @@
+"""GPU tests of the learner glue kernels (csrc/cstr_mlp.hip) against torch autograd evaluating the reference's
+own expressions (core/common/distributions.py:161-260, core/sac/sac.py:230-275, core/td3/td3.py:182-194,
+core/common/torch_layers.py:110-183). fp32 tolerances: 1e-6 relative for forward values, 1e-5 for gradients
+(the analytic squashed-Gaussian backward differs from autograd's by terms that cancel to rounding noise)."""
+import math
+
+import numpy as np
+import pytest
+import torch as th
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert th.cuda.is_available()
+    from core.common import hip_ops
+
+    return hip_ops
+
+
+def ref_squashed(mean, log_std_raw, eps):
+    """The reference's statements, in torch (float64 for the gradient reference)."""
+    log_std = th.clamp(log_std_raw, -20, 2)
+    std = log_std.exp()
+    u = mean + std * eps
+    a = th.tanh(u)
+    lp = (-((u - mean) ** 2) / (2 * std ** 2) - std.log() - math.log(math.sqrt(2 * math.pi))).sum(dim=1)
+    lp = lp - th.sum(th.log(1 - a ** 2 + 1e-6), dim=1)
+    return a, lp
+
+
+@pytest.mark.parametrize("B,A", [(1, 2), (256, 2), (4096, 2), (257, 3)])
+def test_squashed_gaussian_fwd_bwd(ops, B, A):
+    from core.common import fused
+
+    g = th.Generator().manual_seed(B)
+    mean = th.randn(B, A, generator=g)
+    ls = th.randn(B, A, generator=g) * 2 - 1
+    ls[0, 0], ls[-1, -1] = 3.0, -25.0  # outside the clamp range: zero gradient there
+    eps = th.randn(B, A, generator=g)
+    a_ref, lp_ref = ref_squashed(mean, ls, eps)
+    m_d, l_d = mean.cuda().requires_grad_(True), ls.cuda().requires_grad_(True)
+    a, lp = fused.squashed_gaussian(m_d, l_d, eps.cuda())
+    assert rel_err(a.detach().cpu().numpy(), a_ref.numpy(), 1e-3) < 2e-6
+    assert rel_err(lp.detach().cpu().numpy(), lp_ref.numpy(), 1.0) < 2e-6
+    ga, gl = th.randn(B, A, generator=g), th.randn(B, generator=g)
+    th.autograd.backward([a, lp], [ga.cuda(), gl.cuda()])
+    m64, l64 = mean.double().requires_grad_(True), ls.double().requires_grad_(True)
+    a64, lp64 = ref_squashed(m64, l64, eps.double())
+    th.autograd.backward([a64, lp64], [ga.double(), gl.double()])
+    assert rel_err(m_d.grad.cpu().numpy(), m64.grad.numpy(), 1e-2) < 1e-5
+    assert rel_err(l_d.grad.cpu().numpy(), l64.grad.numpy(), 1e-2) < 1e-5
+    assert float(l_d.grad[0, 0]) == 0.0 and float(l_d.grad[-1, -1]) == 0.0
+    # acting only (no logp, no grad)
+    with th.no_grad():
+        a2, none = fused.squashed_gaussian(mean.cuda(), ls.cuda(), eps.cuda(), want_logp=False)
+    assert none is None and th.equal(a2, a.detach())
+
+
+@pytest.mark.parametrize("M,K,N,act", [(256, 6, 256, 1), (256, 256, 256, 1), (256, 256, 1, 0), (256, 256, 2, 0),
+                                       (4096, 4, 256, 1), (64, 32, 2, 2), (7, 5, 3, 1)])
+def test_fused_linear_matches_module(ops, M, K, N, act):
+    """linear() forward/backward (with gradients written into arena views) == nn.Linear + activation + autograd."""
+    from core.common import fused
+    from core.common.arena import ParamArena
+
+    th.manual_seed(M + N)
+    lin = th.nn.Linear(K, N)
+    ref = th.nn.Linear(K, N)
+    ref.load_state_dict(lin.state_dict())
+    ref = ref.cuda()
+    arena = ParamArena(lin.parameters(), "cuda")
+    x = th.randn(M, K, device="cuda", requires_grad=True)
+    x2 = x.detach().clone().requires_grad_(True)
+    fn = {0: lambda t: t, 1: th.relu, 2: th.tanh}[act]
+    y_ref = fn(ref(x2))
+    y = fused.linear(x, lin.weight, lin.bias, act, True)
+    assert rel_err(y.detach().cpu().numpy(), y_ref.detach().cpu().numpy(), 1e-2) < 1e-5
+    gy = th.randn(M, N, device="cuda")
+    arena.grad.fill_(123.0)  # stale values must be overwritten, not accumulated
+    y.backward(gy)
+    y_ref.backward(gy)
+    for got, want in ((lin.weight.grad, ref.weight.grad), (lin.bias.grad, ref.bias.grad), (x.grad, x2.grad)):
+        assert rel_err(got.cpu().numpy(), want.cpu().numpy(), max(1e-2, float(want.abs().mean()))) < 1e-5
+    assert lin.weight.grad.data_ptr() == arena.grad.data_ptr()  # still the arena view
+    # frozen parameters: only dx, arena untouched
+    arena.grad.fill_(7.0)
+    x3 = x.detach().clone().requires_grad_(True)
+    fused.linear(x3, lin.weight, lin.bias, act, False).backward(gy)
+    assert th.all(arena.grad == 7.0)
+    assert rel_err(x3.grad.cpu().numpy(), x2.grad.cpu().numpy(), max(1e-2, float(x2.grad.abs().mean()))) < 1e-5
+
+
+def test_loss_heads(ops):
+    g = th.Generator().manual_seed(0)
+    for B in (1, 64, 256, 1000):
+        q1, q2, t = (th.randn(B, 1, generator=g) * 3 for _ in range(3))
+        lp = th.randn(B, generator=g)
+        d = lambda x: x.cuda().contiguous()  # noqa: E731
+        gq1, gq2, glp = th.empty(B, 1, device="cuda"), th.empty(B, 1, device="cuda"), th.empty(B, device="cuda")
+        loss, acc = th.zeros(1, device="cuda"), th.full((1,), 10.0, device="cuda")
+        for scale in (0.5, 1.0):  # SAC sac.py:261 / TD3 td3.py:182
+            a, b = q1.clone().requires_grad_(True), q2.clone().requires_grad_(True)
+            ref = scale * (th.nn.functional.mse_loss(a, t) + th.nn.functional.mse_loss(b, t))
+            ref.backward()
+            acc.fill_(10.0)
+            ops.twin_q_loss(d(q1), d(q2), d(t), scale, gq1, gq2, loss, acc)
+            assert rel_err(float(loss), float(ref), 1e-3) < 2e-6 and abs(float(acc) - 10.0 - float(ref)) < 1e-4
+            assert rel_err(gq1.cpu().numpy(), a.grad.numpy(), 1e-4) < 2e-6 and rel_err(gq2.cpu().numpy(), b.grad.numpy(), 1e-4) < 2e-6
+        # SAC actor loss sac.py:273-275
+        ent = th.tensor([0.37])
+        a, b, l = q1.clone().requires_grad_(True), q2.clone().requires_grad_(True), lp.clone().requires_grad_(True)
+        mn, _ = th.min(th.cat((a, b), dim=1), dim=1, keepdim=True)
+        ref = (ent * l.reshape(-1, 1) - mn).mean()
+        ref.backward()
+        ops.sac_actor_loss(d(lp), d(q1), d(q2), d(ent), glp, gq1, gq2, loss, None)
+        assert rel_err(float(loss), float(ref), 1e-3) < 2e-6
+        for got, want in ((glp, l.grad), (gq1, a.grad), (gq2, b.grad)):
+            assert rel_err(got.cpu().numpy().reshape(-1), want.numpy().reshape(-1), 1e-4) < 2e-6
+        # entropy coefficient sac.py:230-231
+        la = th.tensor([-0.3], requires_grad=True)
+        ref = -(la * (lp.reshape(-1, 1) - 2.0).detach()).mean()
+        ref.backward()
+        grad, ec, ls_, es = (th.zeros(1, device="cuda") for _ in range(4))
+        ops.sac_alpha(d(la.detach()), d(lp), -2.0, grad, ec, ls_, es)
+        assert rel_err(float(grad), float(la.grad), 1e-3) < 2e-6 and rel_err(float(ec), math.exp(-0.3), 1e-3) < 1e-6
+        assert rel_err(float(ls_), float(ref), 1e-3) < 2e-6 and rel_err(float(es), math.exp(-0.3), 1e-3) < 1e-6
+        # TD3 actor loss td3.py:194
+        a = q1.clone().requires_grad_(True)
+        ref = -a.mean()
+        ref.backward()
+        ops.neg_mean_loss(d(q1), gq1, loss, None)
+        assert rel_err(float(loss), float(ref), 1e-3) < 2e-6 and rel_err(gq1.cpu().numpy(), a.grad.numpy(), 1e-6) < 1e-6
+
+
+def test_fast_modules_equal_nn_modules():
+    """FastSacActor / FastTwinCritic read the nn.Modules' tensors: same outputs as the module forwards."""
+    from core.common.vec_env import CSTRVecEnv
+    from core.sac import SAC
+
+    model = SAC("MlpPolicy", CSTRVecEnv(4), seed=3, policy_kwargs=dict(net_arch=[64, 64]))
+    obs = th.rand(128, 4, device="cuda") * 2 - 1
+    act = th.rand(128, 2, device="cuda") * 2 - 1
+    eps = th.randn(128, 2, device="cuda")
+    with th.no_grad():
+        model.actor.action_dist.eps_queue = [eps.clone()]
+        a_ref, lp_ref = model.actor.action_log_prob(obs)
+        a, lp = model._fast_actor.action_log_prob(obs, eps=eps, train_params=False)
+        q_ref = model.critic(obs, act)
+        q = model._fast_critic(obs, act, train_params=False)
+    assert rel_err(a.cpu().numpy(), a_ref.cpu().numpy(), 1e-3) < 1e-5 and rel_err(lp.cpu().numpy(), lp_ref.cpu().numpy(), 1.0) < 1e-5
+    for x, y in zip(q, q_ref):
+        assert rel_err(x.cpu().numpy(), y.cpu().numpy(), 1e-2) < 1e-5

@@ -65,8 +65,9 @@ def _make_env(n=4):
     return CSTRVecEnv(n)
 
 
+@pytest.mark.parametrize("fused_path", [True, False])
 @pytest.mark.parametrize("tag", ["small", "default"])
-def test_sac_train_teacher_forced(golden, tag):
+def test_sac_train_teacher_forced(golden, tag, fused_path):
     from core.common import legacy_rng
     from core.sac import SAC
 
@@ -75,6 +76,8 @@ def test_sac_train_teacher_forced(golden, tag):
     B, n_steps = int(B), int(n_steps)
     kw = dict(policy_kwargs=dict(net_arch=[64, 64])) if tag == "small" else {}
     model = SAC("MlpPolicy", _make_env(4), seed=0, batch_size=B, buffer_size=64 * 4, **kw)
+    assert model.fused_learner  # the default configuration runs the fused HIP path
+    model.fused_learner = fused_path  # False: stock-ATen evaluation of the same statements
     assert model.gamma == gamma and model.tau == tau and model.target_entropy == target_entropy and model.lr_schedule(1) == lr
     mods = ["actor", "critic", "critic_target"]
     if tag == "small":
@@ -107,7 +110,8 @@ def test_sac_train_teacher_forced(golden, tag):
     assert model.actor.optimizer.step_count == n_steps and model.critic.optimizer.step_count == n_steps
 
 
-def test_td3_train_teacher_forced(golden):
+@pytest.mark.parametrize("fused_path", [True, False])
+def test_td3_train_teacher_forced(golden, fused_path):
     from core.common import legacy_rng
     from core.td3 import TD3
 
@@ -115,6 +119,8 @@ def test_td3_train_teacher_forced(golden):
     gamma, tau, tpn, tnc, delay, lr, B, n_steps = g["hyper"]
     B, n_steps = int(B), int(n_steps)
     model = TD3("MlpPolicy", _make_env(4), seed=0, batch_size=B, buffer_size=64 * 4, policy_kwargs=dict(net_arch=[48, 32]))
+    assert model.fused_learner
+    model.fused_learner = fused_path
     assert (model.gamma, model.tau, model.target_policy_noise, model.target_noise_clip, model.policy_delay) == (gamma, tau, tpn, tnc, int(delay))
     assert model.lr_schedule(1) == lr
     mods = ["actor", "actor_target", "critic", "critic_target"]
