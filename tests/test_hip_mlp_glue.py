@@ -51,8 +51,15 @@ def test_squashed_gaussian_fwd_bwd(ops, B, A):
     m64, l64 = mean.double().requires_grad_(True), ls.double().requires_grad_(True)
     a64, lp64 = ref_squashed(m64, l64, eps.double())
     th.autograd.backward([a64, lp64], [ga.double(), gl.double()])
-    assert rel_err(m_d.grad.cpu().numpy(), m64.grad.numpy(), 1e-2) < 1e-5
-    assert rel_err(l_d.grad.cpu().numpy(), l64.grad.numpy(), 1e-2) < 1e-5
+    # where tanh saturates in fp32 (1 - a^2 rounds to 0) the fp32 gradient is exactly 0 -- also in the reference's
+    # fp32 autograd -- while the fp64 reference keeps a tiny tail: compare away from saturation, check finiteness
+    u64 = (mean.double() + th.clamp(ls.double(), -20, 2).exp() * eps.double()).abs().numpy()
+    ok = u64 < 5.0
+    assert ok.mean() > 0.8
+    gm, gls = m_d.grad.cpu().numpy(), l_d.grad.cpu().numpy()
+    assert np.isfinite(gm).all() and np.isfinite(gls).all()
+    assert rel_err(gm[ok], m64.grad.numpy()[ok], 1e-2) < 1e-5
+    assert rel_err(gls[ok], l64.grad.numpy()[ok], 1e-2) < 1e-5
     assert float(l_d.grad[0, 0]) == 0.0 and float(l_d.grad[-1, -1]) == 0.0
     # acting only (no logp, no grad)
     with th.no_grad():
