@@ -45,7 +45,11 @@ def test_squashed_gaussian_fwd_bwd(ops, B, A):
     m_d, l_d = mean.cuda().requires_grad_(True), ls.cuda().requires_grad_(True)
     a, lp = fused.squashed_gaussian(m_d, l_d, eps.cuda())
     assert rel_err(a.detach().cpu().numpy(), a_ref.numpy(), 1e-3) < 2e-6
-    assert rel_err(lp.detach().cpu().numpy(), lp_ref.numpy(), 1.0) < 2e-6
+    # log(1 - a^2 + 1e-6) is ill-conditioned where tanh saturates (a 1-ulp difference between libm's and ocml's tanhf
+    # is amplified by 1/(1 - a^2 + 1e-6)); this synthetic batch saturates heavily (std up to e^2)
+    assert rel_err(lp.detach().cpu().numpy(), lp_ref.numpy(), 1.0) < 5e-5
+    u_abs = (mean + th.clamp(ls, -20, 2).exp() * eps).abs().max(dim=1).values.numpy()
+    assert rel_err(lp.detach().cpu().numpy()[u_abs < 3], lp_ref.numpy()[u_abs < 3], 1.0) < 2e-6
     ga, gl = th.randn(B, A, generator=g), th.randn(B, generator=g)
     th.autograd.backward([a, lp], [ga.cuda(), gl.cuda()])
     m64, l64 = mean.double().requires_grad_(True), ls.double().requires_grad_(True)
@@ -115,7 +119,7 @@ def test_loss_heads(ops):
             ref.backward()
             acc.fill_(10.0)
             ops.twin_q_loss(d(q1), d(q2), d(t), scale, gq1, gq2, loss, acc)
-            assert rel_err(float(loss), float(ref), 1e-3) < 2e-6 and abs(float(acc) - 10.0 - float(ref)) < 1e-4
+            assert rel_err(float(loss), float(ref.detach()), 1e-3) < 2e-6 and abs(float(acc) - 10.0 - float(ref.detach())) < 1e-4
             assert rel_err(gq1.cpu().numpy(), a.grad.numpy(), 1e-4) < 2e-6 and rel_err(gq2.cpu().numpy(), b.grad.numpy(), 1e-4) < 2e-6
         # SAC actor loss sac.py:273-275
         ent = th.tensor([0.37])
