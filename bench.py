@@ -235,7 +235,7 @@ def main():
     model = cls("MlpPolicy", env, seed=0, device=f"cuda:{local_rank}")  # class defaults: buffer 1e6 -> 244 rows x 4096
     total = (args.warmup + args.steps) * N
     _, callback = model._setup_learn(total, NoopCallback(), True, "bench", False)
-    use_graph = bool(args.graph) and world == 1
+    use_graph = bool(args.graph)  # world > 1: graph segments with the RCCL all-reduces between them
     model.enable_graph_capture(use_graph)
     if args.tunable:
         th.cuda.tunable.enable(True)

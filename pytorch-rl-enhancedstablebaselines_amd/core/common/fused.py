@@ -147,12 +147,39 @@ class FastSacActor:
 
 
 class FastTwinCritic:
-    """core/common/policies.py:960-987 on the fused path (n_critics Q networks on cat(obs, action))."""
+    """core/common/policies.py:960-987 on the fused path (n_critics Q networks on cat(obs, action)).
 
-    def __init__(self, critic):
+    The two Q networks are independent chains of ~5-us launches. With `two_streams` the second network is issued
+    on a side HIP stream (fork after the concat, join before the outputs are used): under hipGraph capture the two
+    chains become parallel branches of the graph, forward AND backward (autograd replays each node on the stream
+    of its forward), so the pair costs about one chain's latency. Same kernels, same arithmetic."""
+
+    def __init__(self, critic, two_streams: bool = True):
         self.nets = [FastMLP(q) for q in critic.q_networks]
+        self.two_streams = two_streams and len(self.nets) == 2
+        self._side: Optional[th.cuda.Stream] = None
 
     def __call__(self, obs: th.Tensor, actions: th.Tensor, train_params: bool = True, only_first: bool = False):
         x = th.cat([obs, actions], dim=1)
-        nets = self.nets[:1] if only_first else self.nets
-        return tuple(net(x, train_params) for net in nets)
+        if only_first or not self.two_streams:
+            nets = self.nets[:1] if only_first else self.nets
+            return tuple(net(x, train_params) for net in nets)
+        cur = th.cuda.current_stream(x.device)
+        if self._side is None:
+            self._side = th.cuda.Stream(device=x.device)
+        side = self._side
+        side.wait_stream(cur)
+        x.record_stream(side)
+        q1 = self.nets[0](x, train_params)
+        with th.cuda.stream(side):
+            q2 = self.nets[1](x, train_params)
+        cur.wait_stream(side)
+        q2.record_stream(cur)
+        return q1, q2
+
+    def join(self) -> None:
+        """After a backward pass through this critic: make the caller's stream wait for the side stream. The second
+        network's weight/bias gradients are written into the arena by its backward nodes ON THE SIDE STREAM; autograd
+        only synchronises streams along tensor edges it knows about, and those writes are side effects."""
+        if self._side is not None:
+            th.cuda.current_stream(self._side.device).wait_stream(self._side)

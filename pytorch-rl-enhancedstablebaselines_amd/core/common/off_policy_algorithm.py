@@ -160,7 +160,7 @@ class OffPolicyAlgorithm(BaseAlgorithm):
 
     def _graph_eligible(self, callback: BaseCallback) -> bool:
         return (self._fast_path() and getattr(callback, "is_noop", False) and self.action_noise is None
-                and self.world_size == 1 and self.train_freq == TrainFreq(1, TrainFrequencyUnit.STEP)
+                and self.train_freq == TrainFreq(1, TrainFrequencyUnit.STEP)
                 and self.gradient_steps >= 1 and self.num_timesteps >= self.learning_starts
                 and self.num_timesteps + self.n_envs > self.learning_starts and not getattr(self, "debug_capture", False))
 
@@ -197,15 +197,48 @@ class OffPolicyAlgorithm(BaseAlgorithm):
                 self._graph_warm += 1
                 self._graph_host_bookkeeping(log_interval)
                 return
-            g = th.cuda.CUDAGraph()
             self._train_host_pre()
-            th.cuda.synchronize(self.device)
-            with th.cuda.graph(g):  # records the launches; nothing executes here
-                self._graph_body()
-            self._graph = g
+            self._graph = self._capture_segments()
         self._train_host_pre()
-        self._graph.replay()
+        for item in self._graph:  # hipGraph segments interleaved with the eager collectives that separate them
+            item.replay() if isinstance(item, th.cuda.CUDAGraph) else item()
         self._graph_host_bookkeeping(log_interval)
+
+    def _capture_segments(self) -> list:
+        """Record the iteration as hipGraph segments. A data-parallel run has an RCCL all-reduce between backward and
+        the optimiser step (three per SAC gradient step); collectives stay OUTSIDE the captured graphs -- every
+        `_eager_boundary` closes the current segment, runs the collective eagerly and opens the next segment in the same
+        memory pool (activations saved for a later segment's backward stay alive). Single-GPU runs have no boundary and
+        get one graph. Nothing executes while recording."""
+        th.cuda.synchronize(self.device)
+        side = th.cuda.Stream(device=self.device)
+        side.wait_stream(th.cuda.current_stream(self.device))
+        items: list = []
+        with th.cuda.stream(side):
+            self._cap = dict(pool=th.cuda.graph_pool_handle(), graph=th.cuda.CUDAGraph(), items=items)
+            self._cap["graph"].capture_begin(pool=self._cap["pool"], capture_error_mode="thread_local")
+            try:
+                self._graph_body()
+                self._cap["graph"].capture_end()
+                items.append(self._cap["graph"])
+            finally:
+                self._cap = None
+        th.cuda.current_stream(self.device).wait_stream(side)
+        th.cuda.synchronize(self.device)
+        return items
+
+    def _eager_boundary(self, fn) -> None:
+        """Run `fn` (a collective) eagerly; when a capture is in progress, split the graph around it."""
+        cap = getattr(self, "_cap", None)
+        if cap is None:
+            fn()
+            return
+        cap["graph"].capture_end()
+        cap["items"].append(cap["graph"])
+        fn()
+        cap["items"].append(fn)
+        cap["graph"] = th.cuda.CUDAGraph()
+        cap["graph"].capture_begin(pool=cap["pool"], capture_error_mode="thread_local")
 
     # ---- action selection -----------------------------------------------------------------------------------------
     def _action_mode(self, warmup: bool) -> int:
@@ -352,5 +385,5 @@ class OffPolicyAlgorithm(BaseAlgorithm):
 
     # ---- data-parallel helper used by train() ----------------------------------------------------------------------
     def _allreduce_grads(self, arena) -> None:
-        if self.world_size > 1:
-            dist_util.allreduce_sum_(arena.grad)
+        if self.world_size > 1 or getattr(self, "_force_segment_boundaries", False):
+            self._eager_boundary(lambda: dist_util.allreduce_sum_(arena.grad))

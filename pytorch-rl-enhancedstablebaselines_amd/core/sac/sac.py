@@ -12,11 +12,16 @@ import numpy as np
 import torch as th
 from torch.nn import functional as F
 
+import os
+
 from core.common import fused, hip_ops
 from core.common.arena import FlatAdam, ParamArena
 from core.common.logger import DeviceMean
 from core.common.off_policy_algorithm import OffPolicyAlgorithm
 from core.sac.policies import MlpPolicy, SACPolicy
+
+
+_TWO_STREAMS = os.environ.get("CSTR_TWIN_STREAMS", "1") != "0"
 
 
 class SAC(OffPolicyAlgorithm):
@@ -68,7 +73,9 @@ class SAC(OffPolicyAlgorithm):
         else:
             self.ent_coef_tensor = th.tensor(float(self.ent_coef), device=self.device)
         z = lambda: th.zeros(1, dtype=th.float32, device=self.device)  # noqa: E731
-        self._loss_sums = dict(actor=z(), critic=z(), ent_coef_loss=z(), ent_coef=z())
+        self._loss_sum_buf = th.zeros(4, dtype=th.float32, device=self.device)  # one fill per train() instead of four
+        sb = self._loss_sum_buf
+        self._loss_sums = dict(actor=sb[0:1], critic=sb[1:2], ent_coef_loss=sb[2:3], ent_coef=sb[3:4])
         self._loss_now = dict(actor=z(), critic=z())
         self._ent_coef_buf = z()
         self._static_batch = None
@@ -76,8 +83,8 @@ class SAC(OffPolicyAlgorithm):
         self.fused_learner = self._fused_supported()
         if self.fused_learner:
             self._fast_actor = fused.FastSacActor(self.actor)
-            self._fast_critic = fused.FastTwinCritic(self.critic)
-            self._fast_critic_target = fused.FastTwinCritic(self.critic_target)
+            self._fast_critic = fused.FastTwinCritic(self.critic, _TWO_STREAMS)
+            self._fast_critic_target = fused.FastTwinCritic(self.critic_target, _TWO_STREAMS)
 
     def _fused_supported(self) -> bool:
         from core.common.arena import FlatAdam
@@ -117,8 +124,7 @@ class SAC(OffPolicyAlgorithm):
         self._update_learning_rate(optimizers)  # :208
 
     def _train_device_only(self, gradient_steps: int, batch_size: int) -> None:
-        for v in self._loss_sums.values():
-            v.zero_()
+        self._loss_sum_buf.zero_()
         for gradient_step in range(gradient_steps):
             self._gradient_step(batch_size, gradient_step)
 
@@ -168,12 +174,14 @@ class SAC(OffPolicyAlgorithm):
         q1, q2 = self._fast_critic(rd.observations, rd.actions)  # :258
         hip_ops.twin_q_loss(q1, q2, self._target_q, 0.5, gq1, gq2, self._loss_now["critic"], s["critic"])  # :261
         th.autograd.backward([q1, q2], [gq1, gq2])  # :266-268
+        self._fast_critic.join()
         self._allreduce_grads(pol.critic_arena)
         self.critic.optimizer.step()
 
         q1_pi, q2_pi = self._fast_critic(rd.observations, actions_pi, train_params=False)  # :273-275 (critic weights frozen)
         hip_ops.sac_actor_loss(log_prob, q1_pi, q2_pi, ent_coef, g_lp, gq1, gq2, self._loss_now["actor"], s["actor"])
         th.autograd.backward([log_prob, q1_pi, q2_pi], [g_lp, gq1, gq2])  # :279-281
+        self._fast_critic.join()
         self._allreduce_grads(pol.actor_arena)
         self.actor.optimizer.step()
 

@@ -5,10 +5,15 @@ from typing import List, Optional, Union
 import torch as th
 from torch.nn import functional as F
 
+import os
+
 from core.common import fused, hip_ops
 from core.common.logger import DeviceMean
 from core.common.off_policy_algorithm import OffPolicyAlgorithm
 from core.td3.policies import MlpPolicy
+
+
+_TWO_STREAMS = os.environ.get("CSTR_TWIN_STREAMS", "1") != "0"
 
 
 class TD3(OffPolicyAlgorithm):
@@ -50,7 +55,7 @@ class TD3(OffPolicyAlgorithm):
                               and fused.FastMLP.supported(self.actor.mu) and all(fused.FastMLP.supported(q) for q in self.critic.q_networks))
         if self.fused_learner:
             self._fast_actor, self._fast_actor_target = fused.FastMLP(self.actor.mu), fused.FastMLP(self.actor_target.mu)
-            self._fast_critic, self._fast_critic_target = fused.FastTwinCritic(self.critic), fused.FastTwinCritic(self.critic_target)
+            self._fast_critic, self._fast_critic_target = fused.FastTwinCritic(self.critic, _TWO_STREAMS), fused.FastTwinCritic(self.critic_target, _TWO_STREAMS)
 
     def _policy_out_device(self, obs: th.Tensor) -> th.Tensor:
         if not self.fused_learner:
@@ -153,6 +158,7 @@ class TD3(OffPolicyAlgorithm):
             th.autograd.backward([q1, q2], [gq1, gq2])
         else:
             th.autograd.backward([q1], [gq1 + gq2])
+        self._fast_critic.join()
         self._allreduce_grads(pol.critic_arena)
         self.critic.optimizer.step()
         actor_done = False

@@ -45,30 +45,45 @@ __global__ void bias_act_fwd_vec4_kernel(float4 *__restrict__ y, const float4 *_
 }
 
 // gz[m][n] = gy[m][n] * act'(y[m][n]);  gbias[n] = sum_m gz[m][n]   (threshold_backward / tanh_backward + the bias
-// gradient's sum over the batch). One workgroup owns 64 columns: lanes run along columns (coalesced rows), the four
-// waves stride over rows, LDS combines them; every gbias element is written exactly once -> deterministic.
-template <int ACT>
-__global__ __launch_bounds__(256) void bias_act_bwd_kernel(const float *__restrict__ gy, const float *__restrict__ y,
-                                                           float *__restrict__ gz, float *__restrict__ gbias, const int m,
-                                                           const int n)
+// gradient's sum over the batch). One workgroup owns 64 columns: lanes run along columns (coalesced 256-B row
+// segments), its WAVES waves stride over the rows with four rows of loads in flight per wave (the kernel is pure
+// latency at batch 256), LDS combines the waves; every gbias element is written exactly once -> deterministic.
+template <int ACT, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void bias_act_bwd_kernel(const float *gy, const float *__restrict__ y, float *gz,
+                                                                  float *__restrict__ gbias, const int m, const int n)
 {
-    __shared__ float part[4][64];
+    __shared__ float part[WAVES][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int col = blockIdx.x * 64 + lane;
     float acc = 0.0f;
     if (col < n) {
-        for (int r = wave; r < m; r += 4) {
-            const int64_t i = (int64_t)r * n + col;
-            float g = gy[i];
-            if (ACT == ACT_RELU) g = y[i] > 0.0f ? g : 0.0f;
-            if (ACT == ACT_TANH) { const float t = y[i]; g = g * (1.0f - t * t); }
-            if (ACT != ACT_NONE || gz != gy) gz[i] = g;
-            acc += g;
+        for (int r0 = wave; r0 < m; r0 += 4 * WAVES) {
+            float g[4], t[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int r = r0 + k * WAVES;
+                const int64_t i = (int64_t)r * n + col;
+                g[k] = r < m ? gy[i] : 0.0f;
+                t[k] = (ACT != ACT_NONE && r < m) ? y[i] : 0.0f;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int r = r0 + k * WAVES;
+                if (ACT == ACT_RELU) g[k] = t[k] > 0.0f ? g[k] : 0.0f;
+                if (ACT == ACT_TANH) g[k] = g[k] * (1.0f - t[k] * t[k]);
+                if (r < m && (ACT != ACT_NONE || gz != gy)) gz[(int64_t)r * n + col] = g[k];
+                acc += g[k];
+            }
         }
     }
     part[wave][lane] = acc;
     __syncthreads();
-    if (wave == 0 && col < n && gbias) gbias[col] = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+    if (wave == 0 && col < n && gbias) {
+        float s = 0.0f;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) s += part[w][lane];
+        gbias[col] = s;
+    }
 }
 
 // ---- block reduction helper ---------------------------------------------------------------------------
@@ -270,9 +285,15 @@ extern "C" int cstr_bias_act_bwd_f32(const float *gy, const float *y, int act, f
     if (act < 0 || act > 2 || m > 0x7fffffff || n > 0x7fffffff) return CSTR_E_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
     const int grid = (int)((n + 63) / 64);
-    if (act == 0) bias_act_bwd_kernel<0><<<grid, 256, 0, s>>>(gy, y, gz, gbias, (int)m, (int)n);
-    else if (act == 1) bias_act_bwd_kernel<1><<<grid, 256, 0, s>>>(gy, y, gz, gbias, (int)m, (int)n);
-    else bias_act_bwd_kernel<2><<<grid, 256, 0, s>>>(gy, y, gz, gbias, (int)m, (int)n);
+    if (m >= 64) {  // 16 waves per workgroup: 16 rows per wave at batch 256
+        if (act == 0) bias_act_bwd_kernel<0, 16><<<grid, 1024, 0, s>>>(gy, y, gz, gbias, (int)m, (int)n);
+        else if (act == 1) bias_act_bwd_kernel<1, 16><<<grid, 1024, 0, s>>>(gy, y, gz, gbias, (int)m, (int)n);
+        else bias_act_bwd_kernel<2, 16><<<grid, 1024, 0, s>>>(gy, y, gz, gbias, (int)m, (int)n);
+    } else {
+        if (act == 0) bias_act_bwd_kernel<0, 4><<<grid, 256, 0, s>>>(gy, y, gz, gbias, (int)m, (int)n);
+        else if (act == 1) bias_act_bwd_kernel<1, 4><<<grid, 256, 0, s>>>(gy, y, gz, gbias, (int)m, (int)n);
+        else bias_act_bwd_kernel<2, 4><<<grid, 256, 0, s>>>(gy, y, gz, gbias, (int)m, (int)n);
+    }
     return (int)hipGetLastError();
 }
 

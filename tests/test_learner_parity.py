@@ -260,15 +260,20 @@ def test_hipgraph_iteration_equals_eager():
 
     N, B, seed, iters = 128, 64, 9, 12
     results = []
-    for use_graph in (False, True):
+    for use_graph in (False, True, "segmented"):
         env = CSTRVecEnv(N)
         model = SAC("MlpPolicy", env, seed=seed, batch_size=B, buffer_size=N * 6, learning_starts=100,
                     policy_kwargs=dict(net_arch=[64, 64]))
-        model.enable_graph_capture(use_graph)
+        model.enable_graph_capture(bool(use_graph))
+        # "segmented": the data-parallel capture layout (graph | all-reduce | graph | ...) exercised on one GPU,
+        # where the all-reduce is the identity
+        model._force_segment_boundaries = use_graph == "segmented"
         model.learn(N * iters)
         assert model._n_updates == iters and model.num_timesteps == N * iters
         if use_graph:
             assert model._graph is not None, "the steady-state iteration was never captured"
+            n_graphs = sum(isinstance(it, th.cuda.CUDAGraph) for it in model._graph)
+            assert n_graphs == (4 if use_graph == "segmented" else 1) and len(model._graph) == 2 * n_graphs - 1
         th.cuda.synchronize()
         results.append(dict(
             mt=legacy_rng.global_stream(model.device).cpu().numpy().copy(), ctl=model.replay_buffer.ring.ctl.cpu().numpy(),
@@ -276,15 +281,16 @@ def test_hipgraph_iteration_equals_eager():
             actor=model.policy.actor_arena.flat.cpu().numpy(), critic=model.policy.critic_arena.flat.cpu().numpy(),
             target=model.policy.critic_target_arena.flat.cpu().numpy(), obs=env.obs.cpu().numpy(),
             ring_act=model.replay_buffer.actions.cpu().numpy(), alpha=float(model.log_ent_coef.detach())))
-    e, g = results
-    np.testing.assert_array_equal(e["mt"], g["mt"])
-    np.testing.assert_array_equal(e["ctl"], g["ctl"])
-    np.testing.assert_array_equal(e["steps"], g["steps"])
-    assert e["adam"] == g["adam"] == iters
-    # same torch seed -> same exploration noise -> same trajectories up to fp32 GEMM noise
-    for k in ("actor", "critic", "target", "obs", "ring_act"):
-        np.testing.assert_allclose(e[k], g[k], rtol=2e-3, atol=2e-4, err_msg=k)
-    assert abs(e["alpha"] - g["alpha"]) < 1e-5
+    e = results[0]
+    for g in results[1:]:
+        np.testing.assert_array_equal(e["mt"], g["mt"])
+        np.testing.assert_array_equal(e["ctl"], g["ctl"])
+        np.testing.assert_array_equal(e["steps"], g["steps"])
+        assert e["adam"] == g["adam"] == iters
+        # same torch seed -> same exploration noise -> same trajectories up to fp32 GEMM noise
+        for k in ("actor", "critic", "target", "obs", "ring_act"):
+            np.testing.assert_allclose(e[k], g[k], rtol=2e-3, atol=2e-4, err_msg=k)
+        assert abs(e["alpha"] - g["alpha"]) < 1e-5
 
 
 def test_maddpg_train_teacher_forced(golden):
