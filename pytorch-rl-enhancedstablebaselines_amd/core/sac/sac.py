@@ -21,7 +21,8 @@ from core.common.off_policy_algorithm import OffPolicyAlgorithm
 from core.sac.policies import MlpPolicy, SACPolicy
 
 
-_TWO_STREAMS = os.environ.get("CSTR_TWIN_STREAMS", "1") != "0"
+# measured on MI355X (profiles/r01_notes.md): the fork/join edges cost more than the overlap buys (0.497 vs 0.454 ms/iter)
+_TWO_STREAMS = os.environ.get("CSTR_TWIN_STREAMS", "0") != "0"
 
 
 class SAC(OffPolicyAlgorithm):
