@@ -155,8 +155,7 @@ class OffPolicyAlgorithm(BaseAlgorithm):
         Falls back to the eager path whenever the iteration is not capturable (warm-up, callbacks, action noise,
         data-parallel all-reduce, episodic train_freq)."""
         self._graph_enabled = enabled
-        if not enabled:
-            self._graph = None
+        self._graph = None
 
     def _graph_eligible(self, callback: BaseCallback) -> bool:
         return (self._fast_path() and getattr(callback, "is_noop", False) and self.action_noise is None
@@ -182,25 +181,32 @@ class OffPolicyAlgorithm(BaseAlgorithm):
         self._train_host_only(self.gradient_steps)
         self._sync_episode_stats(log_interval)
 
+    def _graph_phase(self) -> int:
+        """Iterations that launch different kernel sequences need different graphs (TD3 / MADDPG: the delayed policy
+        update happens every `policy_delay`-th gradient step)."""
+        return 0
+
     def _graph_iteration(self, log_interval: Optional[int]) -> None:
-        key = (id(self.env.coef), self.batch_size, self.gradient_steps)
-        if self._graph is None or self._graph_key != key:
+        key = (id(self.env.coef), self.batch_size, self.gradient_steps, self._graph_phase())
+        if not isinstance(self._graph, dict):
+            self._graph, self._graph_warm = {}, {}
+        if key not in self._graph:
             # side-stream warm-up (these are REAL iterations: they advance env, ring, RNG and optimiser state)
-            self._graph, self._graph_key, self._graph_warm = None, key, getattr(self, "_graph_warm", 0)
-            if self._graph_warm < 3:
+            warm = self._graph_warm.get(key, 0)
+            if warm < 3:
                 self._train_host_pre()
                 side = th.cuda.Stream(device=self.device)
                 side.wait_stream(th.cuda.current_stream(self.device))
                 with th.cuda.stream(side):
                     self._graph_body()
                 th.cuda.current_stream(self.device).wait_stream(side)
-                self._graph_warm += 1
+                self._graph_warm[key] = warm + 1
                 self._graph_host_bookkeeping(log_interval)
                 return
             self._train_host_pre()
-            self._graph = self._capture_segments()
+            self._graph[key] = self._capture_segments()
         self._train_host_pre()
-        for item in self._graph:  # hipGraph segments interleaved with the eager collectives that separate them
+        for item in self._graph[key]:  # hipGraph segments interleaved with the eager collectives that separate them
             item.replay() if isinstance(item, th.cuda.CUDAGraph) else item()
         self._graph_host_bookkeeping(log_interval)
 

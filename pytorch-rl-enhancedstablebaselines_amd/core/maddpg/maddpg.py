@@ -157,8 +157,10 @@ class MADDPG(OffPolicyAlgorithm):
             self._update_agent_learning_rates(agent_id)
 
     def _graph_eligible(self, callback) -> bool:
-        return super()._graph_eligible(callback) and self.gradient_steps % self.policy_delay == 0 and \
-            self._n_updates % self.policy_delay == 0 and not self.noise_queue
+        return super()._graph_eligible(callback) and not self.noise_queue
+
+    def _graph_phase(self) -> int:
+        return self._n_updates % self.policy_delay
 
     def _train_host_only(self, gradient_steps: int) -> None:
         n_actor = (self._n_updates + gradient_steps) // self.policy_delay - self._n_updates // self.policy_delay

@@ -81,9 +81,11 @@ class TD3(OffPolicyAlgorithm):
         self._update_learning_rate([self.actor.optimizer, self.critic.optimizer])
 
     def _graph_eligible(self, callback) -> bool:
-        # the delayed policy update makes consecutive iterations differ unless a whole delay period is one iteration
-        return super()._graph_eligible(callback) and self.gradient_steps % self.policy_delay == 0 and \
-            self._n_updates % self.policy_delay == 0 and not self.noise_queue
+        return super()._graph_eligible(callback) and not self.noise_queue
+
+    def _graph_phase(self) -> int:
+        # the delayed policy update makes iterations differ: one captured graph per residue of the update counter
+        return self._n_updates % self.policy_delay
 
     def _train_host_only(self, gradient_steps: int) -> None:
         n_actor = (self._n_updates + gradient_steps) // self.policy_delay - self._n_updates // self.policy_delay

@@ -271,9 +271,10 @@ def test_hipgraph_iteration_equals_eager():
         model.learn(N * iters)
         assert model._n_updates == iters and model.num_timesteps == N * iters
         if use_graph:
-            assert model._graph is not None, "the steady-state iteration was never captured"
-            n_graphs = sum(isinstance(it, th.cuda.CUDAGraph) for it in model._graph)
-            assert n_graphs == (4 if use_graph == "segmented" else 1) and len(model._graph) == 2 * n_graphs - 1
+            assert model._graph, "the steady-state iteration was never captured"
+            (segs,) = model._graph.values()
+            n_graphs = sum(isinstance(it, th.cuda.CUDAGraph) for it in segs)
+            assert n_graphs == (4 if use_graph == "segmented" else 1) and len(segs) == 2 * n_graphs - 1
         th.cuda.synchronize()
         results.append(dict(
             mt=legacy_rng.global_stream(model.device).cpu().numpy().copy(), ctl=model.replay_buffer.ring.ctl.cpu().numpy(),
@@ -362,3 +363,30 @@ def test_maddpg_signature_errors_and_learn():
         assert th.isfinite(p).all()
     # buffer_action == env action (quirk Q1): the ring's actions are the actor outputs, inside [-1, 1]
     assert float(model.replay_buffer.actions.abs().max()) <= 1.0
+
+
+def test_td3_hipgraph_two_phase_capture_equals_eager():
+    """TD3's delayed policy update: two captured graphs (update counter even / odd) replayed alternately."""
+    from core.common import legacy_rng
+    from core.common.vec_env import CSTRVecEnv
+    from core.td3 import TD3
+
+    N, B, seed, iters = 128, 64, 4, 16
+    res = []
+    for use_graph in (False, True):
+        env = CSTRVecEnv(N)
+        model = TD3("MlpPolicy", env, seed=seed, batch_size=B, buffer_size=N * 8, learning_starts=100, policy_kwargs=dict(net_arch=[64, 48]))
+        model.enable_graph_capture(use_graph)
+        model.learn(N * iters)
+        assert model._n_updates == iters and model.actor.optimizer.step_count == iters // 2
+        if use_graph:
+            assert len(model._graph) == 2
+        th.cuda.synchronize()
+        res.append(dict(mt=legacy_rng.global_stream(model.device).cpu().numpy().copy(), ctl=model.replay_buffer.ring.ctl.cpu().numpy(),
+                        actor=model.policy.actor_arena.flat.cpu().numpy(), critic=model.policy.critic_arena.flat.cpu().numpy(),
+                        at=model.policy.actor_target_arena.flat.cpu().numpy(), obs=env.obs.cpu().numpy()))
+    e, g = res
+    np.testing.assert_array_equal(e["mt"], g["mt"])
+    np.testing.assert_array_equal(e["ctl"], g["ctl"])
+    for k in ("actor", "critic", "at", "obs"):
+        np.testing.assert_allclose(e[k], g[k], rtol=2e-3, atol=2e-4, err_msg=k)
