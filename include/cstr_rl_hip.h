@@ -29,7 +29,7 @@ extern "C" {
 
 #define CSTR_OK 0
 #define CSTR_E_BADARG (-1)      /* null pointer / non-positive size / misaligned buffer */
-#define CSTR_E_UNSUPPORTED (-2) /* obs_dim not in {4, 8}, act_dim != 2, batch too large, 64-bit index range */
+#define CSTR_E_UNSUPPORTED (-2) /* (obs_dim, act_dim) not in {(4,2), (8,2), (8,4)}, batch too large, 64-bit index range */
 
 #define CSTR_INTEGRATOR_EULER 0 /* the reference: forward Euler, dt = 0.1 (twoseriescstr.py:493-496) */
 #define CSTR_INTEGRATOR_RK4 1   /* north_star's ask; no reference counterpart */
@@ -53,7 +53,7 @@ typedef struct cstr_coef {
 typedef struct cstr_ring {
     float *obs, *next_obs, *act, *rew, *done, *timeout;
     int64_t rows, n_envs;
-    int32_t obs_dim, act_dim;
+    int32_t obs_dim, act_dim; /* (4,2) | (8,2) | (8,4) */
 } cstr_ring_t;
 
 /* ring_ctl: int64[4] in HBM = { pos, full, ticket, adds }  (buffers.py:101-104 `pos`, `full`) */
@@ -76,21 +76,24 @@ void cstr_default_coef(cstr_coef_t *coef, double target_c2, double min_conc, dou
 /* VecEnv.step for N CSTR envs in one launch. Replaces the Python loop of
  * DummyVecEnv.step_wait (core/common/vec_env/dummy_vec_env.py:56-73) over
  * TwoSeriesCSTREnv.step/_dynamics/compute_reward (twoseriescstr.py:394-503, :271-392).
- *   obs        [N][obs_dim] in : current observations (obs_dim 4: normalised state; 8: [normalised | raw])
- *   act        [N][2]       in : env actions (normalised, clipped to [-1,1] inside, :399)
+ *   (obs_dim, act_dim) selects the layout: (4,2) the reference's observation; (8,2) [normalised | raw];
+ *   (8,4) TWO reactor trains side by side -- [train A | train B] normalised, actions [F1A,F2A,F1B,F2B], reward rA + rB,
+ *   one step counter and one reset stream per env: the 8-obs / 4-act environment a 4-agent MADDPG needs.
+ *   obs        [N][obs_dim] in : current observations
+ *   act        [N][act_dim] in : env actions (normalised, clipped to [-1,1] inside, :399)
  *   step_count [N]          i/o: TwoSeriesCSTREnv.current_step
  *   reset_obs  [N][obs_dim] in : observation an env restarts from when it finishes this step
  *   next_obs   [N][obs_dim] out: true next observation (= infos[i]["terminal_observation"] when done)
  *   obs_after  [N][obs_dim] out: what VecEnv.step returns (reset obs when done); may alias obs
  *   reward/done/timeout [N] out: f32; timeout = infos[i]["TimeLimit.truncated"] */
-int cstr_vec_step_f32(const cstr_coef_t *coef, int integrator, int obs_dim, const float *obs, const float *act,
+int cstr_vec_step_f32(const cstr_coef_t *coef, int integrator, int obs_dim, int act_dim, const float *obs, const float *act,
                       int32_t *step_count, const float *reset_obs, float *next_obs, float *obs_after, float *reward,
                       float *done, float *timeout, int64_t n_envs, cstr_stream_t stream);
 
 /* TwoSeriesCSTREnv.reset draws for envs with mask[i] != 0 (mask NULL = all): generate_initial_state
  * with init_mode="random" (twoseriescstr.py:187-224, :267) from per-env numpy-PCG64 states that the
  * host seeds exactly like gymnasium.utils.seeding.np_random(seed + i) (:162). */
-int cstr_reset_draw_f32(uint64_t *pcg_state, const uint8_t *mask, int obs_dim, float *obs_out, int64_t n_envs,
+int cstr_reset_draw_f32(uint64_t *pcg_state, const uint8_t *mask, int obs_dim, int act_dim, float *obs_out, int64_t n_envs,
                         cstr_stream_t stream);
 
 /* ReplayBuffer.add (core/common/buffers.py:247-283) at the device-resident ring position; the last
@@ -103,13 +106,13 @@ int cstr_replay_add_f32(const cstr_ring_t *ring, int64_t *ring_ctl, const float 
  * (core/common/off_policy_algorithm.py:396-406, :564, :477-496; buffers.py:247-283) in ONE pass over the envs:
  * reads state + policy output once, writes the ring row once, updates the env state in place.
  *   env_obs    [N][obs_dim] i/o: VecEnv state (_last_obs); replaced by the post-reset observation
- *   policy_out [N][2]       in : actor output. `squashed` is a bit field: bit 0 set = tanh output in [-1,1] that
+ *   policy_out [N][act_dim] in : actor output. `squashed` is a bit field: bit 0 set = tanh output in [-1,1] that
  *                                predict() first unscales (core/common/policies.py:375), clear = an action already in
  *                                [low, high] (warm-up sample); bit 1 set = the multi-agent algorithms' behaviour
  *                                (core/common/multiagent_policy_algorithm.py:369, :391-392): no scale/unscale round
  *                                trip and no noise, buffer_action = env action = that value
- *   act_low/act_high [2]    in : HOST pointers, bounds of the algorithm-facing action space
- *   noise      [N][2] or NULL  : added to the scaled action, then clip [-1,1] (off_policy_algorithm.py:401-402)
+ *   act_low/act_high [act_dim] in : HOST pointers, bounds of the algorithm-facing action space
+ *   noise [N][act_dim] or NULL : added to the scaled action, then clip [-1,1] (off_policy_algorithm.py:401-402)
  *   reset_obs  [N][obs_dim] or NULL, pcg_state [N][4] or NULL: reset source (exactly one non-NULL)
  *   reward_out/done_out [N] or NULL: per-env copies (what VecEnv.step would have returned)
  *   ep_return [N] + ep_stats double[4] = {episodes, sum of returns, sum of lengths, -} or both NULL: device-side

@@ -36,8 +36,8 @@ class DeviceRing:
     (core/common/buffers.py:212-234): [rows, n_envs, D] / [rows, n_envs, A] / [rows, n_envs]."""
 
     def __init__(self, rows: int, n_envs: int, obs_dim: int, act_dim: int, device):
-        if obs_dim not in (4, 8) or act_dim != 2:
-            raise ValueError(f"DeviceRing supports obs_dim 4|8 and act_dim 2 (CSTR), got {obs_dim}/{act_dim}")
+        if (obs_dim, act_dim) not in ((4, 2), (8, 2), (8, 4)):
+            raise ValueError(f"DeviceRing supports (obs_dim, act_dim) in (4,2), (8,2), (8,4) (CSTR layouts), got {obs_dim}/{act_dim}")
         z = lambda *s: th.zeros(*s, dtype=th.float32, device=device)  # noqa: E731
         self.observations, self.next_observations = z(rows, n_envs, obs_dim), z(rows, n_envs, obs_dim)
         self.actions = z(rows, n_envs, act_dim)
@@ -51,21 +51,22 @@ class DeviceRing:
 
 def vec_step(coef, integrator: str, obs, act, step_count, reset_obs, next_obs, obs_after, reward, done, timeout):
     n, d = obs.shape
-    _chk(obs, "obs", (n, d), th.float32), _chk(act, "act", (n, 2), th.float32)
+    a = act.shape[-1]
+    _chk(obs, "obs", (n, d), th.float32), _chk(act, "act", (n, a), th.float32)
     _chk(step_count, "step_count", (n,), th.int32), _chk(reset_obs, "reset_obs", (n, d), th.float32)
     _chk(next_obs, "next_obs", (n, d), th.float32), _chk(obs_after, "obs_after", (n, d), th.float32)
     for t, nm in ((reward, "reward"), (done, "done"), (timeout, "timeout")):
         _chk(t, nm, (n,), th.float32)
-    check(nv.lib().cstr_vec_step_f32(C.byref(coef), C.c_int(INTEGRATORS[integrator]), C.c_int(d), ptr(obs), ptr(act),
+    check(nv.lib().cstr_vec_step_f32(C.byref(coef), C.c_int(INTEGRATORS[integrator]), C.c_int(d), C.c_int(a), ptr(obs), ptr(act),
                                      ptr(step_count), ptr(reset_obs), ptr(next_obs), ptr(obs_after), ptr(reward),
                                      ptr(done), ptr(timeout), C.c_int64(n), stream_ptr()), "cstr_vec_step_f32")
 
 
-def reset_draw(pcg_state, mask, obs_out):
+def reset_draw(pcg_state, mask, obs_out, act_dim: int = 2):
     n, d = obs_out.shape
     _chk(pcg_state, "pcg_state", (n, nv.PCG_STATE_WORDS), th.int64), _chk(obs_out, "obs_out", (n, d), th.float32)
     _opt(mask, "mask", (n,), th.uint8)
-    check(nv.lib().cstr_reset_draw_f32(ptr(pcg_state), ptr(mask), C.c_int(d), ptr(obs_out), C.c_int64(n), stream_ptr()),
+    check(nv.lib().cstr_reset_draw_f32(ptr(pcg_state), ptr(mask), C.c_int(d), C.c_int(act_dim), ptr(obs_out), C.c_int64(n), stream_ptr()),
           "cstr_reset_draw_f32")
 
 
@@ -81,10 +82,10 @@ def replay_add(ring: DeviceRing, obs, next_obs, act, rew, done, timeout):
 def collect_step(coef, integrator: str, ring: DeviceRing, env_obs, step_count, policy_out, squashed, act_low,
                  act_high, noise=None, reset_obs=None, pcg_state=None, reward_out=None, done_out=None, ep_return=None,
                  ep_stats=None):
-    n, d = ring.n_envs, ring.obs_dim
+    n, d, a = ring.n_envs, ring.obs_dim, ring.act_dim
     _chk(env_obs, "env_obs", (n, d), th.float32), _chk(step_count, "step_count", (n,), th.int32)
-    _chk(policy_out, "policy_out", (n, 2), th.float32)
-    _opt(noise, "noise", (n, 2), th.float32), _opt(reset_obs, "reset_obs", (n, d), th.float32)
+    _chk(policy_out, "policy_out", (n, a), th.float32)
+    _opt(noise, "noise", (n, a), th.float32), _opt(reset_obs, "reset_obs", (n, d), th.float32)
     _opt(pcg_state, "pcg_state", (n, nv.PCG_STATE_WORDS), th.int64)
     _opt(reward_out, "reward_out", (n,), th.float32), _opt(done_out, "done_out", (n,), th.float32)
     _opt(ep_return, "ep_return", (n,), th.float32), _opt(ep_stats, "ep_stats", (4,), th.float64)
@@ -92,8 +93,10 @@ def collect_step(coef, integrator: str, ring: DeviceRing, env_obs, step_count, p
         raise ValueError("ep_return and ep_stats go together")
     if (reset_obs is None) == (pcg_state is None):
         raise ValueError("collect_step needs exactly one reset source: reset_obs or pcg_state")
-    lo = (C.c_float * 2)(float(act_low[0]), float(act_low[1]))
-    hi = (C.c_float * 2)(float(act_high[0]), float(act_high[1]))
+    if len(act_low) != a or len(act_high) != a:
+        raise ValueError(f"act_low/act_high need {a} entries")
+    lo = (C.c_float * a)(*[float(v) for v in act_low])
+    hi = (C.c_float * a)(*[float(v) for v in act_high])
     check(nv.lib().cstr_collect_step_f32(C.byref(coef), C.c_int(INTEGRATORS[integrator]), C.byref(ring.c), ptr(ring.ctl),
                                          ptr(env_obs), ptr(step_count), ptr(policy_out), C.c_int(int(squashed)), lo, hi,
                                          ptr(noise), ptr(reset_obs), ptr(pcg_state), ptr(reward_out), ptr(done_out),

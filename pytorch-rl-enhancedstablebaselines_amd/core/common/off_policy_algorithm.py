@@ -104,7 +104,7 @@ class OffPolicyAlgorithm(BaseAlgorithm):
     def _fast_path(self) -> bool:
         rb = self.replay_buffer
         return (isinstance(self.env, CSTRVecEnv) and type(rb) is ReplayBuffer and rb.n_envs == self.env.num_envs
-                and rb.obs_shape[0] == self.env.obs_dim and self._vec_normalize_env is None)
+                and rb.obs_shape[0] == self.env.obs_dim and rb.action_dim == self.env.act_dim and self._vec_normalize_env is None)
 
     # ---- learn ----------------------------------------------------------------------------------------------------
     def _setup_learn(self, total_timesteps, callback=None, reset_num_timesteps=True, tb_log_name="run", progress_bar=False):

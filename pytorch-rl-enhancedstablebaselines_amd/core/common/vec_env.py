@@ -90,6 +90,9 @@ class CSTRVecEnv(VecEnv):
     :param num_envs: number of reactor trains held by this process / GPU
     :param obs_dim: 4 = the reference's observation [C1,T1,C2,T2] normalised to [-1,1];
                     8 = [normalised | raw] (both halves are emitted by the reference's `info`)
+    :param twin: with obs_dim=8: TWO reactor trains side by side per env -- observation [train A | train B] (both
+                    normalised), 4 actions [F1A,F2A,F1B,F2B], reward rA + rB, one step counter / reset stream per env.
+                    The 8-obs/4-act environment a 4-agent MADDPG needs (constructed, not in the reference)
     :param integrator: "euler" (reference, parity-pinned) or "rk4" (north_star's ask; not in the reference)
     :param default_target, min_concentration, max_concentration, init_mode: TwoSeriesCSTREnv ctor args
     :param seed_offset: added to env seeds, used by data-parallel shards (rank * num_envs)
@@ -100,9 +103,11 @@ class CSTRVecEnv(VecEnv):
 
     def __init__(self, num_envs: int, obs_dim: int = 4, integrator: str = "euler", device="cuda",
                  default_target: float = 0.20, min_concentration: float = 0.05, max_concentration: float = 0.45,
-                 init_mode: str = "random", seed_offset: int = 0):
+                 init_mode: str = "random", seed_offset: int = 0, twin: bool = False):
         if obs_dim not in (4, 8):
             raise ValueError(f"obs_dim must be 4 or 8, got {obs_dim}")
+        if twin and obs_dim != 8:
+            raise ValueError("twin=True needs obs_dim=8 (two 4-dim reactor trains per env)")
         if integrator not in nv.INTEGRATORS:
             raise ValueError(f"integrator must be one of {list(nv.INTEGRATORS)}, got {integrator!r}")
         if init_mode != "random":
@@ -113,12 +118,14 @@ class CSTRVecEnv(VecEnv):
         self.device = get_device(device)
         nv.lib()  # fail loudly if the HIP extension is missing
         one = np.ones(obs_dim, np.float32)
-        if obs_dim == 8:
+        self.twin, self.act_dim = twin, (4 if twin else 2)
+        if obs_dim == 8 and not twin:
             lo = np.concatenate([-one[:4], np.array([0.0, 273.15, 0.0, 273.15], np.float32)])
             hi = np.concatenate([one[:4], np.array([0.7, 400.0, 0.7, 400.0], np.float32)])
         else:
             lo, hi = -one, one
-        super().__init__(num_envs, Box(lo, hi, dtype=np.float32), Box(-np.ones(2, np.float32), np.ones(2, np.float32), dtype=np.float32))
+        a1 = np.ones(self.act_dim, np.float32)
+        super().__init__(num_envs, Box(lo, hi, dtype=np.float32), Box(-a1, a1, dtype=np.float32))
         self.obs_dim, self.integrator, self.seed_offset = obs_dim, integrator, seed_offset
         self.target_C2, self.min_concentration, self.max_concentration = default_target, min_concentration, max_concentration
         self.init_mode = init_mode
@@ -169,7 +176,7 @@ class CSTRVecEnv(VecEnv):
         elif not self._rng_seeded:
             self._seed_rng([None] * self.num_envs)  # unseeded envs draw OS entropy, like gymnasium does
         with th.cuda.device(self.device):
-            hip_ops.reset_draw(self.pcg_state, None, self.obs)
+            hip_ops.reset_draw(self.pcg_state, None, self.obs, self.act_dim)
             self.step_count.zero_()
         self._reset_seeds()
         self._reset_options()
@@ -182,7 +189,7 @@ class CSTRVecEnv(VecEnv):
     def set_state(self, obs, step_count=None) -> None:
         """Inject observations / step counters (tests, fixtures). obs: [N, 4] normalised or [N, obs_dim]."""
         obs = th.as_tensor(np.asarray(obs, np.float32))
-        if obs.shape == (self.num_envs, 4) and self.obs_dim == 8:
+        if obs.shape == (self.num_envs, 4) and self.obs_dim == 8 and not self.twin:
             lo = th.tensor([0.0, 273.15, 0.0, 273.15])
             hi = th.tensor([0.7, 400.0, 0.7, 400.0])
             raw = th.minimum(th.maximum(lo + (obs + 1.0) * (hi - lo) / 2.0, lo), hi)
@@ -208,14 +215,14 @@ class CSTRVecEnv(VecEnv):
             hip_ops.vec_step(self.coef, self.integrator, self.obs, actions, self.step_count, self.obs, self._next_obs,
                              self._reset_buf, self._rew, self._done, self._timeout)
             # _reset_buf now holds obs_after with the OLD obs where done; overwrite those rows with fresh draws
-            hip_ops.reset_draw(self.pcg_state, self._done.to(th.uint8), self._reset_buf)
+            hip_ops.reset_draw(self.pcg_state, self._done.to(th.uint8), self._reset_buf, self.act_dim)
             self.obs.copy_(self._reset_buf)
         return self.obs, self._rew, self._done, self._timeout, self._next_obs
 
     def step_async(self, actions) -> None:
         a = th.as_tensor(np.asarray(actions, dtype=np.float32)) if not isinstance(actions, th.Tensor) else actions
-        if tuple(a.shape) != (self.num_envs, 2):
-            raise ValueError(f"actions shape {tuple(a.shape)} != {(self.num_envs, 2)}")
+        if tuple(a.shape) != (self.num_envs, self.act_dim):
+            raise ValueError(f"actions shape {tuple(a.shape)} != {(self.num_envs, self.act_dim)}")
         self._pending_actions = a.to(self.device, th.float32).contiguous()
 
     def step_wait(self):

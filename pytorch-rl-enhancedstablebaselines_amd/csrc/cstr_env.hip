@@ -167,49 +167,117 @@ __device__ __forceinline__ void denorm4(const cstr_coef_t &k, const float o[4], 
     for (int i = 0; i < 4; ++i) raw[i] = k.s_lo[i] + (o[i] + 1.0f) * k.s_span[i] / 2.0f;
 }
 
-template <int D>
-__device__ __forceinline__ void load_obs(const float *p, int64_t i, float o[4], float raw[4])
+// ---- observation layouts ----------------------------------------------------------------------------
+// L = 0: D=4, A=2  the reference's observation [C1,T1,C2,T2] normalised (twoseriescstr.py:74-85)
+// L = 1: D=8, A=2  [normalised | raw] (both halves are what the reference's `info` carries)
+// L = 2: D=8, A=4  TWO reactor trains side by side, [train A normalised | train B normalised], actions
+//                  [F1A, F2A, F1B, F2B], reward = rA + rB, one step counter / one reset stream per env: the 8-obs/4-act
+//                  environment MADDPG's 4-agent configuration needs (no such env exists in the reference).
+template <int L>
+struct Lay {
+    static constexpr int D = (L == 0) ? 4 : 8, A = (L == 2) ? 4 : 2, TR = (L == 2) ? 2 : 1;
+};
+
+template <int L>
+__device__ __forceinline__ void load_obs(const float *p, int64_t i, float o[2][4])
 {
-    const float4 v = *reinterpret_cast<const float4 *>(p + i * D);
-    o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
-    if (D == 8) {
-        const float4 w = *reinterpret_cast<const float4 *>(p + i * D + 4);
-        raw[0] = w.x; raw[1] = w.y; raw[2] = w.z; raw[3] = w.w;
+    const float4 v = *reinterpret_cast<const float4 *>(p + i * Lay<L>::D);
+    o[0][0] = v.x; o[0][1] = v.y; o[0][2] = v.z; o[0][3] = v.w;
+    if (L != 0) {  // L=1: raw half (carried through to the ring); L=2: train B
+        const float4 w = *reinterpret_cast<const float4 *>(p + i * 8 + 4);
+        o[1][0] = w.x; o[1][1] = w.y; o[1][2] = w.z; o[1][3] = w.w;
     }
 }
 
-template <int D>
-__device__ __forceinline__ void store_obs(float *p, int64_t i, const float o[4], const float raw[4])
+template <int L>
+__device__ __forceinline__ void store_obs(float *p, int64_t i, const float o[2][4])
 {
-    *reinterpret_cast<float4 *>(p + i * D) = make_float4(o[0], o[1], o[2], o[3]);
-    if (D == 8) *reinterpret_cast<float4 *>(p + i * D + 4) = make_float4(raw[0], raw[1], raw[2], raw[3]);
+    *reinterpret_cast<float4 *>(p + i * Lay<L>::D) = make_float4(o[0][0], o[0][1], o[0][2], o[0][3]);
+    if (L != 0) *reinterpret_cast<float4 *>(p + i * 8 + 4) = make_float4(o[1][0], o[1][1], o[1][2], o[1][3]);
 }
 
-template <int D>
+template <int L>
 __device__ __forceinline__ void copy_obs(float *dst, int64_t di, const float *src, int64_t si)
 {
+    constexpr int D = Lay<L>::D;
     *reinterpret_cast<float4 *>(dst + di * D) = *reinterpret_cast<const float4 *>(src + si * D);
     if (D == 8) *reinterpret_cast<float4 *>(dst + di * D + 4) = *reinterpret_cast<const float4 *>(src + si * D + 4);
 }
 
+// All trains of one env advance one step. on[][]: next observation in the layout's register image.
+template <int L, int INTEG>
+__device__ __forceinline__ bool env_step_lane(const cstr_coef_t &k, const float o[2][4], const float a[4], int32_t &step,
+                                              float on[2][4], float &reward)
+{
+    float raw[4], r0;
+    int32_t st = step;
+    bool trunc = cstr_step_lane<INTEG>(k, o[0], a[0], a[1], st, on[0], raw, r0);
+    reward = r0;
+    if (L == 1) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) on[1][j] = raw[j];
+    }
+    if (L == 2) {
+        int32_t st2 = step;
+        float r1;
+        trunc |= cstr_step_lane<INTEG>(k, o[1], a[2], a[3], st2, on[1], raw, r1);
+        reward = r0 + r1;
+    }
+    step = st;
+    return trunc;
+}
+
+template <int L>
+__device__ __forceinline__ void reset_draw_env(const cstr_coef_t &k, uint64_t st[4], float o[2][4])
+{
+    cstr_reset_draw_lane(st, o[0]);
+    if (L == 1) denorm4(k, o[0], o[1]);
+    if (L == 2) cstr_reset_draw_lane(st, o[1]);  // train B continues the env's stream
+}
+
+__device__ __forceinline__ void load_pcg(const uint64_t *pcg, int64_t i, uint64_t st[4])
+{
+    const ulonglong2 a = *reinterpret_cast<const ulonglong2 *>(pcg + 4 * i), b = *reinterpret_cast<const ulonglong2 *>(pcg + 4 * i + 2);
+    st[0] = a.x; st[1] = a.y; st[2] = b.x; st[3] = b.y;
+}
+
+template <int A>
+__device__ __forceinline__ void load_act(const float *p, int64_t i, float a[4])
+{
+    if (A == 2) {
+        const float2 v = *reinterpret_cast<const float2 *>(p + 2 * i);
+        a[0] = v.x; a[1] = v.y; a[2] = 0.0f; a[3] = 0.0f;
+    } else {
+        const float4 v = *reinterpret_cast<const float4 *>(p + 4 * i);
+        a[0] = v.x; a[1] = v.y; a[2] = v.z; a[3] = v.w;
+    }
+}
+
+template <int A>
+__device__ __forceinline__ void store_act(float *p, int64_t i, const float a[4])
+{
+    if (A == 2) *reinterpret_cast<float2 *>(p + 2 * i) = make_float2(a[0], a[1]);
+    else *reinterpret_cast<float4 *>(p + 4 * i) = make_float4(a[0], a[1], a[2], a[3]);
+}
+
 // ---- kernels --------------------------------------------------------------------------------------
 
-template <int D, int INTEG>
+template <int L, int INTEG>
 __global__ void vec_step_kernel(const cstr_coef_t k, const float *__restrict__ obs, const float *__restrict__ act,
                                 int32_t *__restrict__ step_count, const float *__restrict__ reset_obs,
                                 float *__restrict__ next_obs, float *obs_after, float *__restrict__ reward,
                                 float *__restrict__ done, float *__restrict__ timeout, int64_t n)
 {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        float o[4], oraw[4], on[4], raw[4], r;
-        load_obs<D>(obs, i, o, oraw);
-        const float2 a = *reinterpret_cast<const float2 *>(act + 2 * i);
+        float o[2][4], on[2][4], a[4], r;
+        load_obs<L>(obs, i, o);
+        load_act<Lay<L>::A>(act, i, a);
         int32_t st = step_count[i];
-        const bool trunc = cstr_step_lane<INTEG>(k, o, a.x, a.y, st, on, raw, r);
+        const bool trunc = env_step_lane<L, INTEG>(k, o, a, st, on, r);
         const bool d = trunc;  // terminated is always False (:435); done = terminated or truncated (dummy_vec_env.py:63)
-        store_obs<D>(next_obs, i, on, raw);
-        if (d) copy_obs<D>(obs_after, i, reset_obs, i);  // dummy_vec_env.py:68-72
-        else store_obs<D>(obs_after, i, on, raw);
+        store_obs<L>(next_obs, i, on);
+        if (d) copy_obs<L>(obs_after, i, reset_obs, i);  // dummy_vec_env.py:68-72
+        else store_obs<L>(obs_after, i, on);
         reward[i] = r;
         done[i] = d ? 1.0f : 0.0f;
         timeout[i] = trunc ? 1.0f : 0.0f;  // dummy_vec_env.py:66
@@ -217,73 +285,68 @@ __global__ void vec_step_kernel(const cstr_coef_t k, const float *__restrict__ o
     }
 }
 
-template <int D>
+template <int L>
 __global__ void reset_draw_kernel(const cstr_coef_t k, uint64_t *__restrict__ pcg, const uint8_t *__restrict__ mask,
                                   float *__restrict__ obs_out, int64_t n)
 {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         if (mask && !mask[i]) continue;
         uint64_t st[4];
-        const ulonglong2 a = *reinterpret_cast<const ulonglong2 *>(pcg + 4 * i), b = *reinterpret_cast<const ulonglong2 *>(pcg + 4 * i + 2);
-        st[0] = a.x; st[1] = a.y; st[2] = b.x; st[3] = b.y;
-        float o[4], raw[4];
-        cstr_reset_draw_lane(st, o);
-        denorm4(k, o, raw);
-        store_obs<D>(obs_out, i, o, raw);
+        load_pcg(pcg, i, st);
+        float o[2][4];
+        reset_draw_env<L>(k, st, o);
+        store_obs<L>(obs_out, i, o);
         *reinterpret_cast<ulonglong2 *>(pcg + 4 * i) = make_ulonglong2(st[0], st[1]);
     }
 }
 
+struct ActBounds { float lo[4], hi[4]; };
+
 // Fused collect step: action scaling chain + env step + auto-reset + ring row write, one pass.
 // Algorithmic HBM traffic per env (D = 4): 16 B state + 8 B action + 4 B step read; 52 B ring row
 // + 16 B state + 4 B step written  => 104 B / env-step.
-template <int D, int INTEG>
+template <int L, int INTEG>
 __global__ void collect_step_kernel(const cstr_coef_t k, const cstr_ring_t ring, int64_t *__restrict__ ring_ctl,
                                     float *__restrict__ env_obs, int32_t *__restrict__ step_count,
-                                    const float *__restrict__ policy_out, const int squashed, const float lo0,
-                                    const float hi0, const float lo1, const float hi1, const float *__restrict__ noise,
-                                    const float *__restrict__ reset_obs, uint64_t *__restrict__ pcg,
-                                    float *__restrict__ reward_out, float *__restrict__ done_out,
+                                    const float *__restrict__ policy_out, const int squashed, const ActBounds ab,
+                                    const float *__restrict__ noise, const float *__restrict__ reset_obs,
+                                    uint64_t *__restrict__ pcg, float *__restrict__ reward_out, float *__restrict__ done_out,
                                     float *__restrict__ ep_return, double *__restrict__ ep_stats)
 {
+    constexpr int A = Lay<L>::A;
     const int64_t n = ring.n_envs;
     const int64_t pos = ring_ctl[0];  // wave-uniform scalar load
     const int64_t row = pos * n;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        float o[4], oraw[4], on[4], raw[4], r;
-        load_obs<D>(env_obs, i, o, oraw);
-        const float2 p = *reinterpret_cast<const float2 *>(policy_out + 2 * i);
-        float u0 = p.x, u1 = p.y;
-        if (squashed & 1) {  // predict(): unscale_action (core/common/policies.py:375, :413)
-            u0 = lo0 + (0.5f * (u0 + 1.0f) * (hi0 - lo0));
-            u1 = lo1 + (0.5f * (u1 + 1.0f) * (hi1 - lo1));
-        }
-        float s0, s1, a0, a1;
-        if (squashed & 2) {
-            // multi-agent algorithms: `isinstance(any(...), spaces.Box)` is always False in the reference, so neither
-            // scaling nor action noise is applied and buffer_action = action = predict() output
-            // (core/common/multiagent_policy_algorithm.py:369, :391-392)
-            s0 = a0 = u0;
-            s1 = a1 = u1;
-        } else {
-            s0 = 2.0f * ((u0 - lo0) / (hi0 - lo0)) - 1.0f;  // scale_action (policies.py:402)
-            s1 = 2.0f * ((u1 - lo1) / (hi1 - lo1)) - 1.0f;
-            if (noise) {  // off_policy_algorithm.py:401-402
-                const float2 z = *reinterpret_cast<const float2 *>(noise + 2 * i);
-                s0 = fminf(fmaxf(s0 + z.x, -1.0f), 1.0f);
-                s1 = fminf(fmaxf(s1 + z.y, -1.0f), 1.0f);
+        float o[2][4], on[2][4], u[4], sa[4], ea[4], z[4], r;
+        load_obs<L>(env_obs, i, o);
+        load_act<A>(policy_out, i, u);
+        if (noise) load_act<A>(noise, i, z);
+#pragma unroll
+        for (int j = 0; j < A; ++j) {
+            const float lo = ab.lo[j], hi = ab.hi[j];
+            float v = u[j];
+            if (squashed & 1) v = lo + (0.5f * (v + 1.0f) * (hi - lo));  // predict(): unscale_action (policies.py:375, :413)
+            if (squashed & 2) {
+                // multi-agent algorithms: `isinstance(any(...), spaces.Box)` is always False in the reference, so neither
+                // scaling nor action noise is applied and buffer_action = action = predict() output
+                // (core/common/multiagent_policy_algorithm.py:369, :391-392)
+                sa[j] = ea[j] = v;
+            } else {
+                float sc = 2.0f * ((v - lo) / (hi - lo)) - 1.0f;        // scale_action (policies.py:402)
+                if (noise) sc = fminf(fmaxf(sc + z[j], -1.0f), 1.0f);   // off_policy_algorithm.py:401-402
+                sa[j] = sc;                                              // buffer_action (:405)
+                ea[j] = lo + (0.5f * (sc + 1.0f) * (hi - lo));           // unscale_action (:406)
             }
-            a0 = lo0 + (0.5f * (s0 + 1.0f) * (hi0 - lo0));  // unscale_action (:406)
-            a1 = lo1 + (0.5f * (s1 + 1.0f) * (hi1 - lo1));
         }
         int32_t st = step_count[i];
-        const bool trunc = cstr_step_lane<INTEG>(k, o, a0, a1, st, on, raw, r);
+        const bool trunc = env_step_lane<L, INTEG>(k, o, ea, st, on, r);
         const bool d = trunc;
 
         // ring row: obs = _last_obs, next_obs = terminal observation (off_policy_algorithm.py:477-496)
-        store_obs<D>(ring.obs, row + i, o, oraw);
-        store_obs<D>(ring.next_obs, row + i, on, raw);
-        *reinterpret_cast<float2 *>(ring.act + 2 * (row + i)) = make_float2(s0, s1);  // buffer_action (:405)
+        store_obs<L>(ring.obs, row + i, o);
+        store_obs<L>(ring.next_obs, row + i, on);
+        store_act<A>(ring.act, row + i, sa);
         ring.rew[row + i] = r;
         ring.done[row + i] = d ? 1.0f : 0.0f;
         ring.timeout[row + i] = trunc ? 1.0f : 0.0f;
@@ -302,20 +365,18 @@ __global__ void collect_step_kernel(const cstr_coef_t k, const cstr_ring_t ring,
         // env state for the next iteration (dummy_vec_env.py:68-72)
         if (d) {
             if (reset_obs) {
-                copy_obs<D>(env_obs, i, reset_obs, i);
+                copy_obs<L>(env_obs, i, reset_obs, i);
             } else {
                 uint64_t pst[4];
-                const ulonglong2 a = *reinterpret_cast<const ulonglong2 *>(pcg + 4 * i), b = *reinterpret_cast<const ulonglong2 *>(pcg + 4 * i + 2);
-                pst[0] = a.x; pst[1] = a.y; pst[2] = b.x; pst[3] = b.y;
-                float ro[4], rr[4];
-                cstr_reset_draw_lane(pst, ro);
-                denorm4(k, ro, rr);
-                store_obs<D>(env_obs, i, ro, rr);
+                load_pcg(pcg, i, pst);
+                float ro[2][4];
+                reset_draw_env<L>(k, pst, ro);
+                store_obs<L>(env_obs, i, ro);
                 *reinterpret_cast<ulonglong2 *>(pcg + 4 * i) = make_ulonglong2(pst[0], pst[1]);
             }
             st = 0;
         } else {
-            store_obs<D>(env_obs, i, on, raw);
+            store_obs<L>(env_obs, i, on);
         }
         step_count[i] = st;
     }
@@ -323,17 +384,20 @@ __global__ void collect_step_kernel(const cstr_coef_t k, const cstr_ring_t ring,
 }
 
 // ReplayBuffer.add: six row copies in one launch
-template <int D>
+template <int L>
 __global__ void replay_add_kernel(const cstr_ring_t ring, int64_t *__restrict__ ring_ctl, const float *__restrict__ obs,
                                   const float *__restrict__ next_obs, const float *__restrict__ act,
                                   const float *__restrict__ rew, const float *__restrict__ done,
                                   const float *__restrict__ timeout)
 {
+    constexpr int A = Lay<L>::A;
     const int64_t n = ring.n_envs, row = ring_ctl[0] * n;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        copy_obs<D>(ring.obs, row + i, obs, i);
-        copy_obs<D>(ring.next_obs, row + i, next_obs, i);
-        *reinterpret_cast<float2 *>(ring.act + 2 * (row + i)) = *reinterpret_cast<const float2 *>(act + 2 * i);
+        float a[4];
+        copy_obs<L>(ring.obs, row + i, obs, i);
+        copy_obs<L>(ring.next_obs, row + i, next_obs, i);
+        load_act<A>(act, i, a);
+        store_act<A>(ring.act, row + i, a);
         ring.rew[row + i] = rew[i];
         ring.done[row + i] = done[i];
         ring.timeout[row + i] = timeout[i];
@@ -345,42 +409,58 @@ __global__ void replay_add_kernel(const cstr_ring_t ring, int64_t *__restrict__ 
 
 // ---- C ABI ------------------------------------------------------------------------------------------
 
-#define DISPATCH_D_INTEG(KERNEL, ...)                                                                              \
-    do {                                                                                                           \
-        if (obs_dim == 4 && integrator == CSTR_INTEGRATOR_EULER) KERNEL<4, CSTR_INTEGRATOR_EULER><<<grid, block, 0, s>>>(__VA_ARGS__); \
-        else if (obs_dim == 4) KERNEL<4, CSTR_INTEGRATOR_RK4><<<grid, block, 0, s>>>(__VA_ARGS__);                  \
-        else if (integrator == CSTR_INTEGRATOR_EULER) KERNEL<8, CSTR_INTEGRATOR_EULER><<<grid, block, 0, s>>>(__VA_ARGS__); \
-        else KERNEL<8, CSTR_INTEGRATOR_RK4><<<grid, block, 0, s>>>(__VA_ARGS__);                                    \
+static int layout_of(int obs_dim, int act_dim)
+{
+    if (obs_dim == 4 && act_dim == 2) return 0;
+    if (obs_dim == 8 && act_dim == 2) return 1;
+    if (obs_dim == 8 && act_dim == 4) return 2;
+    return -1;
+}
+
+#define DISPATCH_L_INTEG(KERNEL, ...)                                                                       \
+    do {                                                                                                    \
+        const bool eu = integrator == CSTR_INTEGRATOR_EULER;                                               \
+        if (layout == 0 && eu) KERNEL<0, CSTR_INTEGRATOR_EULER><<<grid, block, 0, s>>>(__VA_ARGS__);        \
+        else if (layout == 0) KERNEL<0, CSTR_INTEGRATOR_RK4><<<grid, block, 0, s>>>(__VA_ARGS__);           \
+        else if (layout == 1 && eu) KERNEL<1, CSTR_INTEGRATOR_EULER><<<grid, block, 0, s>>>(__VA_ARGS__);   \
+        else if (layout == 1) KERNEL<1, CSTR_INTEGRATOR_RK4><<<grid, block, 0, s>>>(__VA_ARGS__);           \
+        else if (eu) KERNEL<2, CSTR_INTEGRATOR_EULER><<<grid, block, 0, s>>>(__VA_ARGS__);                  \
+        else KERNEL<2, CSTR_INTEGRATOR_RK4><<<grid, block, 0, s>>>(__VA_ARGS__);                            \
     } while (0)
 
-extern "C" int cstr_vec_step_f32(const cstr_coef_t *coef, int integrator, int obs_dim, const float *obs, const float *act,
-                                 int32_t *step_count, const float *reset_obs, float *next_obs, float *obs_after,
-                                 float *reward, float *done, float *timeout, int64_t n_envs, cstr_stream_t stream)
+extern "C" int cstr_vec_step_f32(const cstr_coef_t *coef, int integrator, int obs_dim, int act_dim, const float *obs,
+                                 const float *act, int32_t *step_count, const float *reset_obs, float *next_obs,
+                                 float *obs_after, float *reward, float *done, float *timeout, int64_t n_envs,
+                                 cstr_stream_t stream)
 {
     if (!coef || !obs || !act || !step_count || !reset_obs || !next_obs || !obs_after || !reward || !done || !timeout || n_envs <= 0)
         return CSTR_E_BADARG;
-    if ((obs_dim != 4 && obs_dim != 8) || (integrator != CSTR_INTEGRATOR_EULER && integrator != CSTR_INTEGRATOR_RK4))
-        return CSTR_E_UNSUPPORTED;
-    if (!aligned16(obs) || !aligned16(reset_obs) || !aligned16(next_obs) || !aligned16(obs_after) || !aligned8(act)) return CSTR_E_BADARG;
+    const int layout = layout_of(obs_dim, act_dim);
+    if (layout < 0 || (integrator != CSTR_INTEGRATOR_EULER && integrator != CSTR_INTEGRATOR_RK4)) return CSTR_E_UNSUPPORTED;
+    if (!aligned16(obs) || !aligned16(reset_obs) || !aligned16(next_obs) || !aligned16(obs_after) ||
+        !(act_dim == 4 ? aligned16(act) : aligned8(act)))
+        return CSTR_E_BADARG;
     hipStream_t s = (hipStream_t)stream;
     int block, grid;
     env_launch_shape(n_envs, block, grid);
-    DISPATCH_D_INTEG(vec_step_kernel, *coef, obs, act, step_count, reset_obs, next_obs, obs_after, reward, done, timeout, n_envs);
+    DISPATCH_L_INTEG(vec_step_kernel, *coef, obs, act, step_count, reset_obs, next_obs, obs_after, reward, done, timeout, n_envs);
     return (int)hipGetLastError();
 }
 
-extern "C" int cstr_reset_draw_f32(uint64_t *pcg_state, const uint8_t *mask, int obs_dim, float *obs_out, int64_t n_envs,
-                                   cstr_stream_t stream)
+extern "C" int cstr_reset_draw_f32(uint64_t *pcg_state, const uint8_t *mask, int obs_dim, int act_dim, float *obs_out,
+                                   int64_t n_envs, cstr_stream_t stream)
 {
     if (!pcg_state || !obs_out || n_envs <= 0 || !aligned16(obs_out) || !aligned16(pcg_state)) return CSTR_E_BADARG;
-    if (obs_dim != 4 && obs_dim != 8) return CSTR_E_UNSUPPORTED;
+    const int layout = layout_of(obs_dim, act_dim);
+    if (layout < 0) return CSTR_E_UNSUPPORTED;
     cstr_coef_t k;
     cstr_default_coef(&k, 0.2, 0.05, 0.45, 400);
     hipStream_t s = (hipStream_t)stream;
     int block, grid;
     env_launch_shape(n_envs, block, grid);
-    if (obs_dim == 4) reset_draw_kernel<4><<<grid, block, 0, s>>>(k, pcg_state, mask, obs_out, n_envs);
-    else reset_draw_kernel<8><<<grid, block, 0, s>>>(k, pcg_state, mask, obs_out, n_envs);
+    if (layout == 0) reset_draw_kernel<0><<<grid, block, 0, s>>>(k, pcg_state, mask, obs_out, n_envs);
+    else if (layout == 1) reset_draw_kernel<1><<<grid, block, 0, s>>>(k, pcg_state, mask, obs_out, n_envs);
+    else reset_draw_kernel<2><<<grid, block, 0, s>>>(k, pcg_state, mask, obs_out, n_envs);
     return (int)hipGetLastError();
 }
 
@@ -388,8 +468,8 @@ static int check_ring(const cstr_ring_t *r)
 {
     if (!r || !r->obs || !r->next_obs || !r->act || !r->rew || !r->done || !r->timeout || r->rows <= 0 || r->n_envs <= 0)
         return CSTR_E_BADARG;
-    if ((r->obs_dim != 4 && r->obs_dim != 8) || r->act_dim != 2) return CSTR_E_UNSUPPORTED;
-    if (!aligned16(r->obs) || !aligned16(r->next_obs) || !aligned8(r->act)) return CSTR_E_BADARG;
+    if (layout_of(r->obs_dim, r->act_dim) < 0) return CSTR_E_UNSUPPORTED;
+    if (!aligned16(r->obs) || !aligned16(r->next_obs) || !(r->act_dim == 4 ? aligned16(r->act) : aligned8(r->act))) return CSTR_E_BADARG;
     return CSTR_OK;
 }
 
@@ -400,12 +480,14 @@ extern "C" int cstr_replay_add_f32(const cstr_ring_t *ring, int64_t *ring_ctl, c
     int rc = check_ring(ring);
     if (rc) return rc;
     if (!ring_ctl || !obs || !next_obs || !act || !rew || !done || !timeout) return CSTR_E_BADARG;
-    if (!aligned16(obs) || !aligned16(next_obs) || !aligned8(act)) return CSTR_E_BADARG;
+    if (!aligned16(obs) || !aligned16(next_obs) || !(ring->act_dim == 4 ? aligned16(act) : aligned8(act))) return CSTR_E_BADARG;
     hipStream_t s = (hipStream_t)stream;
     int block, grid;
     env_launch_shape(ring->n_envs, block, grid);
-    if (ring->obs_dim == 4) replay_add_kernel<4><<<grid, block, 0, s>>>(*ring, ring_ctl, obs, next_obs, act, rew, done, timeout);
-    else replay_add_kernel<8><<<grid, block, 0, s>>>(*ring, ring_ctl, obs, next_obs, act, rew, done, timeout);
+    const int layout = layout_of(ring->obs_dim, ring->act_dim);
+    if (layout == 0) replay_add_kernel<0><<<grid, block, 0, s>>>(*ring, ring_ctl, obs, next_obs, act, rew, done, timeout);
+    else if (layout == 1) replay_add_kernel<1><<<grid, block, 0, s>>>(*ring, ring_ctl, obs, next_obs, act, rew, done, timeout);
+    else replay_add_kernel<2><<<grid, block, 0, s>>>(*ring, ring_ctl, obs, next_obs, act, rew, done, timeout);
     return (int)hipGetLastError();
 }
 
@@ -421,15 +503,20 @@ extern "C" int cstr_collect_step_f32(const cstr_coef_t *coef, int integrator, co
     if ((reset_obs == nullptr) == (pcg_state == nullptr)) return CSTR_E_BADARG;  // exactly one reset source
     if ((ep_return == nullptr) != (ep_stats == nullptr)) return CSTR_E_BADARG;
     if (integrator != CSTR_INTEGRATOR_EULER && integrator != CSTR_INTEGRATOR_RK4) return CSTR_E_UNSUPPORTED;
-    if (!aligned16(env_obs) || !aligned8(policy_out) || (noise && !aligned8(noise)) || (reset_obs && !aligned16(reset_obs)) ||
-        (pcg_state && !aligned16(pcg_state)))
-        return CSTR_E_BADARG;
-    if (!(act_high[0] > act_low[0]) || !(act_high[1] > act_low[1])) return CSTR_E_BADARG;
+    const int A = ring->act_dim;
+    const bool a_ok = A == 4 ? (aligned16(policy_out) && (!noise || aligned16(noise))) : (aligned8(policy_out) && (!noise || aligned8(noise)));
+    if (!aligned16(env_obs) || !a_ok || (reset_obs && !aligned16(reset_obs)) || (pcg_state && !aligned16(pcg_state))) return CSTR_E_BADARG;
+    ActBounds ab;
+    for (int j = 0; j < 4; ++j) {
+        ab.lo[j] = j < A ? act_low[j] : -1.0f;
+        ab.hi[j] = j < A ? act_high[j] : 1.0f;
+        if (!(ab.hi[j] > ab.lo[j])) return CSTR_E_BADARG;
+    }
     hipStream_t s = (hipStream_t)stream;
-    const int obs_dim = ring->obs_dim;
+    const int layout = layout_of(ring->obs_dim, A);
     int block, grid;
     env_launch_shape(ring->n_envs, block, grid);
-    DISPATCH_D_INTEG(collect_step_kernel, *coef, *ring, ring_ctl, env_obs, step_count, policy_out, squashed, act_low[0],
-                     act_high[0], act_low[1], act_high[1], noise, reset_obs, pcg_state, reward_out, done_out, ep_return, ep_stats);
+    DISPATCH_L_INTEG(collect_step_kernel, *coef, *ring, ring_ctl, env_obs, step_count, policy_out, squashed, ab, noise, reset_obs,
+                     pcg_state, reward_out, done_out, ep_return, ep_stats);
     return (int)hipGetLastError();
 }

@@ -109,7 +109,7 @@ __device__ int mt_randint_fill(SampleShared &sh, int pos, uint32_t rng, int coun
     return pos;
 }
 
-template <int D>
+template <int D, int A>
 __global__ __launch_bounds__(TPB) void replay_sample_kernel(const cstr_ring_t ring, const int64_t *__restrict__ ring_ctl,
                                                             uint32_t *__restrict__ mt_state, const int batch,
                                                             float *__restrict__ out_obs, float *__restrict__ out_act,
@@ -138,7 +138,6 @@ __global__ __launch_bounds__(TPB) void replay_sample_kernel(const cstr_ring_t ri
         const int64_t r = row_idx[b], e = env_idx[b], o = r * n + e;
         const float4 x0 = *reinterpret_cast<const float4 *>(ring.obs + o * D);
         const float4 y0 = *reinterpret_cast<const float4 *>(ring.next_obs + o * D);
-        const float2 a = *reinterpret_cast<const float2 *>(ring.act + o * 2);
         const float dn = ring.done[o], to = ring.timeout[o], rw = ring.rew[o];
         *reinterpret_cast<float4 *>(out_obs + (int64_t)b * D) = x0;
         *reinterpret_cast<float4 *>(out_next_obs + (int64_t)b * D) = y0;
@@ -146,7 +145,8 @@ __global__ __launch_bounds__(TPB) void replay_sample_kernel(const cstr_ring_t ri
             *reinterpret_cast<float4 *>(out_obs + (int64_t)b * D + 4) = *reinterpret_cast<const float4 *>(ring.obs + o * D + 4);
             *reinterpret_cast<float4 *>(out_next_obs + (int64_t)b * D + 4) = *reinterpret_cast<const float4 *>(ring.next_obs + o * D + 4);
         }
-        *reinterpret_cast<float2 *>(out_act + (int64_t)b * 2) = a;
+        if (A == 2) *reinterpret_cast<float2 *>(out_act + (int64_t)b * 2) = *reinterpret_cast<const float2 *>(ring.act + o * 2);
+        else *reinterpret_cast<float4 *>(out_act + (int64_t)b * 4) = *reinterpret_cast<const float4 *>(ring.act + o * 4);
         out_done[b] = dn * (1.0f - to);  // buffers.py:322
         out_rew[b] = rw;
         if (out_row_idx) out_row_idx[b] = r;
@@ -183,19 +183,20 @@ extern "C" int cstr_replay_sample_mt19937_f32(const cstr_ring_t *ring, const int
 {
     if (!ring || !ring->obs || !ring->next_obs || !ring->act || !ring->rew || !ring->done || !ring->timeout) return CSTR_E_BADARG;
     if (!ring_ctl || !mt_state || !out_obs || !out_act || !out_next_obs || !out_done || !out_rew || batch <= 0) return CSTR_E_BADARG;
-    if ((ring->obs_dim != 4 && ring->obs_dim != 8) || ring->act_dim != 2) return CSTR_E_UNSUPPORTED;
+    const bool lay_ok = (ring->obs_dim == 4 && ring->act_dim == 2) || (ring->obs_dim == 8 && (ring->act_dim == 2 || ring->act_dim == 4));
+    if (!lay_ok) return CSTR_E_UNSUPPORTED;
     // 32-bit masked-rejection path only (numpy switches to 64-bit words above 2^32 - 1; rng == 2^32 - 1 is unmasked)
     if (batch > CSTR_MAX_SAMPLE_BATCH || ring->rows >= 0xFFFFFFFFLL || ring->n_envs >= 0xFFFFFFFFLL) return CSTR_E_UNSUPPORTED;
-    if (!aligned16(ring->obs) || !aligned16(ring->next_obs) || !aligned8(ring->act) || !aligned16(out_obs) ||
-        !aligned16(out_next_obs) || !aligned8(out_act))
+    const bool a4 = ring->act_dim == 4;
+    if (!aligned16(ring->obs) || !aligned16(ring->next_obs) || !(a4 ? aligned16(ring->act) : aligned8(ring->act)) || !aligned16(out_obs) ||
+        !aligned16(out_next_obs) || !(a4 ? aligned16(out_act) : aligned8(out_act)))
         return CSTR_E_BADARG;
     const size_t dyn = sizeof(int32_t) * 2 * (size_t)batch;
     hipStream_t s = (hipStream_t)stream;
-    if (ring->obs_dim == 4)
-        replay_sample_kernel<4><<<1, TPB, dyn, s>>>(*ring, ring_ctl, mt_state, (int)batch, out_obs, out_act, out_next_obs, out_done,
-                                                    out_rew, out_row_idx, out_env_idx);
-    else
-        replay_sample_kernel<8><<<1, TPB, dyn, s>>>(*ring, ring_ctl, mt_state, (int)batch, out_obs, out_act, out_next_obs, out_done,
-                                                    out_rew, out_row_idx, out_env_idx);
+#define SAMPLE_ARGS *ring, ring_ctl, mt_state, (int)batch, out_obs, out_act, out_next_obs, out_done, out_rew, out_row_idx, out_env_idx
+    if (ring->obs_dim == 4) replay_sample_kernel<4, 2><<<1, TPB, dyn, s>>>(SAMPLE_ARGS);
+    else if (!a4) replay_sample_kernel<8, 2><<<1, TPB, dyn, s>>>(SAMPLE_ARGS);
+    else replay_sample_kernel<8, 4><<<1, TPB, dyn, s>>>(SAMPLE_ARGS);
+#undef SAMPLE_ARGS
     return (int)hipGetLastError();
 }

@@ -49,12 +49,13 @@ def test_bad_arguments_are_rejected_on_the_host():
     lib = nv.lib()
     coef = nv.default_coef()
     null = C.c_void_p(None)
-    assert lib.cstr_vec_step_f32(C.byref(coef), 0, 4, null, null, null, null, null, null, null, null, null, C.c_int64(8), null) == -1
+    assert lib.cstr_vec_step_f32(C.byref(coef), 0, 4, 2, null, null, null, null, null, null, null, null, null, C.c_int64(8), null) == -1
     assert lib.cstr_polyak_f32(null, null, C.c_double(0.005), C.c_int64(4), null) == -1
     assert lib.cstr_td_target_min_f32(null, null, null, null, null, null, C.c_float(0.99), null, C.c_int64(4), null) == -1
     fake = C.c_void_p(0x1000)  # never dereferenced: argument checks fail first
-    assert lib.cstr_vec_step_f32(C.byref(coef), 0, 5, fake, fake, fake, fake, fake, fake, fake, fake, fake, C.c_int64(8), null) == -2
-    assert lib.cstr_vec_step_f32(C.byref(coef), 7, 4, fake, fake, fake, fake, fake, fake, fake, fake, fake, C.c_int64(8), null) == -2
+    assert lib.cstr_vec_step_f32(C.byref(coef), 0, 5, 2, fake, fake, fake, fake, fake, fake, fake, fake, fake, C.c_int64(8), null) == -2
+    assert lib.cstr_vec_step_f32(C.byref(coef), 0, 4, 4, fake, fake, fake, fake, fake, fake, fake, fake, fake, C.c_int64(8), null) == -2  # (4,4) is not a layout
+    assert lib.cstr_vec_step_f32(C.byref(coef), 7, 4, 2, fake, fake, fake, fake, fake, fake, fake, fake, fake, C.c_int64(8), null) == -2
     ring = nv.Ring(0x1000, 0x1000, 0x1000, 0x1000, 0x1000, 0x1000, 4, 4, 4, 3)  # act_dim 3
     assert lib.cstr_replay_sample_mt19937_f32(C.byref(ring), fake, fake, C.c_int64(8), fake, fake, fake, fake, fake, null, null, null) == -2
     ring = nv.Ring(0x1000, 0x1000, 0x1000, 0x1000, 0x1000, 0x1000, 4, 4, 4, 2)

@@ -404,3 +404,86 @@ def test_ops_reject_bad_shapes(ops):
     with pytest.raises(ValueError):
         ops.replay_sample(ring, th.zeros(625, dtype=th.int32, device="cuda"), 1 << 15,
                           *(th.zeros(1 << 15, k, device="cuda") for k in (4, 2, 4, 1, 1)))
+
+
+# ------------------------------------------------------------------------- twin-train layout (8 obs / 4 act)
+def _twin_expected(obs8, act4, steps, reset8, integ="euler"):
+    """Two independent reference trains per env, composed from the single-train oracle."""
+    A = orc.vec_step(obs8[:, :4], act4[:, :2], steps, reset8[:, :4], integrator=integ)
+    B = orc.vec_step(obs8[:, 4:], act4[:, 2:], steps, reset8[:, 4:], integrator=integ)
+    nxt = np.concatenate([A[0], B[0]], 1)
+    done = np.maximum(A[3], B[3])
+    after = np.where(done[:, None] > 0, reset8, nxt)
+    return nxt, after, (A[2] + B[2]).astype(np.float32), done, done.copy(), np.where(done > 0, 0, steps + 1).astype(np.int32)
+
+
+def test_twin_layout_vec_step_collect_and_sampler(ops):
+    from core import _native as nv
+
+    rng = np.random.default_rng(21)
+    N, R, T = 333, 3, 7
+    obs = rng.uniform(-1, 1, (N, 8)).astype(np.float32)
+    steps = rng.integers(392, 400, N).astype(np.int32)
+    coef = nv.default_coef()
+    # unfused VecEnv.step
+    act = rng.uniform(-1.3, 1.3, (N, 4)).astype(np.float32)
+    reset = rng.uniform(-1, 1, (N, 8)).astype(np.float32)
+    o, a, st, ro = dev(obs), dev(act), dev(steps, th.int32), dev(reset)
+    nxt, after = th.empty_like(o), th.empty_like(o)
+    rew, done, tout = (th.empty(N, device="cuda") for _ in range(3))
+    ops.vec_step(coef, "euler", o, a, st, ro, nxt, after, rew, done, tout)
+    e = _twin_expected(obs, act, steps, reset)
+    assert rel_err(nxt.cpu().numpy(), e[0], OBS_FLOOR) < 5e-7 and rel_err(after.cpu().numpy(), e[1], OBS_FLOOR) < 5e-7
+    assert rel_err(rew.cpu().numpy(), e[2], 1.0) < 2e-6
+    np.testing.assert_array_equal(done.cpu().numpy(), e[3])
+    np.testing.assert_array_equal(st.cpu().numpy(), e[5])
+    # fused collect into a (8, 4) ring, then the sampler gathers float4 actions
+    ring, oring = ops.DeviceRing(R, N, 8, 4, "cuda"), orc.ReplayRing(R, N, 8, 4)
+    env_obs, dsteps = dev(obs), dev(steps, th.int32)
+    low, high = -np.ones(4, np.float32), np.ones(4, np.float32)
+    cur, cst = obs.copy(), steps.copy()
+    for k in range(T):
+        pol = np.tanh(rng.normal(0, 1.5, (N, 4))).astype(np.float32)
+        reset = rng.uniform(-1, 1, (N, 8)).astype(np.float32)
+        mode = 1 if k % 2 else 3  # single-agent chain / multi-agent passthrough
+        ops.collect_step(coef, "euler", ring, env_obs, dsteps, dev(pol), mode, low, high, reset_obs=dev(reset))
+        if mode == 1:
+            buf_a, env_a = orc.action_scale_chain(pol, True, low, high)
+        else:
+            buf_a = env_a = (low + (np.float32(0.5) * (pol + np.float32(1.0)) * (high - low))).astype(np.float32)
+        e = _twin_expected(cur, env_a, cst, reset)
+        oring.add(cur, e[0], buf_a, e[2], e[3], e[4])
+        assert rel_err(env_obs.cpu().numpy(), e[1], OBS_FLOOR) < 5e-7
+        np.testing.assert_array_equal(dsteps.cpu().numpy(), e[5])
+        cur, cst = env_obs.cpu().numpy().copy(), e[5]
+    np.testing.assert_array_equal(ring.actions.cpu().numpy(), oring.actions)
+    np.testing.assert_array_equal(ring.observations.cpu().numpy(), oring.observations)
+    np.testing.assert_array_equal(ring.dones.cpu().numpy(), oring.dones)
+    assert rel_err(ring.next_observations.cpu().numpy(), oring.next_observations, OBS_FLOOR) < 5e-7
+    assert oring.dones.sum() > 0
+    # make the oracle ring bit-identical to the device ring, then sample both
+    oring.next_observations[...] = ring.next_observations.cpu().numpy()
+    oring.rewards[...] = ring.rewards.cpu().numpy()
+    mt, omt = th.zeros(625, dtype=th.int32, device="cuda"), orc.MT19937(77)
+    ops.mt19937_seed(mt, 77)
+    B = 200
+    outs = [th.empty(B, 8, device="cuda"), th.empty(B, 4, device="cuda"), th.empty(B, 8, device="cuda"),
+            th.empty(B, 1, device="cuda"), th.empty(B, 1, device="cuda")]
+    for _ in range(3):
+        ops.replay_sample(ring, mt, B, *outs)
+        exp, _ = oring.sample(omt, B)
+        for t, x in zip(outs, exp):
+            np.testing.assert_array_equal(t.cpu().numpy(), x)
+
+
+def test_twin_layout_reset_draw(ops):
+    """Train B continues the env's PCG64 stream after train A: two consecutive generate_initial_state draws."""
+    n = 64
+    st = orc.pcg64_states_from_seeds(np.arange(n))
+    dst = dev(st.view(np.uint64).reshape(n, 4).view(np.int64))
+    out = th.zeros(n, 8, device="cuda")
+    ops.reset_draw(dst, None, out, act_dim=4)
+    a = orc.reset_draw(st)
+    b = orc.reset_draw(st)
+    np.testing.assert_array_equal(out.cpu().numpy(), np.concatenate([a, b], 1))
+    np.testing.assert_array_equal(dst.cpu().numpy().view(np.uint64).reshape(-1), st.view(np.uint64).reshape(-1))

@@ -390,3 +390,25 @@ def test_td3_hipgraph_two_phase_capture_equals_eager():
     np.testing.assert_array_equal(e["ctl"], g["ctl"])
     for k in ("actor", "critic", "at", "obs"):
         np.testing.assert_allclose(e[k], g[k], rtol=2e-3, atol=2e-4, err_msg=k)
+
+
+def test_maddpg_four_agents_on_twin_train_env():
+    """BASELINE config 5's shape: 4 agents (one per reactor) on the 8-obs / 4-act twin-train env, 1024 envs."""
+    from core.common.vec_env import CSTRVecEnv
+    from core.maddpg import MADDPG
+    from core.sac import SAC
+
+    env = CSTRVecEnv(1024, obs_dim=8, twin=True)
+    assert env.observation_space.shape == (8,) and env.action_space.shape == (4,)
+    model = MADDPG(4, "MlpPolicy", env, [[0, 1], [2, 3], [4, 5], [6, 7]], [[0], [1], [2], [3]], learning_rate_list=[1e-3] * 4, seed=0,
+                   policy_kwargs=dict(net_arch=[[64, 64]] * 4))
+    model.learn(1024 * 12)
+    assert model._n_updates == 12 and model.replay_buffer.actions.shape == (976, 1024, 4)
+    assert all(opt.step_count == 12 for opt in model.critic.optimizer_list) and all(opt.step_count == 6 for opt in model.actor.optimizer_list)
+    for p in model.policy.parameters():
+        assert th.isfinite(p).all()
+    # SAC on the same env exercises the (8, 4) single-agent chain + graph capture
+    m2 = SAC("MlpPolicy", CSTRVecEnv(256, obs_dim=8, twin=True), seed=0, policy_kwargs=dict(net_arch=[64, 64]))
+    m2.enable_graph_capture()
+    m2.learn(256 * 10)
+    assert m2._n_updates == 10 and m2._graph and th.isfinite(m2.policy.actor_arena.flat).all()
