@@ -124,14 +124,39 @@ class FlatAdam:
         return int(self.ctl[0])
 
     def state_dict(self) -> dict:
-        return dict(exp_avg=self.exp_avg.clone(), exp_avg_sq=self.exp_avg_sq.clone(), step=int(self.ctl[0]),
-                    lr=float(self.param_groups[0]["lr"]))
+        """torch.optim.Adam's state_dict layout (per-parameter `step` / `exp_avg` / `exp_avg_sq`), so checkpoints are
+        interchangeable with the reference's `actor.optimizer.pth` etc. (core/common/base_class.py:827-840)."""
+        step = float(self.ctl[0])
+        state = {}
+        for i, (p, o) in enumerate(zip(self.arena.params, self.arena.offsets)):
+            sl = slice(o, o + p.numel())
+            state[i] = {"step": th.tensor(step), "exp_avg": self.exp_avg[sl].view(p.shape).clone(),
+                        "exp_avg_sq": self.exp_avg_sq[sl].view(p.shape).clone()}
+        g = self.param_groups[0]
+        group = {"lr": float(g["lr"]), "betas": tuple(g["betas"]), "eps": g["eps"], "weight_decay": 0, "amsgrad": False,
+                 "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
+                 "params": list(range(len(self.arena.params)))}
+        return {"state": state if step > 0 else {}, "param_groups": [group]}
 
     def load_state_dict(self, sd: dict) -> None:
-        self.exp_avg.copy_(sd["exp_avg"])
-        self.exp_avg_sq.copy_(sd["exp_avg_sq"])
-        self.ctl[0] = int(sd["step"])
-        self.param_groups[0]["lr"] = float(sd["lr"])
+        state = sd.get("state", {})
+        self.exp_avg.zero_()
+        self.exp_avg_sq.zero_()
+        steps = set()
+        for i, (p, o) in enumerate(zip(self.arena.params, self.arena.offsets)):
+            st = state.get(i, state.get(str(i)))
+            if st is None:
+                continue
+            sl = slice(o, o + p.numel())
+            self.exp_avg[sl].view(p.shape).copy_(st["exp_avg"])
+            self.exp_avg_sq[sl].view(p.shape).copy_(st["exp_avg_sq"])
+            steps.add(int(float(st["step"])))
+        if len(steps) > 1:
+            raise ValueError(f"FlatAdam needs one common step count, checkpoint has {sorted(steps)}")
+        self.ctl[0] = steps.pop() if steps else 0
+        groups = sd.get("param_groups") or [{}]
+        if "lr" in groups[0]:
+            self.param_groups[0]["lr"] = float(groups[0]["lr"])
         self.sync_lr()
 
 

@@ -1,6 +1,6 @@
 """`BaseAlgorithm`: constructor contract, env wrapping, seeding, lr schedule, learn-time bookkeeping
-(reference: core/common/base_class.py:69-889; only what the off-policy CSTR path touches).
-save/load (zip checkpoints) are a "next" row and raise NotImplementedError for now."""
+(reference: core/common/base_class.py:69-889; only what the off-policy CSTR path touches), and save/load in the
+reference's zip layout (core/common/save_util.py)."""
 import time
 from collections import deque
 from typing import Any, Optional, Union
@@ -191,24 +191,105 @@ class BaseAlgorithm:
     def train(self, *args: Any, **kwargs: Any) -> None:
         raise NotImplementedError
 
-    def get_parameters(self) -> dict:
-        """reference: base_class.py:827-840 (state dicts of the policy and optimisers)"""
-        return {"policy": {k: v.detach().clone() for k, v in self.policy.state_dict().items()}}
+    # ---- checkpoints (reference: base_class.py:666-888, save_util.py:294-466) --------------------------------------
+    _SAVE_HYPERS = ("learning_rate", "buffer_size", "learning_starts", "batch_size", "tau", "gamma", "gradient_steps", "seed",
+                    "policy_kwargs", "num_timesteps", "_n_updates", "_episode_num", "n_envs", "_total_timesteps",
+                    "_num_timesteps_at_start", "_current_progress_remaining", "verbose")
 
-    def set_parameters(self, load_path_or_dict: dict, exact_match: bool = True, device="auto") -> None:
-        if not isinstance(load_path_or_dict, dict):
-            raise NotImplementedError("zip checkpoints are a 'next' row (SURVEY 8f-2); pass a dict of state dicts")
-        sd = load_path_or_dict["policy"]
-        with th.no_grad():  # copy INTO the arena views (load_state_dict would keep them too, but be explicit)
-            own = self.policy.state_dict()
-            if exact_match and set(own) != set(sd):
-                raise ValueError(f"Names of parameters do not match agents' parameters: expected {sorted(own)}, got {sorted(sd)}")
-            for k, v in sd.items():
-                own[k].copy_(th.as_tensor(v).to(own[k].device))
+    def _get_torch_save_params(self) -> tuple:
+        """(state-dict attribute names, plain tensor attribute names) -- overridden per algorithm like the reference."""
+        return ["policy"], []
+
+    def _extra_save_data(self) -> dict:
+        return {}
+
+    def _recursive_getattr(self, name: str):
+        obj = self
+        for part in name.split("."):
+            obj = getattr(obj, part)
+        return obj
+
+    def get_parameters(self) -> dict:
+        """reference: base_class.py:827-840 -- {name: state_dict} for the policy and every optimiser"""
+        names, _ = self._get_torch_save_params()
+        return {name: self._recursive_getattr(name).state_dict() for name in names}
+
+    def set_parameters(self, load_path_or_dict, exact_match: bool = True, device="auto") -> None:
+        """reference: base_class.py:597-664. Values are copied INTO the arena views (module identity is preserved)."""
+        if isinstance(load_path_or_dict, dict):
+            params = load_path_or_dict
+        else:
+            from core.common.save_util import load_from_zip_file
+
+            _, params, _ = load_from_zip_file(load_path_or_dict, device="cpu")
+        names, _ = self._get_torch_save_params()
+        updated = set()
+        for name in params:
+            if name not in names:
+                raise ValueError(f"Key {name} is an invalid object name.")
+            target = self._recursive_getattr(name)
+            if name == "policy" or isinstance(target, th.nn.Module):
+                own = target.state_dict()
+                if exact_match and set(own) != set(params[name]):
+                    raise ValueError(f"Names of parameters do not match agents' parameters: expected {sorted(own)}, got {sorted(params[name])}")
+                with th.no_grad():
+                    for k, v in params[name].items():
+                        if k in own:
+                            own[k].copy_(th.as_tensor(v).to(own[k].device))
+            else:
+                target.load_state_dict(params[name])
+            updated.add(name)
+        if exact_match and updated != set(names):
+            raise ValueError(f"Names of parameters do not match agents' parameters: expected {names}, got {sorted(updated)}")
 
     def save(self, path, exclude=None, include=None) -> None:
-        raise NotImplementedError("SB3 zip checkpoints are a 'next' row (SURVEY 8f-2)")
+        """reference: base_class.py:842-888. Writes the same archive members; `data` holds the JSON-able constructor
+        arguments and counters (nothing is pickled)."""
+        from core import __version__
+        from core.common.save_util import save_to_zip_file
+
+        data = {k: getattr(self, k) for k in self._SAVE_HYPERS if hasattr(self, k)}
+        tf = getattr(self, "train_freq", None)
+        if tf is not None and hasattr(tf, "unit"):
+            data["train_freq"] = [tf.frequency, tf.unit.value]
+        data["algo"] = type(self).__name__
+        for nm, sp in (("observation_space", self.observation_space), ("action_space", self.action_space)):
+            data[nm] = {"low": np.asarray(sp.low).tolist(), "high": np.asarray(sp.high).tolist(), "shape": list(sp.shape), "dtype": str(sp.dtype)}
+        data.update(self._extra_save_data())
+        for k in (exclude or []):
+            data.pop(k, None)
+        _, var_names = self._get_torch_save_params()
+        variables = {n: self._recursive_getattr(n).detach().clone() for n in var_names} if var_names else None
+        save_to_zip_file(path, data=data, params=self.get_parameters(), pytorch_variables=variables, version=__version__)
 
     @classmethod
-    def load(cls, path, env=None, device="auto", **kwargs):
-        raise NotImplementedError("SB3 zip checkpoints are a 'next' row (SURVEY 8f-2)")
+    def load(cls, path, env=None, device="auto", custom_objects=None, print_system_info: bool = False, force_reset: bool = True, **kwargs):
+        """reference: base_class.py:666-825. Works for archives written by this stack and for archives written by the
+        reference (only `weights_only` tensors and plain JSON are read; `env` must then be passed)."""
+        from core.common.save_util import load_from_zip_file
+
+        data, params, variables = load_from_zip_file(path, device="cpu")
+        if env is None:
+            raise ValueError("load(): pass `env` (environments are not stored in the archive)")
+        ctor = {k: data[k] for k in cls._ctor_keys() if k in data}
+        if "train_freq" in data and isinstance(data["train_freq"], list):
+            ctor["train_freq"] = (int(data["train_freq"][0]), str(data["train_freq"][1]))
+        ctor.update(kwargs)
+        model = cls._construct_for_load(env, device, ctor)
+        model.set_parameters(params, exact_match=True)
+        for name, value in (variables or {}).items():
+            tgt = model._recursive_getattr(name)
+            with th.no_grad():
+                tgt.copy_(th.as_tensor(value).to(tgt.device).reshape(tgt.shape))
+        for k in ("num_timesteps", "_n_updates", "_episode_num", "_total_timesteps", "_num_timesteps_at_start"):
+            if k in data:
+                setattr(model, k, data[k])
+        return model
+
+    @classmethod
+    def _ctor_keys(cls) -> tuple:
+        return ("learning_rate", "buffer_size", "learning_starts", "batch_size", "tau", "gamma", "gradient_steps", "seed", "policy_kwargs")
+
+    @classmethod
+    def _construct_for_load(cls, env, device, ctor: dict):
+        return cls("MlpPolicy", env, device=device, **ctor)

@@ -249,6 +249,20 @@ class SAC(OffPolicyAlgorithm):
                                            critic_loss=critic_loss.detach().clone(), actor_loss=actor_loss.detach().clone(),
                                            ent_coef=ent_coef.detach().clone(), log_prob=log_prob.detach().clone())
 
+    def _get_torch_save_params(self) -> tuple:
+        """reference: sac.py:319-326"""
+        state_dicts = ["policy", "actor.optimizer", "critic.optimizer"]
+        if self.ent_coef_optimizer is not None:
+            return state_dicts + ["ent_coef_optimizer"], ["log_ent_coef"]
+        return state_dicts, ["ent_coef_tensor"]
+
+    def _extra_save_data(self) -> dict:
+        return dict(ent_coef=self.ent_coef, target_update_interval=self.target_update_interval, target_entropy=self.target_entropy)
+
+    @classmethod
+    def _ctor_keys(cls) -> tuple:
+        return super()._ctor_keys() + ("ent_coef", "target_update_interval", "target_entropy")
+
     def learn(self, total_timesteps: int, callback=None, log_interval: int = 4, tb_log_name: str = "SAC",
               reset_num_timesteps: bool = True, progress_bar: bool = False):
         return super().learn(total_timesteps=total_timesteps, callback=callback, log_interval=log_interval,

@@ -180,6 +180,17 @@ class TD3(OffPolicyAlgorithm):
                                            critic_loss=self._loss_now["critic"].clone(),
                                            actor_loss=self._loss_now["actor"].clone() if actor_done else None)
 
+    def _get_torch_save_params(self) -> tuple:
+        """reference: td3.py:234-240"""
+        return ["policy", "actor.optimizer", "critic.optimizer"], []
+
+    def _extra_save_data(self) -> dict:
+        return dict(policy_delay=self.policy_delay, target_policy_noise=self.target_policy_noise, target_noise_clip=self.target_noise_clip)
+
+    @classmethod
+    def _ctor_keys(cls) -> tuple:
+        return super()._ctor_keys() + ("policy_delay", "target_policy_noise", "target_noise_clip")
+
     def learn(self, total_timesteps: int, callback=None, log_interval: int = 4, tb_log_name: str = "TD3",
               reset_num_timesteps: bool = True, progress_bar: bool = False):
         return super().learn(total_timesteps=total_timesteps, callback=callback, log_interval=log_interval,
@@ -188,6 +199,10 @@ class TD3(OffPolicyAlgorithm):
 
 class DDPG(TD3):
     """reference: core/ddpg/ddpg.py:14-130 -- TD3 with policy_delay 1, one critic, no target smoothing."""
+
+    @classmethod
+    def _ctor_keys(cls) -> tuple:
+        return OffPolicyAlgorithm._ctor_keys()
 
     def __init__(self, policy, env, learning_rate=1e-3, buffer_size: int = 1_000_000, learning_starts: int = 100,
                  batch_size: int = 256, tau: float = 0.005, gamma: float = 0.99, train_freq: Union[int, tuple] = 1,

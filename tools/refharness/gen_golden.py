@@ -523,6 +523,35 @@ def gen_maddpg():
     save("maddpg_train_kat.npz", **out)
 
 
+def gen_checkpoint():
+    """A checkpoint WRITTEN BY THE REFERENCE (SAC.save, base_class.py:842-888) after two gradient steps, plus the
+    deterministic predictions of the saved model: the product's SAC.load must read it (weights_only tensors + JSON)."""
+    from core.common.logger import Logger
+    from core.sac.sac import SAC
+
+    N, D, A, B = 4, 4, 2, 64
+    model = SAC("MlpPolicy", _make_venv(N), seed=0, device="cpu", batch_size=B, buffer_size=64 * N, learning_starts=77, gamma=0.98,
+                policy_kwargs=dict(net_arch=[64, 64]))
+    model.set_logger(Logger(folder=None, output_formats=[]))
+    rng = np.random.default_rng(4242)
+    _fill_buffer(model, rng, 40, N, D, A)
+    np.random.seed(1)
+    th.manual_seed(1)
+    model.train(gradient_steps=2, batch_size=B)
+    model.num_timesteps = 1234
+    path = os.path.join(OUT, "sac_reference_checkpoint.zip")
+    model.save(path)
+    obs = rng.uniform(-1, 1, (16, D)).astype(np.float32)
+    pred, _ = model.predict(obs, deterministic=True)
+    with th.no_grad():
+        q1, q2 = model.critic(th.as_tensor(obs), th.as_tensor(pred))
+    opt = model.critic.optimizer.state_dict()
+    save("sac_reference_checkpoint_kat.npz", obs=obs, pred=pred, q1=q1.numpy(), q2=q2.numpy(), log_ent_coef=model.log_ent_coef.detach().numpy(),
+         critic_adam_step=np.float32(float(opt["state"][0]["step"])), critic_exp_avg0=opt["state"][0]["exp_avg"].numpy(),
+         n_updates=np.int64(model._n_updates))
+    print("wrote", path, os.path.getsize(path))
+
+
 def gen_init():
     """Initial weights of the reference policies for seed 0 (construction order = RNG order)."""
     from core.sac.sac import SAC
@@ -551,7 +580,7 @@ def gen_init():
 
 
 GENS = {"env": gen_env, "vecenv": gen_vecenv, "sampler": gen_sampler, "replay": gen_replay, "sac": gen_sac,
-        "td3": gen_td3, "init": gen_init, "maddpg": gen_maddpg}
+        "td3": gen_td3, "init": gen_init, "maddpg": gen_maddpg, "checkpoint": gen_checkpoint}
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
