@@ -27,6 +27,9 @@ def _chk(t: th.Tensor, name: str, shape, dtype) -> th.Tensor:
     return t
 
 
+LAYOUTS = ((4, 2), (8, 2), (8, 4))
+
+
 def _opt(t: Optional[th.Tensor], name, shape, dtype):
     return None if t is None else _chk(t, name, shape, dtype)
 
@@ -36,7 +39,7 @@ class DeviceRing:
     (core/common/buffers.py:212-234): [rows, n_envs, D] / [rows, n_envs, A] / [rows, n_envs]."""
 
     def __init__(self, rows: int, n_envs: int, obs_dim: int, act_dim: int, device):
-        if (obs_dim, act_dim) not in ((4, 2), (8, 2), (8, 4)):
+        if (obs_dim, act_dim) not in LAYOUTS:
             raise ValueError(f"DeviceRing supports (obs_dim, act_dim) in (4,2), (8,2), (8,4) (CSTR layouts), got {obs_dim}/{act_dim}")
         z = lambda *s: th.zeros(*s, dtype=th.float32, device=device)  # noqa: E731
         self.observations, self.next_observations = z(rows, n_envs, obs_dim), z(rows, n_envs, obs_dim)
@@ -52,6 +55,8 @@ class DeviceRing:
 def vec_step(coef, integrator: str, obs, act, step_count, reset_obs, next_obs, obs_after, reward, done, timeout):
     n, d = obs.shape
     a = act.shape[-1]
+    if (d, a) not in LAYOUTS:
+        raise ValueError(f"(obs_dim, act_dim) = {(d, a)} is not a CSTR layout {LAYOUTS}")
     _chk(obs, "obs", (n, d), th.float32), _chk(act, "act", (n, a), th.float32)
     _chk(step_count, "step_count", (n,), th.int32), _chk(reset_obs, "reset_obs", (n, d), th.float32)
     _chk(next_obs, "next_obs", (n, d), th.float32), _chk(obs_after, "obs_after", (n, d), th.float32)
@@ -64,6 +69,8 @@ def vec_step(coef, integrator: str, obs, act, step_count, reset_obs, next_obs, o
 
 def reset_draw(pcg_state, mask, obs_out, act_dim: int = 2):
     n, d = obs_out.shape
+    if (d, act_dim) not in LAYOUTS:
+        raise ValueError(f"(obs_dim, act_dim) = {(d, act_dim)} is not a CSTR layout {LAYOUTS}")
     _chk(pcg_state, "pcg_state", (n, nv.PCG_STATE_WORDS), th.int64), _chk(obs_out, "obs_out", (n, d), th.float32)
     _opt(mask, "mask", (n,), th.uint8)
     check(nv.lib().cstr_reset_draw_f32(ptr(pcg_state), ptr(mask), C.c_int(d), C.c_int(act_dim), ptr(obs_out), C.c_int64(n), stream_ptr()),
