@@ -6,7 +6,7 @@ import os
 with open(os.path.join(os.path.dirname(__file__), "version.txt")) as _fh:  # the reference forgot to ship this file
     __version__ = _fh.read().strip()
 
-__all__ = ["SAC", "TD3", "MADDPG", "DDPG", "__version__"]
+__all__ = ["SAC", "TD3", "MADDPG", "IDDPG", "DDPG", "__version__"]
 
 
 def __getattr__(name):
@@ -16,6 +16,9 @@ def __getattr__(name):
     if name in ("TD3", "DDPG"):
         import core.td3 as m
         return getattr(m, name)
+    if name == "IDDPG":
+        from core.iddpg import IDDPG
+        return IDDPG
     if name == "MADDPG":
         from core.maddpg import MADDPG
         return MADDPG

@@ -81,34 +81,40 @@ class Actor(_MultiAgentModule):
 
 
 class ContinuousCritic(_MultiAgentModule):
-    """Per-agent twin Q networks on the joint input (reference: maddpg/policies.py:131-272)."""
+    """Per-agent twin Q networks. `local=False` (MADDPG, reference: maddpg/policies.py:131-272): every agent's critic
+    sees the joint input cat(all features, all actions). `local=True` (IDDPG, reference: iddpg/policies.py:22-145): each
+    critic sees only its own agent's observation slice and action slice."""
 
     def __init__(self, n_agents, observation_space, action_space, observation_space_list, action_space_list, net_arch: List[list],
-                 activation_fn=nn.ReLU, n_critics: int = 2):
+                 activation_fn=nn.ReLU, n_critics: int = 2, local: bool = False):
         super().__init__(n_agents, observation_space, action_space, observation_space_list, action_space_list)
-        self.n_critics, self.net_arch = n_critics, net_arch
-        feat_sum = sum(int(np.prod(sp.shape)) for sp in self.observation_space_list)
-        act_sum = sum(get_action_dim(sp) for sp in self.action_space_list)
+        self.n_critics, self.net_arch, self.local = n_critics, net_arch, local
+        feat = [int(np.prod(sp.shape)) for sp in self.observation_space_list]
+        act = [get_action_dim(sp) for sp in self.action_space_list]
         self.q_networks_list: List[List[nn.Module]] = []
         for agent_id in range(n_agents):
+            width = feat[agent_id] + act[agent_id] if local else sum(feat) + sum(act)
             nets = []
             for idx in range(n_critics):
-                q_net = nn.Sequential(*create_mlp(feat_sum + act_sum, 1, net_arch[agent_id], activation_fn))
+                q_net = nn.Sequential(*create_mlp(width, 1, net_arch[agent_id], activation_fn))
                 self.add_module(f"agent{agent_id}_qf{idx}", q_net)
                 nets.append(q_net)
             self.q_networks_list.append(nets)
 
-    def _joint_input(self, obs: th.Tensor, actions: th.Tensor) -> th.Tensor:
+    def _input(self, agent_id: int, obs: th.Tensor, actions: th.Tensor) -> th.Tensor:
+        if self.local:
+            return th.cat((self._agent_obs_tensor_extract(agent_id, obs).float(), self._agent_action_tensor_extract(agent_id, actions)), dim=-1)
         feats = [self._agent_obs_tensor_extract(i, obs).float() for i in range(self.n_agents)]
         return th.cat([th.cat(feats, dim=-1), actions], dim=1)
 
     def forward(self, obs: th.Tensor, actions: th.Tensor) -> list:
-        x = self._joint_input(obs, actions)
-        return [tuple(q(x) for q in self.q_networks_list[i]) for i in range(self.n_agents)]
+        shared = None if self.local else self._input(0, obs, actions)
+        return [tuple(q(shared if shared is not None else self._input(i, obs, actions)) for q in self.q_networks_list[i])
+                for i in range(self.n_agents)]
 
     def q1_forward(self, obs: th.Tensor, actions: th.Tensor) -> list:
-        x = self._joint_input(obs, actions)
-        return [self.q_networks_list[i][0](x) for i in range(self.n_agents)]
+        shared = None if self.local else self._input(0, obs, actions)
+        return [self.q_networks_list[i][0](shared if shared is not None else self._input(i, obs, actions)) for i in range(self.n_agents)]
 
 
 class MADDPGPolicy(nn.Module):
@@ -120,6 +126,7 @@ class MADDPGPolicy(nn.Module):
                  features_extractor_kwargs_list=None, normalize_images: bool = True, optimizer_class_list=None,
                  optimizer_kwargs_list=None, n_critics: int = 2, share_features_extractor: bool = False):
         super().__init__()
+        local_critics = getattr(type(self), "local_critics", False)
         if features_extractor_class_list is not None or optimizer_class_list is not None:
             raise NotImplementedError("custom feature extractors / optimiser classes are out of scope (SURVEY 2)")
         if share_features_extractor:
@@ -139,8 +146,8 @@ class MADDPGPolicy(nn.Module):
         self.actor = Actor(*args, self.actor_arch, activation_fn)
         self.actor_target = Actor(*args, self.actor_arch, activation_fn)
         self.actor_target.load_state_dict(self.actor.state_dict())
-        self.critic = ContinuousCritic(*args, self.critic_arch, activation_fn, n_critics)
-        self.critic_target = ContinuousCritic(*args, self.critic_arch, activation_fn, n_critics)
+        self.critic = ContinuousCritic(*args, self.critic_arch, activation_fn, n_critics, local_critics)
+        self.critic_target = ContinuousCritic(*args, self.critic_arch, activation_fn, n_critics, local_critics)
         self.critic_target.load_state_dict(self.critic.state_dict())
         self.actor_target.set_training_mode(False)
         self.critic_target.set_training_mode(False)

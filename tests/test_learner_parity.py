@@ -294,13 +294,16 @@ def test_hipgraph_iteration_equals_eager():
         assert abs(e["alpha"] - g["alpha"]) < 1e-5
 
 
-def test_maddpg_train_teacher_forced(golden):
-    """MADDPG on the natural 2-agent split of the CSTR env vs the unmodified reference (core/maddpg/maddpg.py:117-191),
-    quirks Q1-Q4 included: per-agent Q-values / TD targets / losses at 1e-5, weights after 4 steps."""
+@pytest.mark.parametrize("algo", ["maddpg", "iddpg"])
+def test_maddpg_train_teacher_forced(golden, algo):
+    """MADDPG / IDDPG on the natural 2-agent split of the CSTR env vs the unmodified reference (core/maddpg/maddpg.py:117-191,
+    core/iddpg/iddpg.py), quirks Q1-Q4 included: per-agent Q-values / TD targets / losses at 1e-5, weights after 4 steps."""
     from core.common import legacy_rng
-    from core.maddpg import MADDPG
+    from core.iddpg import IDDPG
+    from core.maddpg import MADDPG as _MADDPG
 
-    g = golden("maddpg_train_kat.npz")
+    MADDPG = _MADDPG if algo == "maddpg" else IDDPG
+    g = golden(f"{algo}_train_kat.npz")
     gamma, tau, tpn, tnc, delay, lr, B, n_steps, n_agents = g["hyper"]
     B, n_steps, n_agents = int(B), int(n_steps), int(n_agents)
     model = MADDPG(n_agents, "MlpPolicy", _make_env(4), [[0, 1], [2, 3]], [[0], [1]], learning_rate_list=[lr, lr], seed=0,
@@ -412,3 +415,17 @@ def test_maddpg_four_agents_on_twin_train_env():
     m2.enable_graph_capture()
     m2.learn(256 * 10)
     assert m2._n_updates == 10 and m2._graph and th.isfinite(m2.policy.actor_arena.flat).all()
+
+
+def test_evaluate_policy_on_device_env():
+    from core.common.evaluation import evaluate_policy
+    from core.common.vec_env import CSTRVecEnv
+    from core.sac import SAC
+
+    env = CSTRVecEnv(8)
+    env.seed(0)
+    model = SAC("MlpPolicy", env, seed=0, policy_kwargs=dict(net_arch=[16, 16]))
+    rets, lens = evaluate_policy(model, env, n_eval_episodes=12, return_episode_rewards=True)
+    assert len(rets) == 12 and all(l == 400 for l in lens) and all(r < 0 for r in rets)
+    mean, std = evaluate_policy(model, env, n_eval_episodes=8)
+    assert mean < 0 and std >= 0

@@ -438,13 +438,21 @@ def gen_td3():
     save("td3_train_kat.npz", **out)
 
 
-def gen_maddpg():
-    """MADDPG on the natural 2-agent split of the CSTR env: agent 0 = reactor 1 ([C1,T1] -> F1), agent 1 = reactor 2."""
+def gen_iddpg():
+    gen_maddpg(algo="iddpg")
+
+
+def gen_maddpg(algo="maddpg"):
+    """MADDPG / IDDPG on the natural 2-agent split of the CSTR env: agent 0 = reactor 1 ([C1,T1] -> F1), agent 1 = reactor 2."""
     import torch.nn.functional as F_real
 
-    import core.maddpg.maddpg as mmod
     from core.common.logger import Logger
-    from core.maddpg.maddpg import MADDPG
+    if algo == "maddpg":
+        import core.maddpg.maddpg as mmod
+        from core.maddpg.maddpg import MADDPG
+    else:
+        import core.iddpg.iddpg as mmod
+        from core.iddpg.iddpg import IDDPG as MADDPG
 
     rec = _Recorder()
 
@@ -520,7 +528,7 @@ def gen_maddpg():
     act, buf_act = model._sample_action(0, NormalActionNoise(np.zeros(1), np.ones(1)), N)
     pred, _ = model.predict(obs, deterministic=False)
     out.update(sa_obs=obs, sa_action=act, sa_buffer_action=buf_act, sa_predict=pred)
-    save("maddpg_train_kat.npz", **out)
+    save(f"{algo}_train_kat.npz", **out)
 
 
 def gen_checkpoint():
@@ -580,7 +588,7 @@ def gen_init():
 
 
 GENS = {"env": gen_env, "vecenv": gen_vecenv, "sampler": gen_sampler, "replay": gen_replay, "sac": gen_sac,
-        "td3": gen_td3, "init": gen_init, "maddpg": gen_maddpg, "checkpoint": gen_checkpoint}
+        "td3": gen_td3, "init": gen_init, "maddpg": gen_maddpg, "iddpg": gen_iddpg, "checkpoint": gen_checkpoint}
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
