@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/cstr_rl_hip.h"
 
@@ -13,13 +14,17 @@ static inline bool aligned8(const void *p) { return (reinterpret_cast<uintptr_t>
 // there are waves. Large N streams: 256-thread workgroups, capped at 8 per CU, grid-stride for the rest.
 static inline void env_launch_shape(int64_t n, int &block, int &grid)
 {
-    if (n <= 65536) {
+    // tuning knobs for the A/B microbenchmarks (tools/microbench_collect.py); unset in production
+    static const int ov_block = getenv("CSTR_ENV_BLOCK") ? atoi(getenv("CSTR_ENV_BLOCK")) : 0;
+    static const int ov_cap = getenv("CSTR_ENV_GRID_CAP") ? atoi(getenv("CSTR_ENV_GRID_CAP")) : 0;
+    if (n <= 65536 && !ov_block) {
         block = 64;
         grid = (int)((n + 63) / 64);
     } else {
-        block = 256;
-        int64_t g = (n + 255) / 256;
-        grid = (int)(g < 2048 ? g : 2048);
+        block = ov_block ? ov_block : 256;
+        const int64_t cap = ov_cap ? ov_cap : 2048;
+        int64_t g = (n + block - 1) / block;
+        grid = (int)(g < cap ? g : cap);
     }
 }
 
