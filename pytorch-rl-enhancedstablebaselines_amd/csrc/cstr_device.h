@@ -21,8 +21,10 @@ static inline void env_launch_shape(int64_t n, int &block, int &grid)
         block = 64;
         grid = (int)((n + 63) / 64);
     } else {
-        block = ov_block ? ov_block : 256;
-        const int64_t cap = ov_cap ? ov_cap : 2048;
+        // streaming regime (A/B on MI355X, N = 2^22, profiles/r01_notes.md): 512-thread workgroups, <= 4096 of them
+        // (2 envs per lane) beat 256 x 2048 by ~5 %; > 4096 workgroups lose to the per-workgroup ticket atomics
+        block = ov_block ? ov_block : 512;
+        const int64_t cap = ov_cap ? ov_cap : 4096;
         int64_t g = (n + block - 1) / block;
         grid = (int)(g < cap ? g : cap);
     }

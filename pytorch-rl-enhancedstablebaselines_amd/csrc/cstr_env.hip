@@ -196,6 +196,35 @@ __device__ __forceinline__ void store_obs(float *p, int64_t i, const float o[2][
     if (L != 0) *reinterpret_cast<float4 *>(p + i * 8 + 4) = make_float4(o[1][0], o[1][1], o[1][2], o[1][3]);
 }
 
+// Ring rows are written once and not read again until some later sample(): streaming (non-temporal) stores keep them
+// from displacing the env state and the parameters in L2 / Infinity Cache. Built with -DCSTR_NT_STORES=1 for the A/B.
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+template <int L>
+__device__ __forceinline__ void store_ring_obs(float *p, int64_t i, const float o[2][4])
+{
+#if CSTR_NT_STORES
+    v4f a = {o[0][0], o[0][1], o[0][2], o[0][3]};
+    __builtin_nontemporal_store(a, reinterpret_cast<v4f *>(p + i * Lay<L>::D));
+    if (L != 0) {
+        v4f b = {o[1][0], o[1][1], o[1][2], o[1][3]};
+        __builtin_nontemporal_store(b, reinterpret_cast<v4f *>(p + i * 8 + 4));
+    }
+#else
+    store_obs<L>(p, i, o);
+#endif
+}
+
+__device__ __forceinline__ void store_ring_f32(float *p, int64_t i, float v)
+{
+#if CSTR_NT_STORES
+    __builtin_nontemporal_store(v, p + i);
+#else
+    p[i] = v;
+#endif
+}
+
 template <int L>
 __device__ __forceinline__ void copy_obs(float *dst, int64_t di, const float *src, int64_t si)
 {
@@ -344,12 +373,12 @@ __global__ void collect_step_kernel(const cstr_coef_t k, const cstr_ring_t ring,
         const bool d = trunc;
 
         // ring row: obs = _last_obs, next_obs = terminal observation (off_policy_algorithm.py:477-496)
-        store_obs<L>(ring.obs, row + i, o);
-        store_obs<L>(ring.next_obs, row + i, on);
+        store_ring_obs<L>(ring.obs, row + i, o);
+        store_ring_obs<L>(ring.next_obs, row + i, on);
         store_act<A>(ring.act, row + i, sa);
-        ring.rew[row + i] = r;
-        ring.done[row + i] = d ? 1.0f : 0.0f;
-        ring.timeout[row + i] = trunc ? 1.0f : 0.0f;
+        store_ring_f32(ring.rew, row + i, r);
+        store_ring_f32(ring.done, row + i, d ? 1.0f : 0.0f);
+        store_ring_f32(ring.timeout, row + i, trunc ? 1.0f : 0.0f);
         if (reward_out) reward_out[i] = r;
         if (done_out) done_out[i] = d ? 1.0f : 0.0f;
         if (ep_return) {  // Monitor semantics: return/length of the episode that ends here
