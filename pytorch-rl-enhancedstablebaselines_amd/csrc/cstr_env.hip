@@ -197,7 +197,8 @@ __device__ __forceinline__ void store_obs(float *p, int64_t i, const float o[2][
 }
 
 // Ring rows are written once and not read again until some later sample(): streaming (non-temporal) stores keep them
-// from displacing the env state and the parameters in L2 / Infinity Cache. Built with -DCSTR_NT_STORES=1 for the A/B.
+// from displacing the env state and the parameters in L2 / Infinity Cache. Measured on MI355X at N = 2^22 (A/B, 4 interleaved
+// rounds, profiles/r01_notes.md): 89.7 -> 70.3 us per launch, 4.86 -> 6.2 TB/s. -DCSTR_NT_STORES=0 restores plain stores.
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef float v2f __attribute__((ext_vector_type(2)));
 
@@ -213,6 +214,23 @@ __device__ __forceinline__ void store_ring_obs(float *p, int64_t i, const float 
     }
 #else
     store_obs<L>(p, i, o);
+#endif
+}
+
+template <int A>
+__device__ __forceinline__ void store_ring_act(float *p, int64_t i, const float a[4])
+{
+#if CSTR_NT_STORES
+    if (A == 2) {
+        v2f v = {a[0], a[1]};
+        __builtin_nontemporal_store(v, reinterpret_cast<v2f *>(p + 2 * i));
+    } else {
+        v4f v = {a[0], a[1], a[2], a[3]};
+        __builtin_nontemporal_store(v, reinterpret_cast<v4f *>(p + 4 * i));
+    }
+#else
+    if (A == 2) *reinterpret_cast<float2 *>(p + 2 * i) = make_float2(a[0], a[1]);
+    else *reinterpret_cast<float4 *>(p + 4 * i) = make_float4(a[0], a[1], a[2], a[3]);
 #endif
 }
 
@@ -375,7 +393,7 @@ __global__ void collect_step_kernel(const cstr_coef_t k, const cstr_ring_t ring,
         // ring row: obs = _last_obs, next_obs = terminal observation (off_policy_algorithm.py:477-496)
         store_ring_obs<L>(ring.obs, row + i, o);
         store_ring_obs<L>(ring.next_obs, row + i, on);
-        store_act<A>(ring.act, row + i, sa);
+        store_ring_act<A>(ring.act, row + i, sa);
         store_ring_f32(ring.rew, row + i, r);
         store_ring_f32(ring.done, row + i, d ? 1.0f : 0.0f);
         store_ring_f32(ring.timeout, row + i, trunc ? 1.0f : 0.0f);
