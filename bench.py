@@ -149,6 +149,15 @@ def other_kernels(model, batch):
     lr = th.tensor([3e-4], dtype=th.float64, device=p.device)
     us = event_time_us(lambda: hip_ops.adam(p, g, m, v, ctl, lr), 200, stream)
     out["adam_kernel"] = dict(launch_us=round(us, 3), n_params=n, gbs=round(28 * n / us / 1e3, 2))
+    # the same two kernels in their bandwidth-bound regime (2^25 parameters: 403 MB / 940 MB of traffic per launch)
+    nbig = 1 << 25
+    pb, tb = th.randn(nbig, device=p.device), th.randn(nbig, device=p.device)
+    us = event_time_us(lambda: hip_ops.polyak(pb, tb, 0.005), 20, stream)
+    out["polyak_kernel_stream"] = dict(launch_us=round(us, 2), n_params=nbig, gbs=round(12 * nbig / us / 1e3, 1), frac=round(12 * nbig / us / 1e3 / HBM_PEAK_GBS, 4))
+    mb, vb = th.zeros(nbig, device=p.device), th.zeros(nbig, device=p.device)
+    us = event_time_us(lambda: hip_ops.adam(pb, tb, mb, vb, ctl, lr), 20, stream)
+    out["adam_kernel_stream"] = dict(launch_us=round(us, 2), n_params=nbig, gbs=round(28 * nbig / us / 1e3, 1), frac=round(28 * nbig / us / 1e3 / HBM_PEAK_GBS, 4))
+    del pb, tb, mb, vb
     rb = model.replay_buffer
     b = rb.alloc_batch(batch)
     mt = th.zeros(625, dtype=th.int32, device=p.device)
