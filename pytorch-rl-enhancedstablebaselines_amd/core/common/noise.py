@@ -60,3 +60,28 @@ class VectorizedActionNoise(ActionNoise):
 
     def __call__(self) -> np.ndarray:
         return np.stack([noise() for noise in self.noises])
+
+
+class DeviceNormalActionNoise(ActionNoise):
+    """Gaussian exploration noise drawn on the GPU for all envs at once: N(mean, sigma) of shape [n_envs, action_dim],
+    graph-capturable. What `VectorizedActionNoise(NormalActionNoise(...), n_envs)` (reference: noise.py:29-45, :108-174)
+    computes, but from torch's device generator instead of n_envs sequential `np.random.normal` calls on the legacy
+    global stream -- statistically identical, NOT bit-identical."""
+
+    def __init__(self, mean, sigma, n_envs: int, device):
+        import torch as th
+
+        self._mu = th.as_tensor(np.asarray(mean, np.float32), device=device).reshape(1, -1)
+        self._sigma = th.as_tensor(np.asarray(sigma, np.float32), device=device).reshape(1, -1)
+        self.n_envs, self.device = n_envs, device
+
+    def __call__(self):
+        import torch as th
+
+        return self._mu + self._sigma * th.randn(self.n_envs, self._mu.shape[1], device=self.device)
+
+    def reset(self, indices: Optional[Iterable[int]] = None) -> None:
+        pass  # memoryless
+
+    def __repr__(self) -> str:
+        return f"DeviceNormalActionNoise(mu={self._mu.flatten().tolist()}, sigma={self._sigma.flatten().tolist()}, n_envs={self.n_envs})"

@@ -108,9 +108,13 @@ class OffPolicyAlgorithm(BaseAlgorithm):
 
     # ---- learn ----------------------------------------------------------------------------------------------------
     def _setup_learn(self, total_timesteps, callback=None, reset_num_timesteps=True, tb_log_name="run", progress_bar=False):
-        if self.action_noise is not None and self.env.num_envs > 1 and not hasattr(self.action_noise, "noises"):
-            from core.common.noise import VectorizedActionNoise
+        from core.common.noise import DeviceNormalActionNoise, NormalActionNoise, VectorizedActionNoise
 
+        if isinstance(self.action_noise, NormalActionNoise) and self._fast_path():
+            # memoryless Gaussian noise: one device draw for all envs instead of n_envs host draws per vec-step
+            self.action_noise = DeviceNormalActionNoise(self.action_noise._mu, self.action_noise._sigma, self.env.num_envs, self.device)
+        elif self.action_noise is not None and self.env.num_envs > 1 and not hasattr(self.action_noise, "noises") \
+                and not isinstance(self.action_noise, DeviceNormalActionNoise):
             self.action_noise = VectorizedActionNoise(self.action_noise, self.env.num_envs)
         return super()._setup_learn(total_timesteps, callback, reset_num_timesteps, tb_log_name, progress_bar)
 
@@ -158,7 +162,10 @@ class OffPolicyAlgorithm(BaseAlgorithm):
         self._graph = None
 
     def _graph_eligible(self, callback: BaseCallback) -> bool:
-        return (self._fast_path() and getattr(callback, "is_noop", False) and self.action_noise is None
+        from core.common.noise import DeviceNormalActionNoise
+
+        return (self._fast_path() and getattr(callback, "is_noop", False)
+                and (self.action_noise is None or isinstance(self.action_noise, DeviceNormalActionNoise))
                 and self.train_freq == TrainFreq(1, TrainFrequencyUnit.STEP)
                 and self.gradient_steps >= 1 and self.num_timesteps >= self.learning_starts
                 and self.num_timesteps + self.n_envs > self.learning_starts and not getattr(self, "debug_capture", False))
@@ -167,8 +174,9 @@ class OffPolicyAlgorithm(BaseAlgorithm):
         env, rb = self.env, self.replay_buffer
         self.policy.set_training_mode(False)
         pol = self._policy_out_device(env.obs)
+        noise = None if self.action_noise is None else self.action_noise().contiguous()
         hip_ops.collect_step(env.coef, env.integrator, rb.ring, env.obs, env.step_count, pol, self._action_mode(False),
-                             self.action_space.low, self.action_space.high, pcg_state=env.pcg_state, reward_out=env._rew, done_out=env._done,
+                             self.action_space.low, self.action_space.high, noise=noise, pcg_state=env.pcg_state, reward_out=env._rew, done_out=env._done,
                              ep_return=self._ep_return, ep_stats=self._ep_stats)
         self.policy.set_training_mode(True)
         self._train_device_only(self.gradient_steps, self.batch_size)

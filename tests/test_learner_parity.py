@@ -429,3 +429,20 @@ def test_evaluate_policy_on_device_env():
     assert len(rets) == 12 and all(l == 400 for l in lens) and all(r < 0 for r in rets)
     mean, std = evaluate_policy(model, env, n_eval_episodes=8)
     assert mean < 0 and std >= 0
+
+
+def test_td3_with_normal_action_noise_runs_on_device_and_in_graph():
+    """The reference's own CSTR recipe uses TD3 + NormalActionNoise(sigma=0.1) (experiments/basic_test/
+    TwoSeriesCSTR_TD3.py:31-36): the noise is drawn on the device, clipped into [-1, 1] by the collect kernel."""
+    from core.common.noise import DeviceNormalActionNoise, NormalActionNoise
+    from core.common.vec_env import CSTRVecEnv
+    from core.td3 import TD3
+
+    env = CSTRVecEnv(256)
+    model = TD3("MlpPolicy", env, seed=0, batch_size=64, buffer_size=256 * 16, action_noise=NormalActionNoise(np.zeros(2), 0.1 * np.ones(2)),
+                policy_kwargs=dict(net_arch=[32, 32]))
+    model.enable_graph_capture()
+    model.learn(256 * 14)
+    assert isinstance(model.action_noise, DeviceNormalActionNoise) and len(model._graph) == 2
+    a = model.replay_buffer.actions
+    assert float(a.abs().max()) <= 1.0 and float(a.std()) > 0.05 and model._n_updates == 14
