@@ -160,23 +160,26 @@ int cstr_adam_f32(float *param, const float *grad, float *exp_avg, float *exp_av
 #define CSTR_ACT_TANH 2
 
 /* nn.Linear's bias add + the activation create_mlp puts behind it (core/common/torch_layers.py:110-183), in place on
- * the GEMM output y[m][n]. */
-int cstr_bias_act_fwd_f32(float *y, const float *bias, int act, int64_t m, int64_t n, cstr_stream_t stream);
+ * the GEMM output. Grouped form for batched GEMMs (twin critics): y [groups][m][n], bias [groups][n]. */
+int cstr_bias_act_fwd_f32(float *y, const float *bias, int act, int64_t groups, int64_t m, int64_t n, cstr_stream_t stream);
 
 /* Backward of the same: gz = gy * act'(y) and gbias[n] = sum_m gz[m][n] (autograd's threshold/tanh backward + the
  * bias gradient's batch sum). gbias may be NULL; with act == NONE and gz == gy nothing is copied. */
-int cstr_bias_act_bwd_f32(const float *gy, const float *y, int act, float *gz, float *gbias, int64_t m, int64_t n,
+int cstr_bias_act_bwd_f32(const float *gy, const float *y, int act, float *gz, float *gbias, int64_t groups, int64_t m, int64_t n,
                           cstr_stream_t stream);
 
 /* SquashedDiagGaussianDistribution (core/common/distributions.py:161-260) with SAC's log_std clamp
  * (core/sac/policies.py:20-22, :162-164): u = mean + exp(clamp(log_std_raw, -20, 2)) * eps, action = tanh(u),
- * logp = sum_j Normal.log_prob(u_j) - sum_j log(1 - action_j^2 + 1e-6). logp may be NULL (acting only). */
+ * logp = sum_j Normal.log_prob(u_j) - sum_j log(1 - action_j^2 + 1e-6). logp may be NULL (acting only).
+ * in_stride = row stride of mean / log_std_raw: act_dim for separate tensors, 2*act_dim when they are the two halves of
+ * one merged mu|log_std GEMM output. */
 int cstr_squashed_gaussian_fwd_f32(const float *mean, const float *log_std_raw, const float *eps, float *action, float *logp,
-                                   int64_t batch, int act_dim, cstr_stream_t stream);
-/* Its analytic backward: (g_action [B][A] or NULL, g_logp [B] or NULL) -> g_mean, g_log_std_raw. */
+                                   int64_t batch, int act_dim, int in_stride, cstr_stream_t stream);
+/* Its analytic backward: (g_action rows of stride g_action_stride or NULL, g_logp [B] or NULL) -> g_mean, g_log_std_raw
+ * (rows of stride in_stride). */
 int cstr_squashed_gaussian_bwd_f32(const float *g_action, const float *g_logp, const float *action, const float *log_std_raw,
                                    const float *eps, float *g_mean, float *g_log_std_raw, int64_t batch, int act_dim,
-                                   cstr_stream_t stream);
+                                   int in_stride, int g_action_stride, cstr_stream_t stream);
 
 /* SAC entropy coefficient (core/sac/sac.py:230-243): ent_coef_out = exp(log_alpha); grad_out = d/dlog_alpha of
  * -mean(log_alpha * (logp + target_entropy)) = -mean(logp + target_entropy). loss_sum / ent_coef_sum (device scalars,

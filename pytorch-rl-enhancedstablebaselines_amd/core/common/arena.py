@@ -25,13 +25,37 @@ _ALIGN = 64  # floats (256 B)
 
 
 class ParamArena:
-    def __init__(self, params: Iterable[nn.Parameter], device, with_grad: bool = True):
-        self.params: List[nn.Parameter] = list(params)
+    """`groups`: lists of same-shaped parameters that must sit back to back WITHOUT padding (the group starts on a
+    256-B boundary), so that `stacked(i)` is a plain [G, *shape] view of the arena -- twin critics' layer-l weights as
+    one batched-GEMM operand, the actor's mu / log_std heads as one [2A, H] weight. Grouped parameters are placed at
+    their first member's position in the parameter order; the layout is a pure function of (shapes, groups), so a
+    network and its target network built with the same grouping have identical layouts (polyak is one launch)."""
+
+    def __init__(self, params: Iterable[nn.Parameter], device, with_grad: bool = True, groups: Optional[list] = None):
+        params = list(params)
+        groups = [list(g) for g in (groups or [])]
+        in_group = {id(p): gi for gi, g in enumerate(groups) for p in g}
+        for g in groups:
+            if len({tuple(p.shape) for p in g}) != 1:
+                raise ValueError("ParamArena group members must have the same shape")
+        ordered, placed = [], set()
+        for p in params:  # a group is emitted where its first member appears
+            if id(p) in placed:
+                continue
+            members = groups[in_group[id(p)]] if id(p) in in_group else [p]
+            ordered.append(members)
+            placed.update(id(q) for q in members)
+        self.params: List[nn.Parameter] = [q for members in ordered for q in members]
         self.device = th.device(device)
-        self.offsets, off = [], 0
-        for p in self.params:
-            self.offsets.append(off)
-            off += -(-p.numel() // _ALIGN) * _ALIGN
+        self.offsets, self.group_spans, off = [], {}, 0
+        for members in ordered:
+            start = off
+            for q in members:
+                self.offsets.append(off)
+                off += q.numel()
+            if len(members) > 1:
+                self.group_spans[in_group[id(members[0])]] = (start, len(members), tuple(members[0].shape))
+            off = -(-off // _ALIGN) * _ALIGN
         self.numel = max(off, _ALIGN)
         self.flat = th.zeros(self.numel, dtype=th.float32, device=self.device)
         self.grad = th.zeros(self.numel, dtype=th.float32, device=self.device) if with_grad else None
@@ -42,6 +66,13 @@ class ParamArena:
                 p.data = view
                 if with_grad and p.requires_grad:
                     p.grad = self.grad[o:o + p.numel()].view(p.shape)
+
+    def stacked(self, group_index: int):
+        """([G, *shape] view of the parameters, same view of the gradient arena or None)."""
+        start, g, shape = self.group_spans[group_index]
+        n = g * int(th.tensor(shape).prod()) if shape else g
+        w = self.flat[start:start + n].view(g, *shape)
+        return w, (None if self.grad is None else self.grad[start:start + n].view(g, *shape))
 
     def zero_grad(self) -> None:
         """One memset; `.grad` views stay attached so autograd keeps accumulating in place."""
@@ -161,11 +192,11 @@ class FlatAdam:
 
 
 def make_optimizer(module_params: Iterable[nn.Parameter], device, lr: float, optimizer_class=None,
-                   optimizer_kwargs: Optional[dict] = None):
+                   optimizer_kwargs: Optional[dict] = None, groups: Optional[list] = None):
     """Default (optimizer_class None or torch.optim.Adam with default kwargs) -> arena + FlatAdam. Any other
     optimiser class is honoured with the stock torch implementation on the arena's parameter views."""
     optimizer_kwargs = dict(optimizer_kwargs or {})
-    arena = ParamArena(module_params, device)
+    arena = ParamArena(module_params, device, groups=groups)
     if optimizer_class in (None, th.optim.Adam) and set(optimizer_kwargs) <= {"betas", "eps"}:
         return arena, FlatAdam(arena, lr=lr, **optimizer_kwargs)
     return arena, optimizer_class(arena.params, lr=lr, **optimizer_kwargs)

@@ -6,7 +6,8 @@ a hand-written HIP kernel, and gradients are written STRAIGHT into the flat aren
                                + `torch.mm(gz^T, x, out=<arena view of W.grad>)` + `torch.mm(gz, W)`.
     No AccumulateGrad adds, no zero_grad memsets: every parameter's gradient is (over)written exactly once per
     backward; frozen parameters (critic during the actor loss) skip the weight/bias GEMMs entirely.
-  * `squashed_gaussian(mean, log_std, eps)` = 1 launch forward, 1 launch backward (analytic).
+  * twin critics = ONE chain of batched GEMMs over stacked arena views; the actor's mu / log_std heads = ONE GEMM;
+  * `squashed_gaussian([mean | log_std], eps)` = 1 launch forward, 1 launch backward (analytic).
 
 The nn.Modules keep owning the parameters (state_dict / API); `FastMLP` only reads their tensors. Arithmetic per
 element is the reference's (core/common/torch_layers.py:110-183, core/common/distributions.py:161-260).
@@ -95,91 +96,199 @@ class FastMLP:
 
 
 class _SquashedGaussianFn(th.autograd.Function):
+    """`params` is either (mean, log_std_raw) as two [B, A] tensors or ONE merged-head GEMM output [B, 2A]."""
+
     @staticmethod
-    def forward(ctx, mean, log_std_raw, eps):
-        mean, log_std_raw = mean.contiguous(), log_std_raw.contiguous()
-        action = th.empty_like(mean)
-        logp = th.empty(mean.shape[0], dtype=mean.dtype, device=mean.device)
-        hip_ops.squashed_gaussian_fwd(mean, log_std_raw, eps, action, logp)
-        ctx.save_for_backward(action, log_std_raw, eps)
+    def forward(ctx, params, eps, act_dim: int):
+        mean, ls = params[:, :act_dim], params[:, act_dim:]
+        action = th.empty(params.shape[0], act_dim, dtype=params.dtype, device=params.device)
+        logp = th.empty(params.shape[0], dtype=params.dtype, device=params.device)
+        hip_ops.squashed_gaussian_fwd(mean, ls, eps, action, logp)
+        ctx.save_for_backward(action, params, eps)
+        ctx.act_dim = act_dim
         ctx.set_materialize_grads(False)
         return action, logp
 
     @staticmethod
     def backward(ctx, g_action, g_logp):
-        action, log_std_raw, eps = ctx.saved_tensors
-        g_mean, g_ls = th.empty_like(action), th.empty_like(action)
-        hip_ops.squashed_gaussian_bwd(None if g_action is None else g_action.contiguous(),
-                                      None if g_logp is None else g_logp.contiguous(), action, log_std_raw, eps, g_mean, g_ls)
-        return g_mean, g_ls, None
+        action, params, eps = ctx.saved_tensors
+        a = ctx.act_dim
+        g_params = th.empty_like(params)
+        if g_action is not None and g_action.stride(1) != 1:
+            g_action = g_action.contiguous()
+        hip_ops.squashed_gaussian_bwd(g_action, None if g_logp is None else g_logp.contiguous(), action, params[:, a:], eps,
+                                      g_params[:, :a], g_params[:, a:])
+        return g_params, None, None
 
 
-def squashed_gaussian(mean: th.Tensor, log_std_raw: th.Tensor, eps: th.Tensor, want_logp: bool = True):
-    """(action, logp) of SAC's squashed Gaussian with the log_std clamp folded in; logp is None when not wanted."""
+def squashed_gaussian(params: th.Tensor, eps: th.Tensor, act_dim: int, want_logp: bool = True):
+    """(action, logp) of SAC's squashed Gaussian (log_std clamp folded in) from the merged [B, 2A] head output
+    [mean | log_std_raw]; logp is None when not wanted."""
     eps = eps.contiguous()
-    if th.is_grad_enabled() and (mean.requires_grad or log_std_raw.requires_grad):
-        return _SquashedGaussianFn.apply(mean, log_std_raw, eps)
-    mean, log_std_raw = mean.contiguous(), log_std_raw.contiguous()
-    action = th.empty_like(mean)
-    logp = th.empty(mean.shape[0], dtype=mean.dtype, device=mean.device) if want_logp else None
-    hip_ops.squashed_gaussian_fwd(mean, log_std_raw, eps, action, logp)
+    if th.is_grad_enabled() and params.requires_grad:
+        return _SquashedGaussianFn.apply(params, eps, act_dim)
+    action = th.empty(params.shape[0], act_dim, dtype=params.dtype, device=params.device)
+    logp = th.empty(params.shape[0], dtype=params.dtype, device=params.device) if want_logp else None
+    hip_ops.squashed_gaussian_fwd(params[:, :act_dim], params[:, act_dim:], eps, action, logp)
     return action, logp
 
 
-class FastSacActor:
-    """core/sac/policies.py:147-175 on the fused path."""
+class _StackedLinearFn(th.autograd.Function):
+    """G independent Linear layers as ONE batched GEMM: x [G, M, K] (may be a stride-0 expand of a shared input),
+    W [G, N, K], b [G, N] are stacked VIEWS of the parameter arena, wgrad / bgrad the same views of the gradient arena."""
 
-    def __init__(self, actor):
+    @staticmethod
+    def forward(ctx, x, weight, bias, wgrad, bgrad, act: int, train_params: bool, *owners):
+        y = th.bmm(x, weight.transpose(1, 2))
+        hip_ops.bias_act_fwd_(y, bias, act)
+        ctx.act, ctx.train_params = act, train_params
+        ctx.save_for_backward(x, weight, y)
+        ctx.wgrad, ctx.bgrad = wgrad, bgrad
+        ctx.n_owners = len(owners)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight, y = ctx.saved_tensors
+        gy = gy.contiguous()
+        gbias = ctx.bgrad if ctx.train_params else None
+        if ctx.act != ACT_NONE:
+            gz = th.empty_like(gy)
+            hip_ops.bias_act_bwd(gy, y, ctx.act, gz, gbias)
+        else:
+            gz = gy
+            if gbias is not None:
+                hip_ops.bias_act_bwd(gy, None, ACT_NONE, gy, gbias)
+        if ctx.train_params:
+            th.bmm(gz.transpose(1, 2), x, out=ctx.wgrad)
+        dx = th.bmm(gz, weight) if ctx.needs_input_grad[0] else None
+        return (dx, None, None, None, None, None, None) + (None,) * ctx.n_owners
+
+
+def stacked_linear(x, weight, bias, wgrad, bgrad, act: int, train_params: bool, owners=()):
+    """`owners`: the nn.Parameters whose storage `weight` / `bias` alias; passing them makes the output require grad when
+    only the parameters do (first layer on replay data)."""
+    if not th.is_grad_enabled() or not (x.requires_grad or train_params):
+        y = th.bmm(x, weight.transpose(1, 2))
+        return hip_ops.bias_act_fwd_(y, bias, act)
+    return _StackedLinearFn.apply(x, weight, bias, wgrad, bgrad, act, train_params, *(owners if train_params else ()))
+
+
+class FastSacActor:
+    """core/sac/policies.py:147-175 on the fused path. With `head` = (stacked [2, A, H] weight view, [2, A] bias view and
+    their gradient views) the mu and log_std heads are ONE GEMM with N = 2A."""
+
+    def __init__(self, actor, head=None):
         self.actor = actor
         self.latent = FastMLP(actor.latent_pi)
         self.mu, self.log_std = actor.mu, actor.log_std
+        self.act_dim = actor.mu.weight.shape[0]
+        self.head = head
+        if head is not None:
+            w, wg, b, bg = head
+            a2 = 2 * self.act_dim
+            self._hw, self._hb = w.view(a2, -1), b.view(a2)
+            self._hwg, self._hbg = wg.view(a2, -1), bg.view(a2)
 
-    def dist_params(self, obs: th.Tensor, train_params: bool = True):
+    def dist_params(self, obs: th.Tensor, train_params: bool = True) -> th.Tensor:
+        """[B, 2A] = [mean | log_std_raw]"""
         h = self.latent(obs, train_params)
-        return (linear(h, self.mu.weight, self.mu.bias, ACT_NONE, train_params),
-                linear(h, self.log_std.weight, self.log_std.bias, ACT_NONE, train_params))
+        if self.head is None:
+            return th.cat((linear(h, self.mu.weight, self.mu.bias, ACT_NONE, train_params),
+                           linear(h, self.log_std.weight, self.log_std.bias, ACT_NONE, train_params)), dim=1)
+        if not th.is_grad_enabled() or not (h.requires_grad or train_params):
+            return hip_ops.bias_act_fwd_(th.mm(h, self._hw.t()), self._hb, ACT_NONE)
+        return _MergedHeadFn.apply(h, self._hw, self._hb, self._hwg, self._hbg, train_params, self.mu.weight, self.log_std.weight)
 
     def action_log_prob(self, obs: th.Tensor, eps: Optional[th.Tensor] = None, train_params: bool = True, want_logp: bool = True):
-        mean, ls = self.dist_params(obs, train_params)
+        params = self.dist_params(obs, train_params)
         if eps is None:
-            eps = self.actor.action_dist.draw_eps(mean.shape, mean.device)
-        return squashed_gaussian(mean, ls, eps, want_logp)
+            eps = self.actor.action_dist.draw_eps((params.shape[0], self.act_dim), params.device)
+        return squashed_gaussian(params, eps, self.act_dim, want_logp)
+
+
+class _MergedHeadFn(th.autograd.Function):
+    @staticmethod
+    def forward(ctx, h, w, b, wg, bg, train_params: bool, *owners):
+        y = hip_ops.bias_act_fwd_(th.mm(h, w.t()), b, ACT_NONE)
+        ctx.save_for_backward(h, w)
+        ctx.wg, ctx.bg, ctx.train_params = wg, bg, train_params
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        h, w = ctx.saved_tensors
+        gy = gy.contiguous()
+        if ctx.train_params:
+            hip_ops.bias_act_bwd(gy, None, ACT_NONE, gy, ctx.bg)
+            th.mm(gy.t(), h, out=ctx.wg)
+        dx = th.mm(gy, w) if ctx.needs_input_grad[0] else None
+        return dx, None, None, None, None, None, None, None
+
+
+class QOut(tuple):
+    """Tuple of per-network Q tensors; `.stacked` is the [G, B, 1] batched-GEMM output they are views of (or None):
+    backward from the stacked tensor directly (one root) instead of through G select nodes."""
+    stacked: Optional[th.Tensor] = None
+
+
+def backward_q(qs: "QOut", grads: th.Tensor) -> None:
+    """autograd.backward for a critic output with d(loss)/dQ given as a [G, B, 1] tensor."""
+    if qs.stacked is not None:
+        th.autograd.backward([qs.stacked], [grads[:qs.stacked.shape[0]]])
+    else:
+        th.autograd.backward(list(qs), [grads[i] for i in range(len(qs))])
 
 
 class FastTwinCritic:
-    """core/common/policies.py:960-987 on the fused path (n_critics Q networks on cat(obs, action)).
+    """core/common/policies.py:960-987 on the fused path: the n_critics Q networks on cat(obs, action).
 
-    The two Q networks are independent chains of ~5-us launches. With `two_streams` the second network is issued
-    on a side HIP stream (fork after the concat, join before the outputs are used): under hipGraph capture the two
-    chains become parallel branches of the graph, forward AND backward (autograd replays each node on the stream
-    of its forward), so the pair costs about one chain's latency. Same kernels, same arithmetic."""
+    `stack` (per layer: stacked [G, N, K] weight view, [G, N] bias view and their gradient views, from
+    `ParamArena.stacked`) evaluates all Q networks as ONE chain of batched GEMMs -- half the launches of the
+    per-network chains; without it each network is its own `FastMLP`."""
 
-    def __init__(self, critic, two_streams: bool = True):
+    def __init__(self, critic, stack=None):
         self.nets = [FastMLP(q) for q in critic.q_networks]
-        self.two_streams = two_streams and len(self.nets) == 2
-        self._side: Optional[th.cuda.Stream] = None
+        self.stack = stack
+        self.acts = [act for _, act in self.nets[0].layers]
+        self.owners = [[net.layers[li][0].weight for net in self.nets] for li in range(len(self.acts))]
 
     def __call__(self, obs: th.Tensor, actions: th.Tensor, train_params: bool = True, only_first: bool = False):
         x = th.cat([obs, actions], dim=1)
-        if only_first or not self.two_streams:
+        if self.stack is None:
             nets = self.nets[:1] if only_first else self.nets
-            return tuple(net(x, train_params) for net in nets)
-        cur = th.cuda.current_stream(x.device)
-        if self._side is None:
-            self._side = th.cuda.Stream(device=x.device)
-        side = self._side
-        side.wait_stream(cur)
-        x.record_stream(side)
-        q1 = self.nets[0](x, train_params)
-        with th.cuda.stream(side):
-            q2 = self.nets[1](x, train_params)
-        cur.wait_stream(side)
-        q2.record_stream(cur)
-        return q1, q2
+            return QOut(net(x, train_params) for net in nets)
+        g = 1 if only_first else len(self.nets)
+        h = x.unsqueeze(0).expand(g, -1, -1)
+        for li, (w, wg, b, bg) in enumerate(self.stack):
+            if train_params and g != w.shape[0]:
+                raise RuntimeError("stacked critic: parameter gradients need all Q networks in the pass")
+            h = stacked_linear(h, w[:g], b[:g], None if wg is None else wg[:g], None if bg is None else bg[:g], self.acts[li],
+                               train_params, self.owners[li][:g])
+        out = QOut(h[i] for i in range(g))
+        out.stacked = h
+        return out
 
-    def join(self) -> None:
-        """After a backward pass through this critic: make the caller's stream wait for the side stream. The second
-        network's weight/bias gradients are written into the arena by its backward nodes ON THE SIDE STREAM; autograd
-        only synchronises streams along tensor edges it knows about, and those writes are side effects."""
-        if self._side is not None:
-            th.cuda.current_stream(self._side.device).wait_stream(self._side)
+
+def twin_groups(q_networks) -> list:
+    """Arena groups that make `FastTwinCritic`'s stacked views possible: for every layer, the weights of all Q networks
+    back to back, then their biases. Empty for a single Q network or non-identical architectures."""
+    seqs = [[m for m in q if isinstance(m, nn.Linear)] for q in q_networks]
+    if len(seqs) < 2 or len({tuple((l.in_features, l.out_features) for l in sq) for sq in seqs}) != 1:
+        return []
+    groups = []
+    for li in range(len(seqs[0])):
+        groups.append([sq[li].weight for sq in seqs])
+        groups.append([sq[li].bias for sq in seqs])
+    return groups
+
+
+def twin_stack(arena, target: bool = False):
+    """[(W [G,N,K], W.grad view | None, b [G,N], b.grad view | None)] per layer from an arena built with `twin_groups`."""
+    n_layers = len(arena.group_spans) // 2
+    out = []
+    for li in range(n_layers):
+        w, wg = arena.stacked(2 * li)
+        b, bg = arena.stacked(2 * li + 1)
+        out.append((w, wg, b.view(b.shape[0], -1), None if bg is None else bg.view(bg.shape[0], -1)))
+    return out or None

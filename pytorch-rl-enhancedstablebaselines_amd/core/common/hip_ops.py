@@ -174,43 +174,69 @@ def _f32c(t, name):
     return t
 
 
+def _gmn(t):
+    """[m, n] -> (1, m, n); [G, m, n] -> (G, m, n)"""
+    if t.dim() == 2:
+        return (1, t.shape[0], t.shape[1])
+    if t.dim() == 3:
+        return tuple(t.shape)
+    raise ValueError(f"expected a 2-D or 3-D tensor, got shape {tuple(t.shape)}")
+
+
 def bias_act_fwd_(y, bias, act: int):
-    m, n = y.shape
-    _f32c(y, "y"), _chk(bias, "bias", (n,), th.float32)
-    check(nv.lib().cstr_bias_act_fwd_f32(ptr(y), ptr(bias), C.c_int(act), C.c_int64(m), C.c_int64(n), stream_ptr()),
+    g, m, n = _gmn(y)
+    _f32c(y, "y"), _f32c(bias, "bias")
+    if bias.numel() != g * n:
+        raise ValueError(f"bias has {bias.numel()} elements, expected {g * n}")
+    check(nv.lib().cstr_bias_act_fwd_f32(ptr(y), ptr(bias), C.c_int(act), C.c_int64(g), C.c_int64(m), C.c_int64(n), stream_ptr()),
           "cstr_bias_act_fwd_f32")
     return y
 
 
 def bias_act_bwd(gy, y, act: int, gz, gbias):
-    m, n = gy.shape
-    _f32c(gy, "gy"), _chk(gz, "gz", (m, n), th.float32)
+    g, m, n = _gmn(gy)
+    _f32c(gy, "gy"), _chk(gz, "gz", gy.shape, th.float32)
     if act != 0:
-        _chk(y, "y", (m, n), th.float32)
-    _opt(gbias, "gbias", (n,), th.float32)
-    check(nv.lib().cstr_bias_act_bwd_f32(ptr(gy), ptr(y), C.c_int(act), ptr(gz), ptr(gbias), C.c_int64(m), C.c_int64(n),
+        _chk(y, "y", gy.shape, th.float32)
+    if gbias is not None:
+        _f32c(gbias, "gbias")
+        if gbias.numel() != g * n:
+            raise ValueError(f"gbias has {gbias.numel()} elements, expected {g * n}")
+    check(nv.lib().cstr_bias_act_bwd_f32(ptr(gy), ptr(y), C.c_int(act), ptr(gz), ptr(gbias), C.c_int64(g), C.c_int64(m), C.c_int64(n),
                                          stream_ptr()), "cstr_bias_act_bwd_f32")
+
+
+def _rows(t, name, b, a):
+    """A [b, a] float32 device matrix whose rows may be strided (a column slice of a wider row-major matrix)."""
+    if not (isinstance(t, th.Tensor) and t.is_cuda and t.dtype == th.float32 and tuple(t.shape) == (b, a) and t.stride(1) == 1
+            and t.stride(0) >= a):
+        raise ValueError(f"{name}: needs a float32 device matrix [{b}, {a}] with unit column stride")
+    return t.stride(0)
 
 
 def squashed_gaussian_fwd(mean, log_std_raw, eps, action, logp):
     b, a = mean.shape
-    for t, nm in ((mean, "mean"), (log_std_raw, "log_std_raw"), (eps, "eps"), (action, "action")):
-        _chk(t, nm, (b, a), th.float32)
+    stride = _rows(mean, "mean", b, a)
+    if _rows(log_std_raw, "log_std_raw", b, a) != stride:
+        raise ValueError("mean and log_std_raw must share their row stride")
+    _chk(eps, "eps", (b, a), th.float32), _chk(action, "action", (b, a), th.float32)
     _opt(logp, "logp", (b,), th.float32)
     check(nv.lib().cstr_squashed_gaussian_fwd_f32(ptr(mean), ptr(log_std_raw), ptr(eps), ptr(action), ptr(logp), C.c_int64(b),
-                                                  C.c_int(a), stream_ptr()), "cstr_squashed_gaussian_fwd_f32")
+                                                  C.c_int(a), C.c_int(stride), stream_ptr()), "cstr_squashed_gaussian_fwd_f32")
 
 
 def squashed_gaussian_bwd(g_action, g_logp, action, log_std_raw, eps, g_mean, g_log_std_raw):
     b, a = action.shape
-    for t, nm in ((action, "action"), (log_std_raw, "log_std_raw"), (eps, "eps"), (g_mean, "g_mean"), (g_log_std_raw, "g_log_std_raw")):
-        _chk(t, nm, (b, a), th.float32)
-    _opt(g_action, "g_action", (b, a), th.float32)
+    _chk(action, "action", (b, a), th.float32), _chk(eps, "eps", (b, a), th.float32)
+    stride = _rows(log_std_raw, "log_std_raw", b, a)
+    if _rows(g_mean, "g_mean", b, a) != stride or _rows(g_log_std_raw, "g_log_std_raw", b, a) != stride:
+        raise ValueError("g_mean / g_log_std_raw must have log_std_raw's row stride")
+    ga_stride = a if g_action is None else _rows(g_action, "g_action", b, a)
     if g_logp is not None and (g_logp.numel() != b or not g_logp.is_contiguous() or g_logp.dtype != th.float32):
         raise ValueError("g_logp must be a contiguous float32 tensor with batch elements")
     check(nv.lib().cstr_squashed_gaussian_bwd_f32(ptr(g_action), ptr(g_logp), ptr(action), ptr(log_std_raw), ptr(eps), ptr(g_mean),
-                                                  ptr(g_log_std_raw), C.c_int64(b), C.c_int(a), stream_ptr()),
-          "cstr_squashed_gaussian_bwd_f32")
+                                                  ptr(g_log_std_raw), C.c_int64(b), C.c_int(a), C.c_int(stride), C.c_int(ga_stride),
+                                                  stream_ptr()), "cstr_squashed_gaussian_bwd_f32")
 
 
 def _vec(t, name, n):

@@ -92,12 +92,21 @@ class SACPolicy(BasePolicy):
 
     def to_device_arenas(self, device) -> None:
         """`.to(device)` of the reference (off_policy_algorithm.py:209), into flat arenas + one-launch optimisers."""
+        from core.common import fused
+
         lr = self._lr_schedule(1)
+        a = self.actor
+        head_groups = [[a.mu.weight, a.log_std.weight], [a.mu.bias, a.log_std.bias]]  # one GEMM for both heads
         self.actor_arena, self.actor.optimizer = make_optimizer(self.actor.parameters(), device, lr, self.optimizer_class,
-                                                                self.optimizer_kwargs)
+                                                                self.optimizer_kwargs, groups=head_groups)
+        (hw, hwg), (hb, hbg) = self.actor_arena.stacked(0), self.actor_arena.stacked(1)
+        self.actor_head = (hw, hwg, hb, hbg)
         self.critic_arena, self.critic.optimizer = make_optimizer(self.critic.parameters(), device, lr, self.optimizer_class,
-                                                                  self.optimizer_kwargs)
-        self.critic_target_arena = ParamArena(self.critic_target.parameters(), device, with_grad=False)
+                                                                  self.optimizer_kwargs, groups=fused.twin_groups(self.critic.q_networks))
+        self.critic_target_arena = ParamArena(self.critic_target.parameters(), device, with_grad=False,
+                                              groups=fused.twin_groups(self.critic_target.q_networks))
+        self.critic_stack = fused.twin_stack(self.critic_arena)
+        self.critic_target_stack = fused.twin_stack(self.critic_target_arena)
         for p in self.critic_target.parameters():
             p.requires_grad_(False)
 

@@ -12,17 +12,11 @@ import numpy as np
 import torch as th
 from torch.nn import functional as F
 
-import os
-
 from core.common import fused, hip_ops
 from core.common.arena import FlatAdam, ParamArena
 from core.common.logger import DeviceMean
 from core.common.off_policy_algorithm import OffPolicyAlgorithm
 from core.sac.policies import MlpPolicy, SACPolicy
-
-
-# measured on MI355X (profiles/r01_notes.md): the fork/join edges cost more than the overlap buys (0.497 vs 0.454 ms/iter)
-_TWO_STREAMS = os.environ.get("CSTR_TWIN_STREAMS", "0") != "0"
 
 
 class SAC(OffPolicyAlgorithm):
@@ -83,9 +77,9 @@ class SAC(OffPolicyAlgorithm):
         # fused learner path (core/common/fused.py): GEMMs in rocBLAS, everything else hand-written HIP
         self.fused_learner = self._fused_supported()
         if self.fused_learner:
-            self._fast_actor = fused.FastSacActor(self.actor)
-            self._fast_critic = fused.FastTwinCritic(self.critic, _TWO_STREAMS)
-            self._fast_critic_target = fused.FastTwinCritic(self.critic_target, _TWO_STREAMS)
+            self._fast_actor = fused.FastSacActor(self.actor, self.policy.actor_head)
+            self._fast_critic = fused.FastTwinCritic(self.critic, self.policy.critic_stack)
+            self._fast_critic_target = fused.FastTwinCritic(self.critic_target, self.policy.critic_target_stack)
 
     def _fused_supported(self) -> bool:
         from core.common.arena import FlatAdam
@@ -152,8 +146,9 @@ class SAC(OffPolicyAlgorithm):
         B = rd.observations.shape[0]
         if not hasattr(self, "_g_bufs") or self._g_bufs[0].shape[0] != B:
             e = lambda *sh: th.empty(*sh, dtype=th.float32, device=self.device)  # noqa: E731
-            self._g_bufs = (e(B, 1), e(B, 1), e(B))
-        gq1, gq2, g_lp = self._g_bufs
+            self._g_bufs = (e(2, B, 1), e(B))
+        gq, g_lp = self._g_bufs
+        gq1, gq2 = gq[0], gq[1]
 
         actions_pi, log_prob = self._fast_actor.action_log_prob(rd.observations)  # :222
 
@@ -172,17 +167,20 @@ class SAC(OffPolicyAlgorithm):
             q1_t, q2_t = self._fast_critic_target(rd.next_observations, next_actions, train_params=False)
             hip_ops.td_target_min(q1_t, q2_t, next_log_prob, rd.rewards, rd.dones, ent_coef, self.gamma, self._target_q)
 
-        q1, q2 = self._fast_critic(rd.observations, rd.actions)  # :258
+        qs = self._fast_critic(rd.observations, rd.actions)  # :258
+        q1, q2 = qs
         hip_ops.twin_q_loss(q1, q2, self._target_q, 0.5, gq1, gq2, self._loss_now["critic"], s["critic"])  # :261
-        th.autograd.backward([q1, q2], [gq1, gq2])  # :266-268
-        self._fast_critic.join()
+        fused.backward_q(qs, gq)  # :266-268
         self._allreduce_grads(pol.critic_arena)
         self.critic.optimizer.step()
 
-        q1_pi, q2_pi = self._fast_critic(rd.observations, actions_pi, train_params=False)  # :273-275 (critic weights frozen)
+        qs_pi = self._fast_critic(rd.observations, actions_pi, train_params=False)  # :273-275 (critic weights frozen)
+        q1_pi, q2_pi = qs_pi
         hip_ops.sac_actor_loss(log_prob, q1_pi, q2_pi, ent_coef, g_lp, gq1, gq2, self._loss_now["actor"], s["actor"])
-        th.autograd.backward([log_prob, q1_pi, q2_pi], [g_lp, gq1, gq2])  # :279-281
-        self._fast_critic.join()
+        if qs_pi.stacked is not None:  # :279-281
+            th.autograd.backward([log_prob, qs_pi.stacked], [g_lp, gq])
+        else:
+            th.autograd.backward([log_prob, q1_pi, q2_pi], [g_lp, gq1, gq2])
         self._allreduce_grads(pol.actor_arena)
         self.actor.optimizer.step()
 

@@ -71,13 +71,18 @@ class TD3Policy(BasePolicy):
         self.actor.optimizer = self.critic.optimizer = None
 
     def to_device_arenas(self, device) -> None:
+        from core.common import fused
+
         lr = self._lr_schedule(1)
         self.actor_arena, self.actor.optimizer = make_optimizer(self.actor.parameters(), device, lr, self.optimizer_class,
                                                                 self.optimizer_kwargs)
         self.critic_arena, self.critic.optimizer = make_optimizer(self.critic.parameters(), device, lr, self.optimizer_class,
-                                                                  self.optimizer_kwargs)
+                                                                  self.optimizer_kwargs, groups=fused.twin_groups(self.critic.q_networks))
         self.actor_target_arena = ParamArena(self.actor_target.parameters(), device, with_grad=False)
-        self.critic_target_arena = ParamArena(self.critic_target.parameters(), device, with_grad=False)
+        self.critic_target_arena = ParamArena(self.critic_target.parameters(), device, with_grad=False,
+                                              groups=fused.twin_groups(self.critic_target.q_networks))
+        self.critic_stack = fused.twin_stack(self.critic_arena)
+        self.critic_target_stack = fused.twin_stack(self.critic_target_arena)
         for p in list(self.actor_target.parameters()) + list(self.critic_target.parameters()):
             p.requires_grad_(False)
 

@@ -5,16 +5,10 @@ from typing import List, Optional, Union
 import torch as th
 from torch.nn import functional as F
 
-import os
-
 from core.common import fused, hip_ops
 from core.common.logger import DeviceMean
 from core.common.off_policy_algorithm import OffPolicyAlgorithm
 from core.td3.policies import MlpPolicy
-
-
-# measured on MI355X (profiles/r01_notes.md): the fork/join edges cost more than the overlap buys (0.497 vs 0.454 ms/iter)
-_TWO_STREAMS = os.environ.get("CSTR_TWIN_STREAMS", "0") != "0"
 
 
 class TD3(OffPolicyAlgorithm):
@@ -56,7 +50,7 @@ class TD3(OffPolicyAlgorithm):
                               and fused.FastMLP.supported(self.actor.mu) and all(fused.FastMLP.supported(q) for q in self.critic.q_networks))
         if self.fused_learner:
             self._fast_actor, self._fast_actor_target = fused.FastMLP(self.actor.mu), fused.FastMLP(self.actor_target.mu)
-            self._fast_critic, self._fast_critic_target = fused.FastTwinCritic(self.critic, _TWO_STREAMS), fused.FastTwinCritic(self.critic_target, _TWO_STREAMS)
+            self._fast_critic, self._fast_critic_target = fused.FastTwinCritic(self.critic, self.policy.critic_stack), fused.FastTwinCritic(self.critic_target, self.policy.critic_target_stack)
 
     def _policy_out_device(self, obs: th.Tensor) -> th.Tensor:
         if not self.fused_learner:
@@ -145,8 +139,9 @@ class TD3(OffPolicyAlgorithm):
         rd = self.replay_buffer.sample_into(self._batch(batch_size))
         B = rd.observations.shape[0]
         if not hasattr(self, "_g_bufs") or self._g_bufs[0].shape[0] != B:
-            self._g_bufs = (th.empty(B, 1, device=self.device), th.empty(B, 1, device=self.device))
-        gq1, gq2 = self._g_bufs
+            self._g_bufs = th.empty(2, B, 1, device=self.device)
+        gq = self._g_bufs
+        gq1, gq2 = gq[0], gq[1]
         with th.no_grad():  # :167-176
             noise = self.noise_queue.pop(0).to(self.device) if self.noise_queue else rd.actions.clone().normal_(0, self.target_policy_noise)
             noise = noise.clamp(-self.target_noise_clip, self.target_noise_clip)
@@ -158,18 +153,17 @@ class TD3(OffPolicyAlgorithm):
         # n_critics == 1 (DDPG): loss = mse(q1, t) -> scale 0.5 of the doubled term
         hip_ops.twin_q_loss(q1, q2, self._target_q, 1.0 if len(qs) == 2 else 0.5, gq1, gq2, self._loss_now["critic"], s["critic"])
         if len(qs) == 2:
-            th.autograd.backward([q1, q2], [gq1, gq2])
+            fused.backward_q(qs, gq)
         else:
             th.autograd.backward([q1], [gq1 + gq2])
-        self._fast_critic.join()
         self._allreduce_grads(pol.critic_arena)
         self.critic.optimizer.step()
         actor_done = False
         if n_updates % self.policy_delay == 0:  # :192-206
             a = self._fast_actor(rd.observations)
-            (q1_pi,) = self._fast_critic(rd.observations, a, train_params=False, only_first=True)
-            hip_ops.neg_mean_loss(q1_pi, gq1, self._loss_now["actor"], s["actor"])
-            th.autograd.backward([q1_pi], [gq1])
+            qs_pi = self._fast_critic(rd.observations, a, train_params=False, only_first=True)
+            hip_ops.neg_mean_loss(qs_pi[0], gq1, self._loss_now["actor"], s["actor"])
+            fused.backward_q(qs_pi, gq)
             self._allreduce_grads(pol.actor_arena)
             self.actor.optimizer.step()
             pol.critic_target_arena.polyak_from(pol.critic_arena, self.tau)

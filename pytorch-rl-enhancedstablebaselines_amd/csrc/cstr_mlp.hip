@@ -20,11 +20,13 @@ constexpr int ACT_NONE = 0, ACT_RELU = 1, ACT_TANH = 2;
 // ---- Linear epilogues --------------------------------------------------------------------------------
 
 // y[m][n] = act(y[m][n] + bias[n])   (nn.Linear + nn.ReLU / nn.Tanh of create_mlp, core/common/torch_layers.py:110-183)
+// Grouped form: y is [G][m][n] and bias [G][n] (a batched GEMM's output: twin critics, merged heads); `gsz` = m * n.
 template <int ACT>
-__global__ void bias_act_fwd_kernel(float *__restrict__ y, const float *__restrict__ bias, const int64_t total, const int n)
+__global__ void bias_act_fwd_kernel(float *__restrict__ y, const float *__restrict__ bias, const int64_t total, const int n,
+                                    const int64_t gsz)
 {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        float v = y[i] + bias[i % n];
+        float v = y[i] + bias[(i / gsz) * n + i % n];
         if (ACT == ACT_RELU) v = v > 0.0f ? v : 0.0f;
         if (ACT == ACT_TANH) v = tanhf(v);
         y[i] = v;
@@ -32,11 +34,12 @@ __global__ void bias_act_fwd_kernel(float *__restrict__ y, const float *__restri
 }
 
 template <int ACT>
-__global__ void bias_act_fwd_vec4_kernel(float4 *__restrict__ y, const float4 *__restrict__ bias, const int64_t total4, const int n4)
+__global__ void bias_act_fwd_vec4_kernel(float4 *__restrict__ y, const float4 *__restrict__ bias, const int64_t total4, const int n4,
+                                         const int64_t gsz4)
 {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
         float4 v = y[i];
-        const float4 b = bias[i % n4];
+        const float4 b = bias[(i / gsz4) * n4 + i % n4];
         v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
         if (ACT == ACT_RELU) { v.x = fmaxf(v.x, 0.0f); v.y = fmaxf(v.y, 0.0f); v.z = fmaxf(v.z, 0.0f); v.w = fmaxf(v.w, 0.0f); }
         if (ACT == ACT_TANH) { v.x = tanhf(v.x); v.y = tanhf(v.y); v.z = tanhf(v.z); v.w = tanhf(v.w); }
@@ -55,6 +58,11 @@ __global__ __launch_bounds__(WAVES * 64) void bias_act_bwd_kernel(const float *g
     __shared__ float part[WAVES][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int col = blockIdx.x * 64 + lane;
+    const int64_t goff = (int64_t)blockIdx.y * m * n;  // group (batched-GEMM member): [G][m][n] tensors, gbias [G][n]
+    gy += goff;
+    gz += goff;
+    if (ACT != ACT_NONE) y += goff;
+    if (gbias) gbias += (int64_t)blockIdx.y * n;
     float acc = 0.0f;
     if (col < n) {
         for (int r0 = wave; r0 < m; r0 += 4 * WAVES) {
@@ -111,17 +119,19 @@ __device__ __forceinline__ float block_sum_256(float v, float *sm)
 constexpr float LOG_STD_MIN = -20.0f, LOG_STD_MAX = 2.0f;  // core/sac/policies.py:20-22
 
 // u = mean + exp(clamp(log_std)) * eps; a = tanh(u); logp = sum_j Normal.log_prob(u_j) - sum_j log(1 - a_j^2 + 1e-6)
+// `in_stride`: row stride of mean / log_std_raw (act_dim when they are separate tensors, 2 * act_dim when they are the two
+// halves of one merged-head GEMM output [B][2A]).
 __global__ void squashed_gaussian_fwd_kernel(const float *__restrict__ mean, const float *__restrict__ log_std_raw,
                                              const float *__restrict__ eps, float *__restrict__ action,
-                                             float *__restrict__ logp, const int64_t batch, const int act_dim)
+                                             float *__restrict__ logp, const int64_t batch, const int act_dim, const int in_stride)
 {
     const float half_log_2pi = 0.91893853320467274178f;  // math.log(math.sqrt(2 * math.pi))
     for (int64_t b = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; b < batch; b += (int64_t)gridDim.x * blockDim.x) {
         float lp = 0.0f, corr = 0.0f;
         for (int j = 0; j < act_dim; ++j) {
-            const int64_t i = b * act_dim + j;
-            const float mu = mean[i];
-            const float ls = fminf(fmaxf(log_std_raw[i], LOG_STD_MIN), LOG_STD_MAX);
+            const int64_t i = b * act_dim + j, k = b * in_stride + j;
+            const float mu = mean[k];
+            const float ls = fminf(fmaxf(log_std_raw[k], LOG_STD_MIN), LOG_STD_MAX);
             const float s = expf(ls);
             const float u = mu + s * eps[i];  // Normal.rsample
             const float a = tanhf(u);
@@ -141,20 +151,21 @@ __global__ void squashed_gaussian_fwd_kernel(const float *__restrict__ mean, con
 __global__ void squashed_gaussian_bwd_kernel(const float *__restrict__ g_action, const float *__restrict__ g_logp,
                                              const float *__restrict__ action, const float *__restrict__ log_std_raw,
                                              const float *__restrict__ eps, float *__restrict__ g_mean,
-                                             float *__restrict__ g_log_std_raw, const int64_t batch, const int act_dim)
+                                             float *__restrict__ g_log_std_raw, const int64_t batch, const int act_dim,
+                                             const int in_stride, const int ga_stride)
 {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < batch * act_dim; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t b = i / act_dim;
-        const float a = action[i], raw = log_std_raw[i];
+        const int64_t b = i / act_dim, j = i % act_dim, k = b * in_stride + j;
+        const float a = action[i], raw = log_std_raw[k];
         const float ls = fminf(fmaxf(raw, LOG_STD_MIN), LOG_STD_MAX);
         const float s = expf(ls);
         const float one_m = 1.0f - a * a;
         const float gl = g_logp ? g_logp[b] : 0.0f;
-        const float ga = g_action ? g_action[i] : 0.0f;
+        const float ga = g_action ? g_action[b * ga_stride + j] : 0.0f;  // may be a column slice of a wider gradient
         const float gu = ga * one_m + gl * (2.0f * a * one_m / (one_m + 1e-6f));
-        g_mean[i] = gu;
+        g_mean[k] = gu;
         const float gls = gu * eps[i] * s - gl;
-        g_log_std_raw[i] = (raw >= LOG_STD_MIN && raw <= LOG_STD_MAX) ? gls : 0.0f;
+        g_log_std_raw[k] = (raw >= LOG_STD_MIN && raw <= LOG_STD_MAX) ? gls : 0.0f;
     }
 }
 
@@ -255,36 +266,36 @@ __global__ __launch_bounds__(256) void neg_mean_loss_kernel(const float *__restr
 
 // ---- C ABI ---------------------------------------------------------------------------------------------
 
-extern "C" int cstr_bias_act_fwd_f32(float *y, const float *bias, int act, int64_t m, int64_t n, cstr_stream_t stream)
+extern "C" int cstr_bias_act_fwd_f32(float *y, const float *bias, int act, int64_t groups, int64_t m, int64_t n, cstr_stream_t stream)
 {
-    if (!y || !bias || m <= 0 || n <= 0) return CSTR_E_BADARG;
+    if (!y || !bias || groups <= 0 || m <= 0 || n <= 0) return CSTR_E_BADARG;
     if (act < 0 || act > 2 || n > 0x7fffffff) return CSTR_E_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
-    const int64_t total = m * n;
+    const int64_t gsz = m * n, total = groups * gsz;
     int block, grid;
     if ((n & 3) == 0 && aligned16(y) && aligned16(bias)) {
         flat_launch_shape(total / 4, block, grid);
         float4 *y4 = reinterpret_cast<float4 *>(y);
         const float4 *b4 = reinterpret_cast<const float4 *>(bias);
-        if (act == 0) bias_act_fwd_vec4_kernel<0><<<grid, block, 0, s>>>(y4, b4, total / 4, (int)(n / 4));
-        else if (act == 1) bias_act_fwd_vec4_kernel<1><<<grid, block, 0, s>>>(y4, b4, total / 4, (int)(n / 4));
-        else bias_act_fwd_vec4_kernel<2><<<grid, block, 0, s>>>(y4, b4, total / 4, (int)(n / 4));
+        if (act == 0) bias_act_fwd_vec4_kernel<0><<<grid, block, 0, s>>>(y4, b4, total / 4, (int)(n / 4), gsz / 4);
+        else if (act == 1) bias_act_fwd_vec4_kernel<1><<<grid, block, 0, s>>>(y4, b4, total / 4, (int)(n / 4), gsz / 4);
+        else bias_act_fwd_vec4_kernel<2><<<grid, block, 0, s>>>(y4, b4, total / 4, (int)(n / 4), gsz / 4);
     } else {
         flat_launch_shape(total, block, grid);
-        if (act == 0) bias_act_fwd_kernel<0><<<grid, block, 0, s>>>(y, bias, total, (int)n);
-        else if (act == 1) bias_act_fwd_kernel<1><<<grid, block, 0, s>>>(y, bias, total, (int)n);
-        else bias_act_fwd_kernel<2><<<grid, block, 0, s>>>(y, bias, total, (int)n);
+        if (act == 0) bias_act_fwd_kernel<0><<<grid, block, 0, s>>>(y, bias, total, (int)n, gsz);
+        else if (act == 1) bias_act_fwd_kernel<1><<<grid, block, 0, s>>>(y, bias, total, (int)n, gsz);
+        else bias_act_fwd_kernel<2><<<grid, block, 0, s>>>(y, bias, total, (int)n, gsz);
     }
     return (int)hipGetLastError();
 }
 
-extern "C" int cstr_bias_act_bwd_f32(const float *gy, const float *y, int act, float *gz, float *gbias, int64_t m, int64_t n,
-                                     cstr_stream_t stream)
+extern "C" int cstr_bias_act_bwd_f32(const float *gy, const float *y, int act, float *gz, float *gbias, int64_t groups, int64_t m,
+                                     int64_t n, cstr_stream_t stream)
 {
-    if (!gy || !gz || m <= 0 || n <= 0 || (act != 0 && !y)) return CSTR_E_BADARG;
-    if (act < 0 || act > 2 || m > 0x7fffffff || n > 0x7fffffff) return CSTR_E_UNSUPPORTED;
+    if (!gy || !gz || groups <= 0 || m <= 0 || n <= 0 || (act != 0 && !y)) return CSTR_E_BADARG;
+    if (act < 0 || act > 2 || m > 0x7fffffff || n > 0x7fffffff || groups > 65535) return CSTR_E_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
-    const int grid = (int)((n + 63) / 64);
+    const dim3 grid((unsigned)((n + 63) / 64), (unsigned)groups);
     if (m >= 64) {  // 16 waves per workgroup: 16 rows per wave at batch 256
         if (act == 0) bias_act_bwd_kernel<0, 16><<<grid, 1024, 0, s>>>(gy, y, gz, gbias, (int)m, (int)n);
         else if (act == 1) bias_act_bwd_kernel<1, 16><<<grid, 1024, 0, s>>>(gy, y, gz, gbias, (int)m, (int)n);
@@ -298,24 +309,26 @@ extern "C" int cstr_bias_act_bwd_f32(const float *gy, const float *y, int act, f
 }
 
 extern "C" int cstr_squashed_gaussian_fwd_f32(const float *mean, const float *log_std_raw, const float *eps, float *action,
-                                              float *logp, int64_t batch, int act_dim, cstr_stream_t stream)
+                                              float *logp, int64_t batch, int act_dim, int in_stride, cstr_stream_t stream)
 {
-    if (!mean || !log_std_raw || !eps || !action || batch <= 0 || act_dim <= 0) return CSTR_E_BADARG;
+    if (!mean || !log_std_raw || !eps || !action || batch <= 0 || act_dim <= 0 || in_stride < act_dim) return CSTR_E_BADARG;
     int block, grid;
     flat_launch_shape(batch, block, grid);
-    squashed_gaussian_fwd_kernel<<<grid, block, 0, (hipStream_t)stream>>>(mean, log_std_raw, eps, action, logp, batch, act_dim);
+    squashed_gaussian_fwd_kernel<<<grid, block, 0, (hipStream_t)stream>>>(mean, log_std_raw, eps, action, logp, batch, act_dim, in_stride);
     return (int)hipGetLastError();
 }
 
 extern "C" int cstr_squashed_gaussian_bwd_f32(const float *g_action, const float *g_logp, const float *action,
                                               const float *log_std_raw, const float *eps, float *g_mean, float *g_log_std_raw,
-                                              int64_t batch, int act_dim, cstr_stream_t stream)
+                                              int64_t batch, int act_dim, int in_stride, int g_action_stride, cstr_stream_t stream)
 {
-    if (!action || !log_std_raw || !eps || !g_mean || !g_log_std_raw || batch <= 0 || act_dim <= 0) return CSTR_E_BADARG;
+    if (!action || !log_std_raw || !eps || !g_mean || !g_log_std_raw || batch <= 0 || act_dim <= 0 || in_stride < act_dim ||
+        (g_action && g_action_stride < act_dim))
+        return CSTR_E_BADARG;
     int block, grid;
     flat_launch_shape(batch * act_dim, block, grid);
     squashed_gaussian_bwd_kernel<<<grid, block, 0, (hipStream_t)stream>>>(g_action, g_logp, action, log_std_raw, eps, g_mean,
-                                                                          g_log_std_raw, batch, act_dim);
+                                                                          g_log_std_raw, batch, act_dim, in_stride, g_action_stride);
     return (int)hipGetLastError();
 }
 

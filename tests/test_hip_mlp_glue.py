@@ -43,7 +43,7 @@ def test_squashed_gaussian_fwd_bwd(ops, B, A):
     eps = th.randn(B, A, generator=g)
     a_ref, lp_ref = ref_squashed(mean, ls, eps)
     m_d, l_d = mean.cuda().requires_grad_(True), ls.cuda().requires_grad_(True)
-    a, lp = fused.squashed_gaussian(m_d, l_d, eps.cuda())
+    a, lp = fused.squashed_gaussian(th.cat((m_d, l_d), dim=1), eps.cuda(), A)  # merged-head layout [mean | log_std_raw]
     assert rel_err(a.detach().cpu().numpy(), a_ref.numpy(), 1.0) < 1e-6  # tanh output lives in [-1, 1]
     # log(1 - a^2 + 1e-6) is ill-conditioned where tanh saturates (a 1-ulp difference between libm's and ocml's tanhf
     # is amplified by 1/(1 - a^2 + 1e-6)); this synthetic batch saturates heavily (std up to e^2)
@@ -67,7 +67,7 @@ def test_squashed_gaussian_fwd_bwd(ops, B, A):
     assert float(l_d.grad[0, 0]) == 0.0 and float(l_d.grad[-1, -1]) == 0.0
     # acting only (no logp, no grad)
     with th.no_grad():
-        a2, none = fused.squashed_gaussian(mean.cuda(), ls.cuda(), eps.cuda(), want_logp=False)
+        a2, none = fused.squashed_gaussian(th.cat((mean, ls), dim=1).cuda(), eps.cuda(), A, want_logp=False)
     assert none is None and th.equal(a2, a.detach())
 
 
@@ -165,3 +165,48 @@ def test_fast_modules_equal_nn_modules():
     assert rel_err(a.cpu().numpy(), a_ref.cpu().numpy(), 1e-3) < 1e-5 and rel_err(lp.cpu().numpy(), lp_ref.cpu().numpy(), 1.0) < 1e-5
     for x, y in zip(q, q_ref):
         assert rel_err(x.cpu().numpy(), y.cpu().numpy(), 1e-2) < 1e-5
+
+
+def test_stacked_twin_critic_and_merged_heads_equal_per_network_path():
+    """The batched-GEMM critics / merged actor heads read the same arena memory as the nn.Modules: forward values and the
+    gradients that land in the arena must equal the per-network fused path and autograd on the modules."""
+    from core.common import fused
+    from core.common.vec_env import CSTRVecEnv
+    from core.sac import SAC
+
+    model = SAC("MlpPolicy", CSTRVecEnv(4), seed=1, policy_kwargs=dict(net_arch=[64, 48]))
+    pol = model.policy
+    assert pol.critic_stack is not None and model._fast_critic.stack is not None
+    obs, act = th.rand(96, 4, device="cuda") * 2 - 1, th.rand(96, 2, device="cuda") * 2 - 1
+    gq = th.randn(2, 96, 1, device="cuda")
+    # stacked
+    qs = model._fast_critic(obs, act)
+    fused.backward_q(qs, gq)
+    g_stacked = pol.critic_arena.grad.clone()
+    # per-network FastMLP chains on the same parameters
+    plain = fused.FastTwinCritic(model.critic, None)
+    pol.critic_arena.grad.fill_(5.0)
+    qp = plain(obs, act)
+    fused.backward_q(qp, gq)
+    for a, b in zip(qs, qp):
+        assert rel_err(a.detach().cpu().numpy(), b.detach().cpu().numpy(), 1e-2) < 1e-5
+    used = th.zeros_like(g_stacked, dtype=th.bool)
+    for p, o in zip(pol.critic_arena.params, pol.critic_arena.offsets):
+        used[o:o + p.numel()] = True
+    assert rel_err(g_stacked[used].cpu().numpy(), pol.critic_arena.grad[used].cpu().numpy(), 1e-3) < 1e-5
+    # nn.Module + autograd reference
+    ref = [q.detach().clone() for q in model.critic(obs, act)]
+    for a, b in zip(qs, ref):
+        assert rel_err(a.detach().cpu().numpy(), b.cpu().numpy(), 1e-2) < 1e-5
+    # actor: merged heads vs separate Linear heads
+    eps = th.randn(96, 2, device="cuda")
+    a1, lp1 = model._fast_actor.action_log_prob(obs, eps=eps)
+    th.autograd.backward([a1, lp1], [th.ones_like(a1), th.ones_like(lp1)])
+    g_merged = pol.actor_arena.grad.clone()
+    sep = fused.FastSacActor(model.actor, None)
+    pol.actor_arena.grad.zero_()
+    a2, lp2 = sep.action_log_prob(obs, eps=eps)
+    th.autograd.backward([a2, lp2], [th.ones_like(a2), th.ones_like(lp2)])
+    assert rel_err(a1.detach().cpu().numpy(), a2.detach().cpu().numpy(), 1.0) < 1e-6
+    assert rel_err(lp1.detach().cpu().numpy(), lp2.detach().cpu().numpy(), 1.0) < 1e-5
+    assert rel_err(g_merged.cpu().numpy(), pol.actor_arena.grad.cpu().numpy(), 1e-2) < 1e-5
