@@ -33,6 +33,7 @@ class ParamArena:
 
     def __init__(self, params: Iterable[nn.Parameter], device, with_grad: bool = True, groups: Optional[list] = None):
         params = list(params)
+        self.input_params: List[nn.Parameter] = params  # the caller's order (= the torch optimiser's parameter indices)
         groups = [list(g) for g in (groups or [])]
         in_group = {id(p): gi for gi, g in enumerate(groups) for p in g}
         for g in groups:
@@ -57,6 +58,7 @@ class ParamArena:
                 self.group_spans[in_group[id(members[0])]] = (start, len(members), tuple(members[0].shape))
             off = -(-off // _ALIGN) * _ALIGN
         self.numel = max(off, _ALIGN)
+        self.offset_of = {id(p): o for p, o in zip(self.params, self.offsets)}
         self.flat = th.zeros(self.numel, dtype=th.float32, device=self.device)
         self.grad = th.zeros(self.numel, dtype=th.float32, device=self.device) if with_grad else None
         with th.no_grad():
@@ -105,7 +107,9 @@ class ArenaSlice:
         start = arena.offsets[idx[0]]
         end = arena.offsets[idx[-1] + 1] if idx[-1] + 1 < len(arena.params) else arena.numel
         self.parent, self.params, self.device = arena, params, arena.device
+        self.input_params = params
         self.offsets = [arena.offsets[i] - start for i in idx]
+        self.offset_of = {id(p): o for p, o in zip(params, self.offsets)}
         self.numel = end - start
         self.flat = arena.flat[start:end]
         self.grad = arena.grad[start:end]
@@ -159,14 +163,15 @@ class FlatAdam:
         interchangeable with the reference's `actor.optimizer.pth` etc. (core/common/base_class.py:827-840)."""
         step = float(self.ctl[0])
         state = {}
-        for i, (p, o) in enumerate(zip(self.arena.params, self.arena.offsets)):
+        for i, p in enumerate(self.arena.input_params):  # torch.optim indexes parameters in the order they were given
+            o = self.arena.offset_of[id(p)]
             sl = slice(o, o + p.numel())
             state[i] = {"step": th.tensor(step), "exp_avg": self.exp_avg[sl].view(p.shape).clone(),
                         "exp_avg_sq": self.exp_avg_sq[sl].view(p.shape).clone()}
         g = self.param_groups[0]
         group = {"lr": float(g["lr"]), "betas": tuple(g["betas"]), "eps": g["eps"], "weight_decay": 0, "amsgrad": False,
                  "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
-                 "params": list(range(len(self.arena.params)))}
+                 "params": list(range(len(self.arena.input_params)))}
         return {"state": state if step > 0 else {}, "param_groups": [group]}
 
     def load_state_dict(self, sd: dict) -> None:
@@ -174,7 +179,8 @@ class FlatAdam:
         self.exp_avg.zero_()
         self.exp_avg_sq.zero_()
         steps = set()
-        for i, (p, o) in enumerate(zip(self.arena.params, self.arena.offsets)):
+        for i, p in enumerate(self.arena.input_params):
+            o = self.arena.offset_of[id(p)]
             st = state.get(i, state.get(str(i)))
             if st is None:
                 continue
