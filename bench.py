@@ -41,7 +41,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=30)
-    ap.add_argument("--algo", default="sac", choices=["sac", "td3"])
+    ap.add_argument("--algo", default="sac", choices=["sac", "td3", "maddpg"])
     ap.add_argument("--n-envs", type=int, default=4096)
     ap.add_argument("--obs-dim", type=int, default=4, choices=[4, 8])
     ap.add_argument("--integrator", default="euler", choices=["euler", "rk4"])
@@ -239,9 +239,16 @@ def main():
 
     blas.configure(args.blas)
     N, B = args.n_envs, 256
-    env = CSTRVecEnv(N, obs_dim=args.obs_dim, integrator=args.integrator, device=f"cuda:{local_rank}")
-    cls = SAC if args.algo == "sac" else TD3
-    model = cls("MlpPolicy", env, seed=0, device=f"cuda:{local_rank}")  # class defaults: buffer 1e6 -> 244 rows x 4096
+    if args.algo == "maddpg":  # BASELINE config 5: 4 agents (one per reactor) on the twin-train 8-obs / 4-act env
+        from core.maddpg import MADDPG
+
+        env = CSTRVecEnv(N, obs_dim=8, twin=True, integrator=args.integrator, device=f"cuda:{local_rank}")
+        model = MADDPG(4, "MlpPolicy", env, [[0, 1], [2, 3], [4, 5], [6, 7]], [[0], [1], [2], [3]], learning_rate_list=[1e-3] * 4,
+                       seed=0, device=f"cuda:{local_rank}")
+    else:
+        env = CSTRVecEnv(N, obs_dim=args.obs_dim, integrator=args.integrator, device=f"cuda:{local_rank}")
+        cls = SAC if args.algo == "sac" else TD3
+        model = cls("MlpPolicy", env, seed=0, device=f"cuda:{local_rank}")  # class defaults: buffer 1e6 -> 244 rows x 4096
     total = (args.warmup + args.steps) * N
     _, callback = model._setup_learn(total, NoopCallback(), True, "bench", False)
     use_graph = bool(args.graph)  # world > 1: graph segments with the RCCL all-reduces between them
@@ -275,7 +282,7 @@ def main():
     value = args.steps * N * world / dt
     line = {
         "metric": "env-steps/sec (SAC, two-series CSTR, 4096 vec-envs) at 1/2/4/8 GPUs" if args.algo == "sac" else
-                  "env-steps/sec (TD3, two-series CSTR, 4096 vec-envs)",
+                  f"env-steps/sec ({args.algo.upper()}, two-series CSTR, {N} vec-envs)",
         "value": round(value, 1), "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
@@ -285,7 +292,7 @@ def main():
                    "n_updates": model._n_updates},
     }
     if rank == 0:
-        if not args.no_roofline:
+        if not args.no_roofline and args.algo != "maddpg":
             line["roofline"] = roofline_collect(N, args.obs_dim, args.integrator, 500)
             line["roofline"]["note"] = ("workload size: 4096 envs x 104 B = 426 KB per launch, cache-resident and launch-latency-"
                                         "bound; see roofline_stream for the bandwidth-bound regime of the same kernel")
