@@ -195,11 +195,11 @@ class MADDPG(OffPolicyAlgorithm):
             for i in range(self.n_agents):
                 agent_obs = A._agent_obs_tensor_extract(i, rd.observations)
                 with th.no_grad():  # :148-151
-                    qs = self.critic_target(rd.next_observations, next_actions)[i]
+                    qs = self.critic_target.agent_forward(i, rd.next_observations, next_actions)
                     hip_ops.td_target_min(qs[0].contiguous(), qs[-1].contiguous(), None, rd.rewards, rd.dones, None, self.gamma,
                                           self._target_q[i])
                     target_q = self._target_q[i]
-                current_q = C(rd.observations, rd.actions)[i]  # :154
+                current_q = C.agent_forward(i, rd.observations, rd.actions)  # :154 (only agent i's networks are needed)
                 critic_loss = sum(F.mse_loss(q, target_q) for q in current_q)  # :157
                 self._loss_sums[f"critic{i}"] += critic_loss.detach()
                 C.optimizer_list[i].zero_grad()  # :162-164
@@ -212,7 +212,7 @@ class MADDPG(OffPolicyAlgorithm):
                         actions = th.cat([A.mu_list[j](agent_obs) for j in range(self.n_agents)], dim=-1)
                     else:
                         actions = A(rd.observations)
-                    actor_loss = -C.q1_forward(rd.observations, actions)[i].mean()
+                    actor_loss = -C.agent_forward(i, rd.observations, actions, only_first=True)[0].mean()
                     self._loss_sums[f"actor{i}"] += actor_loss.detach()
                     A.optimizer_list[i].zero_grad()
                     actor_loss.backward()

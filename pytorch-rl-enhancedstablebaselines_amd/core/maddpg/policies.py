@@ -107,6 +107,13 @@ class ContinuousCritic(_MultiAgentModule):
         feats = [self._agent_obs_tensor_extract(i, obs).float() for i in range(self.n_agents)]
         return th.cat([th.cat(feats, dim=-1), actions], dim=1)
 
+    def agent_forward(self, agent_id: int, obs: th.Tensor, actions: th.Tensor, only_first: bool = False) -> tuple:
+        """Only agent `agent_id`'s Q networks: what `forward(obs, actions)[agent_id]` / `q1_forward(...)[agent_id]` return,
+        without evaluating the other agents' networks (the reference computes all of them and discards n_agents - 1)."""
+        x = self._input(agent_id, obs, actions)
+        nets = self.q_networks_list[agent_id]
+        return tuple(q(x) for q in (nets[:1] if only_first else nets))
+
     def forward(self, obs: th.Tensor, actions: th.Tensor) -> list:
         shared = None if self.local else self._input(0, obs, actions)
         return [tuple(q(shared if shared is not None else self._input(i, obs, actions)) for q in self.q_networks_list[i])
