@@ -20,7 +20,7 @@ from core.common import distributed as dist_util
 from core.common import hip_ops
 from core.common.base_class import BaseAlgorithm
 from core.common.buffers import ReplayBuffer
-from core.common.callbacks import BaseCallback, MaybeCallback
+from core.common.callbacks import BaseCallback, MaybeCallback, to_callback
 from core.common.type_aliases import RolloutReturn, TrainFreq, TrainFrequencyUnit
 from core.common.utils import should_collect_more_steps
 from core.common.vec_env import CSTRVecEnv, VecEnv
@@ -212,7 +212,15 @@ class OffPolicyAlgorithm(BaseAlgorithm):
                 self._graph_host_bookkeeping(log_interval)
                 return
             self._train_host_pre()
-            self._graph[key] = self._capture_segments()
+            try:
+                self._graph[key] = self._capture_segments()
+            except Exception as exc:  # something in the iteration is not capturable: run eagerly from now on
+                import warnings
+
+                warnings.warn(f"hipGraph capture failed ({type(exc).__name__}: {exc}); falling back to eager launches")
+                self._graph_enabled, self._graph = False, None
+                self._learn_iteration(to_callback(None), log_interval)
+                return
         self._train_host_pre()
         for item in self._graph[key]:  # hipGraph segments interleaved with the eager collectives that separate them
             item.replay() if isinstance(item, th.cuda.CUDAGraph) else item()
@@ -235,6 +243,12 @@ class OffPolicyAlgorithm(BaseAlgorithm):
                 self._graph_body()
                 self._cap["graph"].capture_end()
                 items.append(self._cap["graph"])
+            except Exception:
+                try:  # leave capture mode before the graph object is destroyed
+                    self._cap["graph"].capture_end()
+                except Exception:
+                    pass
+                raise
             finally:
                 self._cap = None
         th.cuda.current_stream(self.device).wait_stream(side)

@@ -44,11 +44,21 @@ class _MultiAgentModule(nn.Module):
                                           "You need to implement a custom extraction method.")  # multi_agent_policies.py:389-393
         self.optimizer_list: list = []
 
+    def _index(self, kind: str, agent_id: int, device) -> th.Tensor:
+        """Device-resident index vector of an agent's slice (built once: indexing with a Python list would upload an
+        index tensor on every call, which also breaks hipGraph capture)."""
+        cache = self.__dict__.setdefault("_idx_cache", {})
+        key = (kind, agent_id, str(device))
+        if key not in cache:
+            sp = (self.observation_space_list if kind == "obs" else self.action_space_list)[agent_id]
+            cache[key] = th.as_tensor([int(i) for i in sp.indices], dtype=th.long, device=device)
+        return cache[key]
+
     def _agent_obs_tensor_extract(self, agent_id: int, global_observation: th.Tensor) -> th.Tensor:
-        return global_observation[..., list(self.observation_space_list[agent_id].indices)]
+        return global_observation.index_select(-1, self._index("obs", agent_id, global_observation.device))
 
     def _agent_action_tensor_extract(self, agent_id: int, global_action: th.Tensor) -> th.Tensor:
-        return global_action[..., list(self.action_space_list[agent_id].indices)]
+        return global_action.index_select(-1, self._index("act", agent_id, global_action.device))
 
     def set_training_mode(self, mode: bool) -> None:
         self.train(mode)

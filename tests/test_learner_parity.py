@@ -446,3 +446,17 @@ def test_td3_with_normal_action_noise_runs_on_device_and_in_graph():
     assert isinstance(model.action_noise, DeviceNormalActionNoise) and len(model._graph) == 2
     a = model.replay_buffer.actions
     assert float(a.abs().max()) <= 1.0 and float(a.std()) > 0.05 and model._n_updates == 14
+
+
+def test_maddpg_hipgraph_capture():
+    from core.common.vec_env import CSTRVecEnv
+    from core.maddpg import MADDPG
+
+    env = CSTRVecEnv(128, obs_dim=8, twin=True)
+    model = MADDPG(4, "MlpPolicy", env, [[0, 1], [2, 3], [4, 5], [6, 7]], [[0], [1], [2], [3]], learning_rate_list=[1e-3] * 4, seed=0,
+                   batch_size=64, buffer_size=128 * 16, policy_kwargs=dict(net_arch=[[32, 32]] * 4))
+    model.enable_graph_capture()
+    model.learn(128 * 16)
+    assert model._graph_enabled and len(model._graph) == 2 and model._n_updates == 16  # one graph per policy-delay phase
+    for p in model.policy.parameters():
+        assert th.isfinite(p).all()
