@@ -16,72 +16,7 @@ import torch as th
 from core import _native as nv
 from core.common import hip_ops
 from core.common.spaces import Box
-
-
-class VecEnv:
-    """Abstract protocol; attribute and method names follow the reference."""
-
-    def __init__(self, num_envs: int, observation_space, action_space):
-        self.num_envs = num_envs
-        self.observation_space = observation_space
-        self.action_space = action_space
-        self.reset_infos: list = [{} for _ in range(num_envs)]
-        self._seeds: list = [None for _ in range(num_envs)]
-        self._options: list = [{} for _ in range(num_envs)]
-        self.render_mode = None
-
-    def reset(self):
-        raise NotImplementedError
-
-    def step_async(self, actions) -> None:
-        raise NotImplementedError
-
-    def step_wait(self):
-        raise NotImplementedError
-
-    def step(self, actions):
-        """reference: base_vec_env.py:214-222"""
-        self.step_async(actions)
-        return self.step_wait()
-
-    def close(self) -> None:
-        pass
-
-    def seed(self, seed: Optional[int] = None) -> Sequence[Optional[int]]:
-        """reference: base_vec_env.py:292-309 -- env i is seeded with seed + i at its next reset()."""
-        if seed is None:
-            seed = int(np.random.randint(0, np.iinfo(np.uint32).max, dtype=np.uint32))
-        self._seeds = [seed + idx for idx in range(self.num_envs)]
-        return self._seeds
-
-    def _reset_seeds(self) -> None:
-        self._seeds = [None for _ in range(self.num_envs)]
-
-    def _reset_options(self) -> None:
-        self._options = [{} for _ in range(self.num_envs)]
-
-    def get_attr(self, attr_name: str, indices=None) -> list:
-        return [getattr(self, attr_name) for _ in self._indices(indices)]
-
-    def set_attr(self, attr_name: str, value: Any, indices=None) -> None:
-        setattr(self, attr_name, value)
-
-    def env_method(self, method_name: str, *args, indices=None, **kwargs) -> list:
-        return [getattr(self, method_name)(*args, **kwargs) for _ in self._indices(indices)]
-
-    def env_is_wrapped(self, wrapper_class, indices=None) -> list:
-        return [False for _ in self._indices(indices)]
-
-    def _indices(self, indices):
-        if indices is None:
-            return range(self.num_envs)
-        if isinstance(indices, int):
-            return [indices]
-        return indices
-
-    @property
-    def unwrapped(self):
-        return self
+from core.common.vec_env.base_vec_env import VecEnv
 
 
 class CSTRVecEnv(VecEnv):
@@ -235,21 +170,3 @@ class CSTRVecEnv(VecEnv):
             for i in np.nonzero(done_h)[0]:
                 infos[i]["terminal_observation"] = term[i].copy()
         return obs_h, rew_h, done_h, infos
-
-
-def DummyVecEnv(env_fns) -> VecEnv:
-    """Drop-in for `DummyVecEnv([make_env] * N)` (reference: core/common/vec_env/dummy_vec_env.py:30-54): when every
-    factory returns a `TwoSeriesCSTREnv` with the same constructor arguments the N Python envs collapse into one
-    device-resident `CSTRVecEnv(N)`. Anything else is outside this stack's scope."""
-    from twoseriescstr import TwoSeriesCSTREnv
-
-    envs = [fn() for fn in env_fns]
-    if len(set(id(e) for e in envs)) != len(envs):
-        raise ValueError("You tried to create multiple environments, but the function to create them returned the same "
-                         "instance instead of creating different objects.")  # dummy_vec_env.py:32-42
-    if not envs or not all(isinstance(e, TwoSeriesCSTREnv) for e in envs):
-        raise ValueError("This MI355X build vectorises TwoSeriesCSTREnv only; got " + ", ".join(sorted({type(e).__name__ for e in envs})))
-    kw = envs[0].vec_kwargs()
-    if any(e.vec_kwargs() != kw for e in envs[1:]):
-        raise ValueError("All TwoSeriesCSTREnv instances of one vectorised env must share their constructor arguments")
-    return CSTRVecEnv(len(envs), **kw)
