@@ -100,14 +100,16 @@ class ArenaSlice:
     every agent's): same duck type as ParamArena for FlatAdam and the gradient all-reduce."""
 
     def __init__(self, arena: ParamArena, params: Iterable[nn.Parameter]):
-        params = list(params)
-        idx = [next(i for i, q in enumerate(arena.params) if q is p) for p in params]
+        given = list(params)
+        pos = {id(q): i for i, q in enumerate(arena.params)}
+        idx = sorted(pos[id(p)] for p in given)  # arena order (grouping may have permuted the caller's order)
         if idx != list(range(idx[0], idx[0] + len(idx))):
             raise ValueError("ArenaSlice needs consecutive arena tensors")
+        params = [arena.params[i] for i in idx]
         start = arena.offsets[idx[0]]
         end = arena.offsets[idx[-1] + 1] if idx[-1] + 1 < len(arena.params) else arena.numel
         self.parent, self.params, self.device = arena, params, arena.device
-        self.input_params = params
+        self.input_params = given
         self.offsets = [arena.offsets[i] - start for i in idx]
         self.offset_of = {id(p): o for p, o in zip(params, self.offsets)}
         self.numel = end - start

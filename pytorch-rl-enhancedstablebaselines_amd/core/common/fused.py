@@ -254,7 +254,10 @@ class FastTwinCritic:
         self.owners = [[net.layers[li][0].weight for net in self.nets] for li in range(len(self.acts))]
 
     def __call__(self, obs: th.Tensor, actions: th.Tensor, train_params: bool = True, only_first: bool = False):
-        x = th.cat([obs, actions], dim=1)
+        return self.forward_input(th.cat([obs, actions], dim=1), train_params, only_first)
+
+    def forward_input(self, x: th.Tensor, train_params: bool = True, only_first: bool = False):
+        """Q values for an already assembled critic input [B, features + actions]."""
         if self.stack is None:
             nets = self.nets[:1] if only_first else self.nets
             return QOut(net(x, train_params) for net in nets)
@@ -283,12 +286,14 @@ def twin_groups(q_networks) -> list:
     return groups
 
 
-def twin_stack(arena, target: bool = False):
-    """[(W [G,N,K], W.grad view | None, b [G,N], b.grad view | None)] per layer from an arena built with `twin_groups`."""
-    n_layers = len(arena.group_spans) // 2
+def twin_stack(arena, first_group: int = 0, n_layers: Optional[int] = None):
+    """[(W [G,N,K], W.grad view | None, b [G,N], b.grad view | None)] per layer from an arena built with `twin_groups`
+    (`first_group` / `n_layers`: the slice of groups of one agent when several critics share an arena)."""
+    if n_layers is None:
+        n_layers = len(arena.group_spans) // 2
     out = []
     for li in range(n_layers):
-        w, wg = arena.stacked(2 * li)
-        b, bg = arena.stacked(2 * li + 1)
+        w, wg = arena.stacked(first_group + 2 * li)
+        b, bg = arena.stacked(first_group + 2 * li + 1)
         out.append((w, wg, b.view(b.shape[0], -1), None if bg is None else bg.view(bg.shape[0], -1)))
     return out or None

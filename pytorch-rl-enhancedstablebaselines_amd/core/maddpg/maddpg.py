@@ -19,7 +19,7 @@ import numpy as np
 import torch as th
 from torch.nn import functional as F
 
-from core.common import blas, hip_ops
+from core.common import blas, fused, hip_ops
 from core.common.buffers import ReplayBuffer
 from core.common.logger import DeviceMean
 from core.common.off_policy_algorithm import OffPolicyAlgorithm
@@ -98,9 +98,24 @@ class MADDPG(OffPolicyAlgorithm):
         self._ep_stats = th.zeros(4, dtype=th.float64, device=self.device)
         self.actor, self.actor_target = self.policy.actor, self.policy.actor_target
         self.critic, self.critic_target = self.policy.critic, self.policy.critic_target
-        z = lambda: th.zeros((), dtype=th.float32, device=self.device)  # noqa: E731
+        z = lambda: th.zeros(1, dtype=th.float32, device=self.device)  # noqa: E731
         self._loss_sums = {f"{k}{i}": z() for k in ("actor", "critic") for i in range(self.n_agents)}
         self._static_batch = None
+        self._loss_now = z()
+        pol = self.policy
+        self.fused_learner = (all(fused.FastMLP.supported(m) for m in self.actor.mu_list)
+                              and all(fused.FastMLP.supported(q) for nets in self.critic.q_networks_list for q in nets))
+        if self.fused_learner:
+            self._fast_actors = [fused.FastMLP(m) for m in self.actor.mu_list]
+            self._fast_actor_targets = [fused.FastMLP(m) for m in self.actor_target.mu_list]
+
+            class _Nets:  # FastTwinCritic reads `.q_networks`
+                def __init__(self, nets):
+                    self.q_networks = nets
+
+            self._fast_critics = [fused.FastTwinCritic(_Nets(n), st) for n, st in zip(self.critic.q_networks_list, pol.critic_stacks)]
+            self._fast_critic_targets = [fused.FastTwinCritic(_Nets(n), st)
+                                         for n, st in zip(self.critic_target.q_networks_list, pol.critic_target_stacks)]
         if self.faithful_quirks:
             widths = {len(s) for s in self.observation_splits}
             if len(widths) != 1:
@@ -178,6 +193,9 @@ class MADDPG(OffPolicyAlgorithm):
         A, C = self.actor, self.critic
         for _ in range(gradient_steps):
             n_updates += 1
+            if self.fused_learner:
+                self._gradient_step_fused(batch_size, n_updates)
+                continue
             rd = self.replay_buffer.sample_into(self._batch(batch_size))
             next_actions_list = []
             with th.no_grad():
@@ -230,6 +248,73 @@ class MADDPG(OffPolicyAlgorithm):
                 self.policy.actor_target_arena.polyak_from(self.policy.actor_arena, self.tau)
             if self.debug_capture:
                 self.last_train_tensors = dict(agents=captured)
+
+    def _gradient_step_fused(self, batch_size: int, n_updates: int) -> None:
+        """maddpg.py:127-185 on the fused path (core/common/fused.py): the same statements and quirks, GEMMs in rocBLAS,
+        epilogues / loss roots in HIP, gradients written into the arenas, only the updating agent's networks evaluated."""
+        pol, A, C = self.policy, self.actor, self.critic
+        rd = self.replay_buffer.sample_into(self._batch(batch_size))
+        B = rd.observations.shape[0]
+        if not hasattr(self, "_g_bufs") or self._g_bufs.shape[1] != B:
+            self._g_bufs = th.empty(2, B, 1, device=self.device)
+        gq = self._g_bufs
+        with th.no_grad():  # :131-144
+            nxt = []
+            for i in range(self.n_agents):
+                agent_next_obs = A._agent_obs_tensor_extract(i, rd.next_observations)
+                if self.noise_queue:
+                    noise = self.noise_queue.pop(0).to(self.device)
+                else:
+                    noise = th.empty(B, len(self.action_splits[i]), device=self.device).normal_(0, self.target_policy_noise)
+                noise = noise.clamp(-self.target_noise_clip, self.target_noise_clip)
+                nxt.append((self._fast_actor_targets[i](agent_next_obs, train_params=False) + noise).clamp(-1, 1))
+            next_actions = th.cat(nxt, dim=-1)
+            shared_next = None if C.local else self.critic_target._input(0, rd.next_observations, next_actions)
+        shared_cur = None if C.local else C._input(0, rd.observations, rd.actions)
+        captured = []
+        for i in range(self.n_agents):
+            with th.no_grad():  # :148-151
+                x_next = shared_next if shared_next is not None else self.critic_target._input(i, rd.next_observations, next_actions)
+                qs_t = self._fast_critic_targets[i].forward_input(x_next, train_params=False)
+                hip_ops.td_target_min(qs_t[0], qs_t[-1], None, rd.rewards, rd.dones, None, self.gamma, self._target_q[i])
+            x_cur = shared_cur if shared_cur is not None else C._input(i, rd.observations, rd.actions)
+            qs = self._fast_critics[i].forward_input(x_cur)  # :154
+            scale = 1.0 if len(qs) == 2 else 0.5
+            hip_ops.twin_q_loss(qs[0], qs[-1], self._target_q[i], scale, gq[0], gq[1], self._loss_now, self._loss_sums[f"critic{i}"])
+            if len(qs) == 2:
+                fused.backward_q(qs, gq)  # :162-164
+            else:
+                th.autograd.backward([qs[0]], [gq[0] + gq[1]])
+            self._allreduce_grads(pol.critic_slices[i])
+            C.optimizer_list[i].step()
+            critic_loss_now = self._loss_now.clone() if self.debug_capture else None
+            actor_loss_now = None
+            if n_updates % self.policy_delay == 0:  # :167-185
+                agent_obs = A._agent_obs_tensor_extract(i, rd.observations)
+                if self.faithful_quirks:  # Q2: every agent's actor sees agent i's observation slice
+                    acts = [self._fast_actors[j](agent_obs, train_params=(j == i)) for j in range(self.n_agents)]
+                else:
+                    acts = [self._fast_actors[j](A._agent_obs_tensor_extract(j, rd.observations), train_params=(j == i))
+                            for j in range(self.n_agents)]
+                actions = th.cat(acts, dim=-1)
+                qs_pi = self._fast_critics[i].forward_input(C._input(i, rd.observations, actions), train_params=False, only_first=True)
+                hip_ops.neg_mean_loss(qs_pi[0], gq[0], self._loss_now, self._loss_sums[f"actor{i}"])
+                fused.backward_q(qs_pi, gq)
+                self._allreduce_grads(pol.actor_slices[i])
+                A.optimizer_list[i].step()
+                if self.debug_capture:
+                    actor_loss_now = self._loss_now.clone()
+                if self.faithful_quirks:  # Q3: polyak inside the agent loop
+                    pol.critic_target_arena.polyak_from(pol.critic_arena, self.tau)
+                    pol.actor_target_arena.polyak_from(pol.actor_arena, self.tau)
+            if self.debug_capture:
+                captured.append(dict(target_q=self._target_q[i].clone(), current_q=[q.detach().clone() for q in qs],
+                                     critic_loss=critic_loss_now, actor_loss=actor_loss_now))
+        if not self.faithful_quirks and n_updates % self.policy_delay == 0:
+            pol.critic_target_arena.polyak_from(pol.critic_arena, self.tau)
+            pol.actor_target_arena.polyak_from(pol.actor_arena, self.tau)
+        if self.debug_capture:
+            self.last_train_tensors = dict(agents=captured)
 
     def learn(self, total_timesteps: int, callback=None, log_interval: int = 4, tb_log_name: str = "MADDPG",
               reset_num_timesteps: bool = True, progress_bar: bool = False):

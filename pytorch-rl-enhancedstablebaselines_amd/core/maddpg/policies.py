@@ -170,10 +170,21 @@ class MADDPGPolicy(nn.Module):
         self.critic_target.set_training_mode(False)
 
     def to_device_arenas(self, device) -> None:
+        from core.common import fused
+
+        def groups(critic):  # per agent: its twin Q networks' layers back to back (batched GEMMs)
+            return [g for nets in critic.q_networks_list for g in fused.twin_groups(nets)]
+
         self.actor_arena = ParamArena(self.actor.parameters(), device)
-        self.critic_arena = ParamArena(self.critic.parameters(), device)
+        self.critic_arena = ParamArena(self.critic.parameters(), device, groups=groups(self.critic))
         self.actor_target_arena = ParamArena(self.actor_target.parameters(), device, with_grad=False)
-        self.critic_target_arena = ParamArena(self.critic_target.parameters(), device, with_grad=False)
+        self.critic_target_arena = ParamArena(self.critic_target.parameters(), device, with_grad=False, groups=groups(self.critic_target))
+        self.critic_stacks, self.critic_target_stacks, g0 = [], [], 0
+        for nets in self.critic.q_networks_list:
+            n_groups = len(fused.twin_groups(nets))
+            self.critic_stacks.append(fused.twin_stack(self.critic_arena, g0, n_groups // 2) if n_groups else None)
+            self.critic_target_stacks.append(fused.twin_stack(self.critic_target_arena, g0, n_groups // 2) if n_groups else None)
+            g0 += n_groups
         for p in list(self.actor_target.parameters()) + list(self.critic_target.parameters()):
             p.requires_grad_(False)
         self.actor_slices, self.critic_slices = [], []

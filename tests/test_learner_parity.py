@@ -294,8 +294,9 @@ def test_hipgraph_iteration_equals_eager():
         assert abs(e["alpha"] - g["alpha"]) < 1e-5
 
 
+@pytest.mark.parametrize("fused_path", [True, False])
 @pytest.mark.parametrize("algo", ["maddpg", "iddpg"])
-def test_maddpg_train_teacher_forced(golden, algo):
+def test_maddpg_train_teacher_forced(golden, algo, fused_path):
     """MADDPG / IDDPG on the natural 2-agent split of the CSTR env vs the unmodified reference (core/maddpg/maddpg.py:117-191,
     core/iddpg/iddpg.py), quirks Q1-Q4 included: per-agent Q-values / TD targets / losses at 1e-5, weights after 4 steps."""
     from core.common import legacy_rng
@@ -309,6 +310,8 @@ def test_maddpg_train_teacher_forced(golden, algo):
     model = MADDPG(n_agents, "MlpPolicy", _make_env(4), [[0, 1], [2, 3]], [[0], [1]], learning_rate_list=[lr, lr], seed=0,
                    batch_size=B, buffer_size=64 * 4, policy_kwargs=dict(net_arch=[[32, 24], [32, 24]]))
     assert (model.gamma, model.tau, model.target_policy_noise, model.target_noise_clip, model.policy_delay) == (gamma, tau, tpn, tnc, int(delay))
+    assert model.fused_learner
+    model.fused_learner = fused_path
     mods = ["actor", "actor_target", "critic", "critic_target"]
     for nm in mods:  # seeded init == reference (construction order = RNG order)
         sd = getattr(model, nm).state_dict()
