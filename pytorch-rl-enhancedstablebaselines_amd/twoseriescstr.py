@@ -79,27 +79,27 @@ class TwoSeriesCSTREnv:
         return obs.astype(np.float32), info
 
     def step(self, action: np.ndarray):
+        """reference: twoseriescstr.py:394-454 -> (obs, reward, terminated=False, truncated, info). A single gym env does
+        not auto-reset, so the VecEnv backend's post-step reset is undone here."""
         if self.state is None:
             raise ValueError("Please call env.reset() to reset the env first!")
-        v = self._backend()
-        a = np.asarray(action, np.float32).reshape(1, 2)
         import torch as th
 
-        _, rew, done, timeout, nxt = v.step_device(th.as_tensor(a).to(v.device))
-        # a single gym env does NOT auto-reset: keep the true next state (the VecEnv face resets)
+        v = self._backend()
+        a = np.asarray(action, np.float32).reshape(1, 2)
+        _, rew, _, timeout, nxt = v.step_device(th.as_tensor(a).to(v.device))
         obs = nxt.cpu().numpy()[0].copy()
         truncated = bool(timeout.cpu().numpy()[0])
-        if not truncated:
-            pass
-        v.obs.copy_(nxt)  # undo the VecEnv auto-reset for the gym face
+        v.obs.copy_(nxt)  # keep the true next state (the VecEnv face would already hold the reset observation)
         if truncated:
             v.step_count.fill_(self.max_steps)
         self.state = obs
-        r = float(rew.cpu().numpy()[0])
+        reward = float(rew.cpu().numpy()[0])
         norm_a = np.clip(a[0], -1.0, 1.0)
-        info = {"reward": r, "raw_action": self.raw_action_low + (norm_a + 1.0) * (self.raw_action_high - self.raw_action_low) / 2.0,
-                "truncated": truncated, "state": obs, "target_C2": self.target_C2, "step": self.current_step}
-        return obs, r, False, truncated, info
+        raw_action = self.raw_action_low + (norm_a + 1.0) * (self.raw_action_high - self.raw_action_low) / 2.0
+        info = {"reward": reward, "raw_action": raw_action, "truncated": truncated, "state": obs, "target_C2": self.target_C2,
+                "step": self.current_step}
+        return obs, reward, False, truncated, info
 
     def render(self):
         if self.render_mode == "human" and self.state is not None:

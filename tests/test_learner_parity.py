@@ -463,3 +463,29 @@ def test_maddpg_hipgraph_capture():
     assert model._graph_enabled and len(model._graph) == 2 and model._n_updates == 16  # one graph per policy-delay phase
     for p in model.policy.parameters():
         assert th.isfinite(p).all()
+
+
+def test_single_gym_env_facade_matches_golden(golden):
+    """`TwoSeriesCSTREnv` (reference constructor / gym API) as a 1-env view of the device env: step values vs the
+    reference's single-step KATs; wrapping it in DummyVecEnv collapses N instances into one CSTRVecEnv."""
+    import sys
+
+    from conftest import PKG
+
+    if PKG not in sys.path:
+        sys.path.insert(0, PKG)
+    from core.common.vec_env import CSTRVecEnv, DummyVecEnv
+    from twoseriescstr import TwoSeriesCSTREnv
+
+    g = golden("env_step_kat.npz")
+    env = TwoSeriesCSTREnv()
+    obs, info = env.reset(seed=3)
+    assert obs.shape == (4,) and "initial_concentration_1" in info
+    for i in (0, 1, 2, 20, 300):
+        env._backend().set_state(g["obs"][i][None], [int(g["step_in"][i])])
+        env.state = g["obs"][i]
+        o, r, term, trunc, inf = env.step(g["act"][i])
+        assert rel_err(o, g["obs_next"][i], 1.0) < 1e-6 and abs(r - float(g["reward"][i])) < 3e-6 * max(1.0, abs(r))
+        assert term is False and trunc == bool(g["truncated"][i]) and rel_err(inf["raw_action"], g["raw_action"][i], 1.0) < 1e-6
+    venv = DummyVecEnv([lambda: TwoSeriesCSTREnv(default_target=0.25) for _ in range(5)])
+    assert isinstance(venv, CSTRVecEnv) and venv.num_envs == 5 and venv.target_C2 == 0.25
