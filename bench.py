@@ -73,11 +73,31 @@ def host_cores() -> int:
     return int(os.environ.get("CSTR_CPU_CORES", min(n, 16)))
 
 
-def event_time_us(fn, n_launch, stream):
-    """Average duration of `fn` (one kernel launch) over n_launch back-to-back launches, HIP events on `stream`."""
+def event_time_us(fn, n_launch, stream, in_graph=False):
+    """Average duration of `fn` (one kernel launch) over n_launch back-to-back launches, HIP events on the launch stream.
+    in_graph: the launches are captured into one hipGraph and the replay is timed -- for microsecond kernels the host's
+    launch gap (~10 us per ctypes call) would otherwise dominate; this is also how the training loop issues them."""
     for _ in range(5):
         fn()
     e0, e1 = th.cuda.Event(enable_timing=True), th.cuda.Event(enable_timing=True)
+    if in_graph:
+        th.cuda.synchronize()
+        side = th.cuda.Stream()
+        side.wait_stream(th.cuda.current_stream())
+        g = th.cuda.CUDAGraph()
+        with th.cuda.stream(side):
+            g.capture_begin(capture_error_mode="thread_local")
+            for _ in range(n_launch):
+                fn()
+            g.capture_end()
+        th.cuda.current_stream().wait_stream(side)
+        g.replay()
+        stream.synchronize()
+        e0.record(stream)
+        g.replay()
+        e1.record(stream)
+        e1.synchronize()
+        return e0.elapsed_time(e1) * 1e3 / n_launch
     stream.synchronize()
     e0.record(stream)
     for _ in range(n_launch):
@@ -111,7 +131,7 @@ def roofline_collect(n_envs, obs_dim, integrator, n_launch):
     def launch():
         hip_ops.collect_step(coef, integrator, ring, obs, steps, pol, True, [-1, -1], [1, 1], pcg_state=pcg)
 
-    us = event_time_us(launch, n_launch, stream)
+    us = event_time_us(launch, n_launch, stream, in_graph=n_envs <= 65536)
     bytes_per_env = 2 * (2 * 4 * obs_dim + 8 + 12)  # 104 B (D=4) / 168 B (D=8): SURVEY 8d
     alg = bytes_per_env * n_envs
     gbs = alg / us / 1e3
@@ -141,13 +161,13 @@ def other_kernels(model, batch):
     out = {}
     n = pol.critic_arena.numel
     tgt = pol.critic_target_arena.flat.clone()
-    us = event_time_us(lambda: hip_ops.polyak(pol.critic_arena.flat, tgt, 0.005), 200, stream)
+    us = event_time_us(lambda: hip_ops.polyak(pol.critic_arena.flat, tgt, 0.005), 200, stream, in_graph=True)
     out["polyak_kernel"] = dict(launch_us=round(us, 3), n_params=n, gbs=round(12 * n / us / 1e3, 2))
     p, g = pol.critic_arena.flat.clone(), th.randn_like(pol.critic_arena.flat)
     m, v = th.zeros_like(p), th.zeros_like(p)
     ctl = th.zeros(2, dtype=th.int64, device=p.device)
     lr = th.tensor([3e-4], dtype=th.float64, device=p.device)
-    us = event_time_us(lambda: hip_ops.adam(p, g, m, v, ctl, lr), 200, stream)
+    us = event_time_us(lambda: hip_ops.adam(p, g, m, v, ctl, lr), 200, stream, in_graph=True)
     out["adam_kernel"] = dict(launch_us=round(us, 3), n_params=n, gbs=round(28 * n / us / 1e3, 2))
     # the same two kernels in their bandwidth-bound regime (2^25 parameters: 403 MB / 940 MB of traffic per launch)
     nbig = 1 << 25
@@ -163,13 +183,13 @@ def other_kernels(model, batch):
     mt = th.zeros(625, dtype=th.int32, device=p.device)
     hip_ops.mt19937_seed(mt, 1)
     us = event_time_us(lambda: hip_ops.replay_sample(rb.ring, mt, batch, b.observations, b.actions, b.next_observations,
-                                                     b.dones, b.rewards), 200, stream)
+                                                     b.dones, b.rewards), 200, stream, in_graph=True)
     d = rb.obs_shape[0]
     out["replay_sample_kernel"] = dict(launch_us=round(us, 3), batch=batch, gbs=round(2 * batch * (8 * d + 20) / us / 1e3, 3))
     q = th.randn(batch, 1, device=p.device)
     o = th.empty_like(q)
     ent = th.ones(1, device=p.device)
-    us = event_time_us(lambda: hip_ops.td_target_min(q, q, q, q, q, ent, 0.99, o), 200, stream)
+    us = event_time_us(lambda: hip_ops.td_target_min(q, q, q, q, q, ent, 0.99, o), 200, stream, in_graph=True)
     out["td_target_min_kernel"] = dict(launch_us=round(us, 3), batch=batch, gbs=round(24 * batch / us / 1e3, 3))
     return out
 
@@ -295,7 +315,8 @@ def main():
         if not args.no_roofline and args.algo != "maddpg":
             line["roofline"] = roofline_collect(N, args.obs_dim, args.integrator, 500)
             line["roofline"]["note"] = ("workload size: 4096 envs x 104 B = 426 KB per launch, cache-resident and launch-latency-"
-                                        "bound; see roofline_stream for the bandwidth-bound regime of the same kernel")
+                                        "bound (duration = issue interval of graph-replayed launches); see roofline_stream for "
+                                        "the bandwidth-bound regime of the same kernel")
             line["roofline_stream"] = roofline_collect(1 << 22, args.obs_dim, args.integrator, 30)
             line["kernels"] = other_kernels(model, B)
         if world == 1 and not args.no_cpu_baseline:

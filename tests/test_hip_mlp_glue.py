@@ -138,7 +138,7 @@ def test_loss_heads(ops):
         grad, ec, ls_, es = (th.zeros(1, device="cuda") for _ in range(4))
         ops.sac_alpha(d(la.detach()), d(lp), -2.0, grad, ec, ls_, es)
         assert rel_err(float(grad), float(la.grad), 1e-3) < 2e-6 and rel_err(float(ec), math.exp(-0.3), 1e-3) < 1e-6
-        assert rel_err(float(ls_), float(ref), 1e-3) < 2e-6 and rel_err(float(es), math.exp(-0.3), 1e-3) < 1e-6
+        assert rel_err(float(ls_), float(ref.detach()), 1e-3) < 2e-6 and rel_err(float(es), math.exp(-0.3), 1e-3) < 1e-6
         # TD3 actor loss td3.py:194
         a = q1.clone().requires_grad_(True)
         ref = -a.mean()
