@@ -165,7 +165,7 @@ def other_kernels(model, batch):
     out["polyak_kernel"] = dict(launch_us=round(us, 3), n_params=n, gbs=round(12 * n / us / 1e3, 2))
     p, g = pol.critic_arena.flat.clone(), th.randn_like(pol.critic_arena.flat)
     m, v = th.zeros_like(p), th.zeros_like(p)
-    ctl = th.zeros(2, dtype=th.int64, device=p.device)
+    ctl = hip_ops.new_adam_ctl(p.device)
     lr = th.tensor([3e-4], dtype=th.float64, device=p.device)
     us = event_time_us(lambda: hip_ops.adam(p, g, m, v, ctl, lr), 200, stream, in_graph=True)
     out["adam_kernel"] = dict(launch_us=round(us, 3), n_params=n, gbs=round(28 * n / us / 1e3, 2))

@@ -58,8 +58,9 @@ typedef struct cstr_ring {
 
 /* ring_ctl: int64[4] in HBM = { pos, full, ticket, adds }  (buffers.py:101-104 `pos`, `full`) */
 #define CSTR_RING_CTL_WORDS 4
-/* adam_ctl: int64[2] in HBM = { step, ticket } (torch.optim.Adam state["step"]) */
-#define CSTR_ADAM_CTL_WORDS 2
+/* adam_ctl: 4 x 64-bit words in HBM = { int64 step, int64 ticket, double beta1^step, double beta2^step }
+ * (torch.optim.Adam state["step"]; the powers are the running products the bias corrections need) */
+#define CSTR_ADAM_CTL_WORDS 4
 /* mt_state: uint32[625] in HBM = { key[624], pos } (numpy legacy RandomState) */
 #define CSTR_MT_STATE_WORDS 625
 /* pcg_state: uint64[4] per env in HBM = { state_hi, state_lo, inc_hi, inc_lo } (numpy PCG64) */

@@ -12,7 +12,7 @@ _PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.environ.get("CSTR_LIB_PATH", os.path.join(_PKG_ROOT, "libcstr_rl_hip.so"))  # override: kernel A/B builds
 
 INTEGRATORS = {"euler": 0, "rk4": 1}
-RING_CTL_WORDS, ADAM_CTL_WORDS, MT_STATE_WORDS, PCG_STATE_WORDS, MAX_SAMPLE_BATCH = 4, 2, 625, 4, 16384
+RING_CTL_WORDS, ADAM_CTL_WORDS, MT_STATE_WORDS, PCG_STATE_WORDS, MAX_SAMPLE_BATCH = 4, 4, 625, 4, 16384
 
 SYMBOLS = (
     "cstr_abi_version", "cstr_error_string", "cstr_default_coef", "cstr_vec_step_f32", "cstr_reset_draw_f32",

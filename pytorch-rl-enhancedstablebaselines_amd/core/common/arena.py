@@ -134,7 +134,7 @@ class FlatAdam:
         dev = arena.device
         self.exp_avg = th.zeros_like(arena.flat)
         self.exp_avg_sq = th.zeros_like(arena.flat)
-        self.ctl = th.zeros(nv.ADAM_CTL_WORDS, dtype=th.int64, device=dev)
+        self.ctl = hip_ops.new_adam_ctl(dev, 0, betas[0], betas[1])
         self.lr_dev = th.tensor([lr], dtype=th.float64, device=dev)
         self._lr_on_device = float(lr)
         self.grad_scale = 1.0  # 1 / world_size after a summing all-reduce
@@ -192,7 +192,8 @@ class FlatAdam:
             steps.add(int(float(st["step"])))
         if len(steps) > 1:
             raise ValueError(f"FlatAdam needs one common step count, checkpoint has {sorted(steps)}")
-        self.ctl[0] = steps.pop() if steps else 0
+        g0 = self.param_groups[0]
+        hip_ops.set_adam_step(self.ctl, steps.pop() if steps else 0, g0["betas"][0], g0["betas"][1])
         groups = sd.get("param_groups") or [{}]
         if "lr" in groups[0]:
             self.param_groups[0]["lr"] = float(groups[0]["lr"])

@@ -154,6 +154,21 @@ def polyak(param_flat, target_flat, tau: float):
           "cstr_polyak_f32")
 
 
+def new_adam_ctl(device, step: int = 0, beta1: float = 0.9, beta2: float = 0.999) -> th.Tensor:
+    """adam_ctl = {step, ticket, beta1^step, beta2^step} (the two powers stored as f64 bit patterns in the int64 tensor)."""
+    ctl = th.zeros(nv.ADAM_CTL_WORDS, dtype=th.int64, device=device)
+    set_adam_step(ctl, step, beta1, beta2)
+    return ctl
+
+
+def set_adam_step(ctl: th.Tensor, step: int, beta1: float = 0.9, beta2: float = 0.999) -> None:
+    host = th.zeros(nv.ADAM_CTL_WORDS, dtype=th.int64)
+    host[0] = int(step)
+    host.view(th.float64)[2] = float(beta1) ** int(step)
+    host.view(th.float64)[3] = float(beta2) ** int(step)
+    ctl.copy_(host)
+
+
 def adam(param, grad, exp_avg, exp_avg_sq, adam_ctl, lr_dev, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0):
     n = param.numel()
     for t, nm in ((param, "param"), (grad, "grad"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq")):

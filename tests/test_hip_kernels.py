@@ -363,7 +363,7 @@ def test_adam_vs_torch_and_oracle(ops, n):
     ref = th.nn.Parameter(p0.clone())
     opt = th.optim.Adam([ref], lr=3e-4)
     p, m, v = p0.clone().cuda(), th.zeros(n, device="cuda"), th.zeros(n, device="cuda")
-    ctl = th.zeros(nv.ADAM_CTL_WORDS, dtype=th.int64, device="cuda")
+    ctl = ops.new_adam_ctl("cuda")
     lr = th.tensor([3e-4], dtype=th.float64, device="cuda")
     op, om, ov = p0.numpy().copy(), np.zeros(n, np.float32), np.zeros(n, np.float32)
     for step in range(1, 7):
@@ -381,9 +381,9 @@ def test_adam_vs_torch_and_oracle(ops, n):
         assert rel_err(p.cpu().numpy(), ref.detach().numpy(), 1e-3) < 1e-6
     # grad_scale (data-parallel mean) folds 1/W into the update
     p2, m2, v2 = p0.clone().cuda(), th.zeros(n, device="cuda"), th.zeros(n, device="cuda")
-    ctl2 = th.zeros(nv.ADAM_CTL_WORDS, dtype=th.int64, device="cuda")
+    ctl2 = ops.new_adam_ctl("cuda")
     p3, m3, v3 = p0.clone().cuda(), th.zeros(n, device="cuda"), th.zeros(n, device="cuda")
-    ctl3 = th.zeros(nv.ADAM_CTL_WORDS, dtype=th.int64, device="cuda")
+    ctl3 = ops.new_adam_ctl("cuda")
     gsum = th.randn(n, generator=g).cuda()
     ops.adam(p2, gsum, m2, v2, ctl2, lr, grad_scale=0.125)
     ops.adam(p3, gsum * 0.125, m3, v3, ctl3, lr)
