@@ -31,7 +31,11 @@ class ParamArena:
     their first member's position in the parameter order; the layout is a pure function of (shapes, groups), so a
     network and its target network built with the same grouping have identical layouts (polyak is one launch)."""
 
-    def __init__(self, params: Iterable[nn.Parameter], device, with_grad: bool = True, groups: Optional[list] = None):
+    def __init__(self, params: Iterable[nn.Parameter], device, with_grad: bool = True, groups: Optional[list] = None,
+                 extra_grad: int = 0, grad_storage: Optional[th.Tensor] = None):
+        """extra_grad: floats appended to the GRADIENT buffer only (`grad_tail`), not covered by the optimiser: a place
+        for another small arena's gradient so that one all-reduce of `grad_full` serves both (SAC: the entropy
+        coefficient rides on the critic's collective). grad_storage: adopt such a tail as this arena's gradient buffer."""
         params = list(params)
         self.input_params: List[nn.Parameter] = params  # the caller's order (= the torch optimiser's parameter indices)
         groups = [list(g) for g in (groups or [])]
@@ -60,7 +64,15 @@ class ParamArena:
         self.numel = max(off, _ALIGN)
         self.offset_of = {id(p): o for p, o in zip(self.params, self.offsets)}
         self.flat = th.zeros(self.numel, dtype=th.float32, device=self.device)
-        self.grad = th.zeros(self.numel, dtype=th.float32, device=self.device) if with_grad else None
+        self.grad = self.grad_full = self.grad_tail = None
+        if grad_storage is not None:
+            if grad_storage.numel() < self.numel or not grad_storage.is_contiguous():
+                raise ValueError("grad_storage too small")
+            self.grad = self.grad_full = grad_storage[:self.numel]
+        elif with_grad:
+            self.grad_full = th.zeros(self.numel + extra_grad, dtype=th.float32, device=self.device)
+            self.grad = self.grad_full[:self.numel]
+            self.grad_tail = self.grad_full[self.numel:] if extra_grad else None
         with th.no_grad():
             for p, o in zip(self.params, self.offsets):
                 view = self.flat[o:o + p.numel()].view(p.shape)
@@ -201,11 +213,11 @@ class FlatAdam:
 
 
 def make_optimizer(module_params: Iterable[nn.Parameter], device, lr: float, optimizer_class=None,
-                   optimizer_kwargs: Optional[dict] = None, groups: Optional[list] = None):
+                   optimizer_kwargs: Optional[dict] = None, groups: Optional[list] = None, extra_grad: int = 0):
     """Default (optimizer_class None or torch.optim.Adam with default kwargs) -> arena + FlatAdam. Any other
     optimiser class is honoured with the stock torch implementation on the arena's parameter views."""
     optimizer_kwargs = dict(optimizer_kwargs or {})
-    arena = ParamArena(module_params, device, groups=groups)
+    arena = ParamArena(module_params, device, groups=groups, extra_grad=extra_grad)
     if optimizer_class in (None, th.optim.Adam) and set(optimizer_kwargs) <= {"betas", "eps"}:
         return arena, FlatAdam(arena, lr=lr, **optimizer_kwargs)
     return arena, optimizer_class(arena.params, lr=lr, **optimizer_kwargs)

@@ -414,4 +414,6 @@ class OffPolicyAlgorithm(BaseAlgorithm):
     # ---- data-parallel helper used by train() ----------------------------------------------------------------------
     def _allreduce_grads(self, arena) -> None:
         if self.world_size > 1 or getattr(self, "_force_segment_boundaries", False):
-            self._eager_boundary(lambda: dist_util.allreduce_sum_(arena.grad))
+            buf = getattr(arena, "grad_full", None)
+            buf = arena.grad if buf is None else buf
+            self._eager_boundary(lambda: dist_util.allreduce_sum_(buf))

@@ -102,7 +102,8 @@ class SACPolicy(BasePolicy):
         (hw, hwg), (hb, hbg) = self.actor_arena.stacked(0), self.actor_arena.stacked(1)
         self.actor_head = (hw, hwg, hb, hbg)
         self.critic_arena, self.critic.optimizer = make_optimizer(self.critic.parameters(), device, lr, self.optimizer_class,
-                                                                  self.optimizer_kwargs, groups=fused.twin_groups(self.critic.q_networks))
+                                                                  self.optimizer_kwargs, groups=fused.twin_groups(self.critic.q_networks),
+                                                                  extra_grad=64)  # tail: the entropy coefficient's gradient
         self.critic_target_arena = ParamArena(self.critic_target.parameters(), device, with_grad=False,
                                               groups=fused.twin_groups(self.critic_target.q_networks))
         self.critic_stack = fused.twin_stack(self.critic_arena)

@@ -60,7 +60,10 @@ class SAC(OffPolicyAlgorithm):
                 init_value = float(self.ent_coef.split("_")[1])
                 assert init_value > 0.0, "The initial value of ent_coef must be greater than 0"
             p = th.nn.Parameter(th.log(th.ones(1) * init_value))
-            self._ent_arena = ParamArena([p], self.device)
+            # its gradient lives in the tail of the critic's gradient buffer: one all-reduce serves both (data-parallel)
+            tail = getattr(self.policy.critic_arena, "grad_tail", None)
+            self._ent_arena = ParamArena([p], self.device, grad_storage=tail)
+            self._ent_rides_critic = tail is not None
             self.log_ent_coef = p
             self.ent_coef_optimizer = FlatAdam(self._ent_arena, lr=self.lr_schedule(1))
             if self.world_size > 1:
@@ -153,10 +156,13 @@ class SAC(OffPolicyAlgorithm):
         actions_pi, log_prob = self._fast_actor.action_log_prob(rd.observations)  # :222
 
         if self.ent_coef_optimizer is not None:  # :230-243
+            # ent_coef = exp(log_ent_coef) BEFORE the update (:230); the updated value is first used by the next gradient
+            # step, so the optimiser step itself may wait for the critic's all-reduce (one collective instead of two)
             hip_ops.sac_alpha(self.log_ent_coef.detach(), log_prob.detach(), self.target_entropy, self._ent_arena.grad[0:1],
                               self._ent_coef_buf, s["ent_coef_loss"], s["ent_coef"])
-            self._allreduce_grads(self._ent_arena)
-            self.ent_coef_optimizer.step()
+            if not self._ent_rides_critic:
+                self._allreduce_grads(self._ent_arena)
+                self.ent_coef_optimizer.step()
             ent_coef = self._ent_coef_buf
         else:
             ent_coef = self.ent_coef_tensor.reshape(1)
@@ -172,6 +178,8 @@ class SAC(OffPolicyAlgorithm):
         hip_ops.twin_q_loss(q1, q2, self._target_q, 0.5, gq1, gq2, self._loss_now["critic"], s["critic"])  # :261
         fused.backward_q(qs, gq)  # :266-268
         self._allreduce_grads(pol.critic_arena)
+        if self.ent_coef_optimizer is not None and self._ent_rides_critic:
+            self.ent_coef_optimizer.step()  # :240-243, gradient averaged by the critic's collective
         self.critic.optimizer.step()
 
         qs_pi = self._fast_critic(rd.observations, actions_pi, train_params=False)  # :273-275 (critic weights frozen)

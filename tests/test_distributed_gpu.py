@@ -45,7 +45,7 @@ def _worker(rank, world, port, out_dir, use_graph):
     th.cuda.synchronize()
     if use_graph:
         (segs,) = model._graph.values()
-        assert sum(isinstance(s, th.cuda.CUDAGraph) for s in segs) == 4  # 3 all-reduces split the iteration in 4 graphs
+        assert sum(isinstance(s, th.cuda.CUDAGraph) for s in segs) == 3  # 2 all-reduces (critic + alpha, actor) -> 3 graphs
     th.save(dict(actor=model.policy.actor_arena.flat.cpu(), critic=model.policy.critic_arena.flat.cpu(),
                  target=model.policy.critic_target_arena.flat.cpu(), alpha=model.log_ent_coef.detach().cpu(),
                  obs=env.obs.cpu(), mt=legacy_rng.global_stream(model.device).cpu(), n_updates=model._n_updates,

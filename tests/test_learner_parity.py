@@ -274,7 +274,7 @@ def test_hipgraph_iteration_equals_eager():
             assert model._graph, "the steady-state iteration was never captured"
             (segs,) = model._graph.values()
             n_graphs = sum(isinstance(it, th.cuda.CUDAGraph) for it in segs)
-            assert n_graphs == (4 if use_graph == "segmented" else 1) and len(segs) == 2 * n_graphs - 1
+            assert n_graphs == (3 if use_graph == "segmented" else 1) and len(segs) == 2 * n_graphs - 1  # 2 collectives
         th.cuda.synchronize()
         results.append(dict(
             mt=legacy_rng.global_stream(model.device).cpu().numpy().copy(), ctl=model.replay_buffer.ring.ctl.cpu().numpy(),
