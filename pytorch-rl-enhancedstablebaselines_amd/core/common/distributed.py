@@ -4,9 +4,10 @@ SURVEY 8e: every rank owns n_envs environments, its own replay ring and its own 
 exchange is ONE summing all-reduce per optimiser step on that optimiser's flat gradient arena. The 1/world
 scale is folded into the Adam kernel (`grad_scale`), so gradient averaging costs no extra pass.
 
-Message sizes are tiny (SAC: 4 B, 543 KB, 272 KB per step): the collective is latency-bound, not xGMI
-link-bound, so the three dependent all-reduces are issued as-is on the training stream and RCCL picks its
-low-latency (tree / one-shot) protocol; no bucketing beyond the per-optimiser arena is useful.
+Message sizes are tiny (SAC: 543 KB critic + entropy coefficient, 272 KB actor per step): the collective is
+latency-bound, not xGMI link-bound, so the two dependent all-reduces are issued as-is on the training stream and
+RCCL picks its low-latency (tree / one-shot) protocol; no bucketing beyond the per-optimiser arena is useful.
+Under hipGraph replay the collectives stay outside the graphs (OffPolicyAlgorithm._capture_segments).
 """
 import os
 from typing import Optional, Tuple
