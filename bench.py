@@ -180,7 +180,7 @@ def other_kernels(model, batch):
     del pb, tb, mb, vb
     rb = model.replay_buffer
     b = rb.alloc_batch(batch)
-    mt = th.zeros(625, dtype=th.int32, device=p.device)
+    mt = th.zeros(628, dtype=th.int32, device=p.device)
     hip_ops.mt19937_seed(mt, 1)
     us = event_time_us(lambda: hip_ops.replay_sample(rb.ring, mt, batch, b.observations, b.actions, b.next_observations,
                                                      b.dones, b.rewards), 200, stream, in_graph=True)

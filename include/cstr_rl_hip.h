@@ -61,8 +61,9 @@ typedef struct cstr_ring {
 /* adam_ctl: 4 x 64-bit words in HBM = { int64 step, int64 ticket, double beta1^step, double beta2^step }
  * (torch.optim.Adam state["step"]; the powers are the running products the bias corrections need) */
 #define CSTR_ADAM_CTL_WORDS 4
-/* mt_state: uint32[625] in HBM = { key[624], pos } (numpy legacy RandomState) */
-#define CSTR_MT_STATE_WORDS 625
+/* mt_state: uint32[628] in HBM = { key[624], pos, has_gauss, gauss (f64, lo word first) } (numpy legacy RandomState) */
+#define CSTR_MT_STATE_WORDS 628
+#define CSTR_MAX_NOISE_PERIOD 8
 /* pcg_state: uint64[4] per env in HBM = { state_hi, state_lo, inc_hi, inc_lo } (numpy PCG64) */
 #define CSTR_PCG_STATE_WORDS 4
 #define CSTR_MAX_SAMPLE_BATCH 16384
@@ -128,6 +129,14 @@ int cstr_collect_step_f32(const cstr_coef_t *coef, int integrator, const cstr_ri
 /* np.random.seed(seed) for the device-resident legacy MT19937 state (core/common/utils.py:46;
  * twoseriescstr.py:164 reseeds the same global stream). */
 int cstr_mt19937_seed(uint32_t *mt_state, uint32_t seed, cstr_stream_t stream);
+
+/* Exploration noise from the SAME legacy stream as the replay sampler: the reference's
+ * VectorizedActionNoise.__call__ -> n_envs x NormalActionNoise.__call__ = np.random.normal(mu, sigma).astype(float32)
+ * (core/common/noise.py:44-45, :141-142; OU noise draws np.random.normal(size=) the same way, :85-89).
+ * out[j] = (float)(loc[j % period] + scale[j % period] * legacy_gauss()), j < count, in numpy's draw order (polar
+ * Box-Muller, second deviate first, odd tail cached in mt_state). loc / scale: HOST double[period], period <= 8. */
+int cstr_mt19937_normal_f32(uint32_t *mt_state, const double *loc, const double *scale, int32_t period, float *out,
+                            int64_t count, cstr_stream_t stream);
 
 /* ReplayBuffer.sample (core/common/buffers.py:106-115, :285-325): upper = rows if full else pos;
  * batch_inds = np.random.randint(0, upper, batch); env_indices = np.random.randint(0, n_envs, batch)

@@ -30,7 +30,7 @@ class Coef(C.Structure):
 
 
 class MTState(C.Structure):
-    _fields_ = [("key", C.c_uint32 * 624), ("pos", C.c_int32)]
+    _fields_ = [("key", C.c_uint32 * 624), ("pos", C.c_int32), ("has_gauss", C.c_int32), ("gauss", C.c_double)]
 
 
 class Ring(C.Structure):
@@ -102,6 +102,17 @@ class MT19937:
         out = np.empty(size, np.int64)
         self.last_used = lib().mt19937_randint_cpu(C.byref(self.st), C.c_int64(high), _p(out), C.c_int64(size))
         return out
+
+    def normal(self, loc, scale, n_calls: int = 1) -> np.ndarray:
+        """`n_calls` consecutive np.random.normal(loc, scale).astype(float32) -> [n_calls, len(loc)]"""
+        loc, scale = np.ascontiguousarray(loc, np.float64).ravel(), np.ascontiguousarray(scale, np.float64).ravel()
+        out = np.empty((n_calls, loc.size), np.float32)
+        lib().mt19937_normal_f32_cpu(C.byref(self.st), _p(loc), _p(scale), C.c_int(loc.size), _p(out), C.c_int64(out.size))
+        return out
+
+    def words(self) -> np.ndarray:
+        """the 628-word device image {key[624], pos, has_gauss, gauss f64}"""
+        return np.frombuffer(bytes(self.st), dtype=np.uint32).copy()
 
     @property
     def key(self):

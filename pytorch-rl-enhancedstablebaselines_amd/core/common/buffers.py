@@ -59,7 +59,7 @@ class ReplayBuffer(BaseBuffer):
     """reference: core/common/buffers.py:158-340.
 
     :param buffer_size: max number of transitions; the ring has `max(buffer_size // n_envs, 1)` rows (:198)
-    :param sampler_stream: optional private MT19937 state (uint32[625] as int32, HBM); default = the device image of
+    :param sampler_stream: optional private MT19937 state (uint32[628] as int32, HBM); default = the device image of
         NumPy's global legacy stream (`np.random.randint`, :113/:309)
     """
 

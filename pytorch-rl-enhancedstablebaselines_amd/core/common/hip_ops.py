@@ -115,6 +115,22 @@ def mt19937_seed(mt_state, seed: int):
     check(nv.lib().cstr_mt19937_seed(ptr(mt_state), C.c_uint32(seed & 0xFFFFFFFF), stream_ptr()), "cstr_mt19937_seed")
 
 
+def mt19937_normal(mt_state, loc, scale, out):
+    """`out.shape[0]` consecutive np.random.normal(loc, scale).astype(float32) from the device legacy stream
+    (reference: core/common/noise.py:44-45, :141-142); out [n, len(loc)] f32."""
+    _chk(mt_state, "mt_state", (nv.MT_STATE_WORDS,), th.int32)
+    loc, scale = [float(v) for v in loc], [float(v) for v in scale]
+    period = len(loc)
+    if len(scale) != period or not 1 <= period <= nv.MAX_NOISE_PERIOD:
+        raise ValueError(f"loc / scale must have the same length in [1, {nv.MAX_NOISE_PERIOD}]")
+    if any(not v >= 0.0 for v in scale):
+        raise ValueError("scale < 0")  # numpy's message
+    _chk(out, "out", (out.shape[0], period), th.float32)
+    check(nv.lib().cstr_mt19937_normal_f32(ptr(mt_state), (C.c_double * period)(*loc), (C.c_double * period)(*scale),
+                                           C.c_int32(period), ptr(out), C.c_int64(out.numel()), stream_ptr()),
+          "cstr_mt19937_normal_f32")
+
+
 def replay_sample(ring: DeviceRing, mt_state, batch: int, out_obs, out_act, out_next_obs, out_done, out_rew,
                   out_row_idx=None, out_env_idx=None):
     d, a = ring.obs_dim, ring.act_dim

@@ -1,7 +1,12 @@
-"""Exploration noise (reference: core/common/noise.py:9-174). NumPy draws on the host, like the reference
-(`np.random.normal` on the global legacy stream, :44-45). NOTE: the device replay sampler owns the HBM image of
-that stream, so host draws here do NOT advance it -- bit-faithful interleaving of noise and index draws is the
-"next" row SURVEY 8f-3; SAC (action_noise=None) and TD3's class default are unaffected."""
+"""Exploration noise (reference: core/common/noise.py:9-174).
+
+The reference draws Gaussian noise with `np.random.normal` on the process-global legacy stream (:44-45) -- the same
+stream ReplayBuffer.sample draws its indices from. On the device env's fast path `NormalActionNoise` is therefore
+replaced by `LegacyStreamNormalActionNoise`, which draws all n_envs x action_dim deviates in ONE kernel from the HBM
+image of that stream (cstr_mt19937_normal_f32): the noise values and the replay index stream that follows stay
+bit-faithful to a seeded reference run. `DeviceNormalActionNoise` is the faster, statistically
+equivalent alternative (torch's device generator, not bit-faithful). The plain host classes keep the reference's
+NumPy code for generic (non-device) envs; their host draws do NOT advance the device stream."""
 import copy
 from typing import Iterable, Optional
 
@@ -60,6 +65,32 @@ class VectorizedActionNoise(ActionNoise):
 
     def __call__(self) -> np.ndarray:
         return np.stack([noise() for noise in self.noises])
+
+
+class LegacyStreamNormalActionNoise(ActionNoise):
+    """`VectorizedActionNoise(NormalActionNoise(mean, sigma), n_envs)()` (reference: noise.py:44-45, :141-142) on the
+    GPU: n_envs consecutive `np.random.normal(mean, sigma).astype(float32)` draws from the legacy MT19937 stream that
+    `stream_fn()` returns (the replay sampler's), in numpy's order. Graph-capturable: all state lives in HBM."""
+
+    def __init__(self, mean, sigma, n_envs: int, device, stream_fn):
+        import torch as th
+
+        self._mu = np.asarray(mean, np.float64).reshape(-1)
+        self._sigma = np.broadcast_to(np.asarray(sigma, np.float64).reshape(-1), self._mu.shape).copy()
+        self.n_envs, self.device, self._stream_fn = int(n_envs), th.device(device), stream_fn
+        self._out = th.empty(self.n_envs, self._mu.size, dtype=th.float32, device=self.device)
+
+    def __call__(self):
+        from core.common import hip_ops
+
+        hip_ops.mt19937_normal(self._stream_fn(), self._mu, self._sigma, self._out)
+        return self._out
+
+    def reset(self, indices: Optional[Iterable[int]] = None) -> None:
+        pass  # memoryless
+
+    def __repr__(self) -> str:
+        return f"LegacyStreamNormalActionNoise(mu={self._mu.tolist()}, sigma={self._sigma.tolist()}, n_envs={self.n_envs})"
 
 
 class DeviceNormalActionNoise(ActionNoise):

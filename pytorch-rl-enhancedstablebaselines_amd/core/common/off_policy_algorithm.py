@@ -108,13 +108,19 @@ class OffPolicyAlgorithm(BaseAlgorithm):
 
     # ---- learn ----------------------------------------------------------------------------------------------------
     def _setup_learn(self, total_timesteps, callback=None, reset_num_timesteps=True, tb_log_name="run", progress_bar=False):
-        from core.common.noise import DeviceNormalActionNoise, NormalActionNoise, VectorizedActionNoise
+        from core.common.noise import (DeviceNormalActionNoise, LegacyStreamNormalActionNoise, NormalActionNoise,
+                                       VectorizedActionNoise)
 
-        if isinstance(self.action_noise, NormalActionNoise) and self._fast_path():
-            # memoryless Gaussian noise: one device draw for all envs instead of n_envs host draws per vec-step
-            self.action_noise = DeviceNormalActionNoise(self.action_noise._mu, self.action_noise._sigma, self.env.num_envs, self.device)
+        base = self.action_noise
+        if isinstance(base, VectorizedActionNoise) and base.n_envs == self.env.num_envs:
+            base = base.base_noise
+        if isinstance(base, NormalActionNoise) and self._fast_path() and np.size(base._mu) <= 8:
+            # the reference's n_envs sequential np.random.normal draws per vec-step (noise.py:44-45, :141-142) as one
+            # kernel on the HBM image of the same legacy stream the replay sampler uses: bit-faithful interleaving
+            self.action_noise = LegacyStreamNormalActionNoise(base._mu, base._sigma, self.env.num_envs, self.device,
+                                                              lambda: self.replay_buffer.sampler_stream)
         elif self.action_noise is not None and self.env.num_envs > 1 and not hasattr(self.action_noise, "noises") \
-                and not isinstance(self.action_noise, DeviceNormalActionNoise):
+                and not isinstance(self.action_noise, (DeviceNormalActionNoise, LegacyStreamNormalActionNoise)):
             self.action_noise = VectorizedActionNoise(self.action_noise, self.env.num_envs)
         return super()._setup_learn(total_timesteps, callback, reset_num_timesteps, tb_log_name, progress_bar)
 
@@ -162,10 +168,10 @@ class OffPolicyAlgorithm(BaseAlgorithm):
         self._graph = None
 
     def _graph_eligible(self, callback: BaseCallback) -> bool:
-        from core.common.noise import DeviceNormalActionNoise
+        from core.common.noise import DeviceNormalActionNoise, LegacyStreamNormalActionNoise
 
         return (self._fast_path() and getattr(callback, "is_noop", False)
-                and (self.action_noise is None or isinstance(self.action_noise, DeviceNormalActionNoise))
+                and (self.action_noise is None or isinstance(self.action_noise, (DeviceNormalActionNoise, LegacyStreamNormalActionNoise)))
                 and self.train_freq == TrainFreq(1, TrainFrequencyUnit.STEP)
                 and self.gradient_steps >= 1 and self.num_timesteps >= self.learning_starts
                 and self.num_timesteps + self.n_envs > self.learning_starts and not getattr(self, "debug_capture", False))

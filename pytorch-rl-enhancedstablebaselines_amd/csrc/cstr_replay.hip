@@ -154,6 +154,114 @@ __global__ __launch_bounds__(TPB) void replay_sample_kernel(const cstr_ring_t ri
     }
 }
 
+// ---- np.random.normal on the same stream (exploration noise, core/common/noise.py:44-45, :141-142) -----------------
+// numpy's legacy_gauss is the polar Box-Muller method: an attempt eats two 53-bit doubles (four 32-bit words), is
+// rejected with probability 1 - pi/4, and an accepted attempt yields TWO deviates (f*x2 first, f*x1 cached for the next
+// call). Attempts are independent, so one round evaluates every 4-word group of the words left in the current 624-word
+// block in parallel (<= 156 lanes), and the same ballot/popcount prefix sum as the index draw assigns accepted attempts
+// to output slots in stream order. Groups that straddle a twist are handled by carrying the <= 3 left-over words to the
+// front of the window. The f64 arithmetic of the accept test is exact IEEE (the TU is built with -ffp-contract=off), so
+// the stream position follows numpy word for word; log() is ocml's (<= 1 ulp in f64, invisible after the f32 cast).
+struct NormalParams { double loc[CSTR_MAX_NOISE_PERIOD], scale[CSTR_MAX_NOISE_PERIOD]; int period; };
+
+struct NormalShared {
+    uint32_t mt[MT_N];
+    uint32_t win[MT_N + 4];
+    int wave_tot[TPB / 64];
+    int consumed, has_gauss;
+    double gauss;
+};
+
+__global__ __launch_bounds__(TPB) void mt_normal_kernel(uint32_t *__restrict__ mt_state, const NormalParams prm,
+                                                        float *__restrict__ out, const int64_t count)
+{
+    __shared__ NormalShared sh;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, P = prm.period;
+    for (int i = t; i < MT_N; i += TPB) sh.mt[i] = mt_state[i];
+    int pos = (int)mt_state[MT_N];
+    const int has0 = (int)mt_state[MT_N + 1];
+    if (t == 0) {
+        sh.has_gauss = has0;
+        sh.gauss = __hiloint2double((int)mt_state[MT_N + 3], (int)mt_state[MT_N + 2]);
+    }
+    __syncthreads();
+    int64_t j = 0;
+    if (has0 && count > 0) {  // the cached deviate of the previous call comes first
+        if (t == 0) {
+            out[0] = (float)(prm.loc[0] + prm.scale[0] * sh.gauss);
+            sh.has_gauss = 0;
+            sh.gauss = 0.0;
+        }
+        j = 1;
+    }
+    int64_t pairs = (count - j + 1) >> 1;
+    int nwin = 0, wpos = 0;
+    bool filled = false;
+    while (pairs > 0) {  // every quantity in the loop condition is workgroup-uniform
+        const int rem = nwin - wpos;
+        if (rem < 4) {
+            uint32_t c = 0;
+            if (t < rem) c = sh.win[wpos + t];
+            __syncthreads();
+            if (t < rem) sh.win[t] = c;
+            if (pos == MT_N) { mt_twist(sh.mt); pos = 0; }
+            const int blk = MT_N - pos;
+            for (int i = t; i < blk; i += TPB) sh.win[rem + i] = mt_temper(sh.mt[pos + i]);
+            nwin = rem + blk; wpos = 0; pos = MT_N; filled = true;
+            __syncthreads();
+        }
+        const int natt = (nwin - wpos) >> 2;
+        bool acc = false;
+        double x1 = 0.0, x2 = 0.0, r2 = 1.0;
+        if (t < natt) {
+            const uint32_t *w = sh.win + wpos + 4 * t;
+            // mt19937_next_double: (a * 2^26 + b) / 2^53 with a = w0 >> 5, b = w1 >> 6
+            const double d1 = ((double)(int)(w[0] >> 5) * 67108864.0 + (double)(int)(w[1] >> 6)) / 9007199254740992.0;
+            const double d2 = ((double)(int)(w[2] >> 5) * 67108864.0 + (double)(int)(w[3] >> 6)) / 9007199254740992.0;
+            x1 = 2.0 * d1 - 1.0;
+            x2 = 2.0 * d2 - 1.0;
+            r2 = x1 * x1 + x2 * x2;
+            acc = !(r2 >= 1.0 || r2 == 0.0);
+        }
+        const unsigned long long bal = __ballot(acc);
+        const int in_wave = __popcll(bal & ((1ULL << lane) - 1ULL));
+        if (lane == 0) sh.wave_tot[wave] = __popcll(bal);
+        if (t == 0) sh.consumed = natt;
+        __syncthreads();
+        int before = 0, total = 0;
+#pragma unroll
+        for (int wv = 0; wv < TPB / 64; ++wv) {
+            const int c = sh.wave_tot[wv];
+            if (wv < wave) before += c;
+            total += c;
+        }
+        const int rank = before + in_wave;
+        if (acc && rank < pairs) {
+            const double f = sqrt(-2.0 * log(r2) / r2);
+            const int64_t e0 = j + 2 * (int64_t)rank;
+            const int p0 = (int)(e0 % P), p1 = (int)((e0 + 1) % P);
+            out[e0] = (float)(prm.loc[p0] + prm.scale[p0] * (f * x2));
+            if (e0 + 1 < count) out[e0 + 1] = (float)(prm.loc[p1] + prm.scale[p1] * (f * x1));
+            else { sh.has_gauss = 1; sh.gauss = f * x1; }  // odd tail: keep the first deviate for the next call
+            if (rank == pairs - 1) sh.consumed = t + 1;
+        }
+        __syncthreads();
+        wpos += 4 * sh.consumed;
+        const int took = (int)(total < pairs ? total : pairs);
+        j += 2 * (int64_t)took;
+        pairs -= took;
+        __syncthreads();  // sh.consumed / wave_tot are rewritten next round
+    }
+    if (filled) pos = MT_N - (nwin - wpos);  // unconsumed window words are the tail of the current block
+    for (int i = t; i < MT_N; i += TPB) mt_state[i] = sh.mt[i];
+    if (t == 0) {
+        mt_state[MT_N] = (uint32_t)pos;
+        mt_state[MT_N + 1] = (uint32_t)sh.has_gauss;
+        mt_state[MT_N + 2] = (uint32_t)__double2loint(sh.gauss);
+        mt_state[MT_N + 3] = (uint32_t)__double2hiint(sh.gauss);
+    }
+}
+
 // init_genrand (mt19937_seed): serial recurrence, 624 steps, one lane; runs once per (re)seed.
 __global__ void mt_seed_kernel(uint32_t *__restrict__ mt_state, uint32_t seed)
 {
@@ -165,6 +273,9 @@ __global__ void mt_seed_kernel(uint32_t *__restrict__ mt_state, uint32_t seed)
         mt_state[i] = x;
     }
     mt_state[MT_N] = MT_N;
+    mt_state[MT_N + 1] = 0;  // has_gauss, gauss (f64) of the legacy stream
+    mt_state[MT_N + 2] = 0;
+    mt_state[MT_N + 3] = 0;
 }
 
 }  // namespace
@@ -173,6 +284,23 @@ extern "C" int cstr_mt19937_seed(uint32_t *mt_state, uint32_t seed, cstr_stream_
 {
     if (!mt_state) return CSTR_E_BADARG;
     mt_seed_kernel<<<1, 64, 0, (hipStream_t)stream>>>(mt_state, seed);
+    return (int)hipGetLastError();
+}
+
+extern "C" int cstr_mt19937_normal_f32(uint32_t *mt_state, const double *loc, const double *scale, int32_t period, float *out,
+                                       int64_t count, cstr_stream_t stream)
+{
+    if (!mt_state || !loc || !scale || !out || count < 0) return CSTR_E_BADARG;
+    if (period < 1 || period > CSTR_MAX_NOISE_PERIOD) return CSTR_E_UNSUPPORTED;
+    if (count == 0) return CSTR_OK;
+    NormalParams prm;
+    for (int i = 0; i < CSTR_MAX_NOISE_PERIOD; ++i) {
+        prm.loc[i] = loc[i % period];
+        prm.scale[i] = scale[i % period];
+        if (i < period && !(scale[i] >= 0.0)) return CSTR_E_BADARG;  // numpy: "scale < 0"
+    }
+    prm.period = period;
+    mt_normal_kernel<<<1, TPB, 0, (hipStream_t)stream>>>(mt_state, prm, out, count);
     return (int)hipGetLastError();
 }
 

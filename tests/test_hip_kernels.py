@@ -158,7 +158,7 @@ def test_replay_add_sample_vs_golden(ops, golden, tag):
     g = golden("replay_kat.npz")
     R, N, D, A, n_add, B = (int(x) for x in g[f"{tag}_dims"])
     ring = _mk_ring(ops, R, N, D)
-    mt = th.zeros(625, dtype=th.int32, device="cuda")
+    mt = th.zeros(628, dtype=th.int32, device="cuda")
     ops.mt19937_seed(mt, int(g["seed"]))
     outs = [th.empty(B, D, device="cuda"), th.empty(B, A, device="cuda"), th.empty(B, D, device="cuda"),
             th.empty(B, 1, device="cuda"), th.empty(B, 1, device="cuda")]
@@ -183,7 +183,7 @@ def test_mt19937_index_stream_vs_numpy_golden(ops, golden):
         calls = g[f"c{ci}_calls"]
         if len(calls) % 2 or calls.max() >= 2**32 - 1 or (calls[0::2, 1] != calls[1::2, 1]).any():
             continue  # the device sampler draws (rows, envs) pairs of equal batch on the 32-bit path
-        mt = th.zeros(625, dtype=th.int32, device="cuda")
+        mt = th.zeros(628, dtype=th.int32, device="cuda")
         ops.mt19937_seed(mt, int(g[f"c{ci}_seed"]))
         got = []
         for (upper, B), (n_envs, _) in zip(calls[0::2], calls[1::2]):
@@ -221,7 +221,7 @@ def test_sampler_vs_oracle_random_fill(ops, seed, R, N, B):
              (rng.uniform(size=N) < 0.3).astype(np.float32), (rng.uniform(size=N) < 0.2).astype(np.float32)]
         oring.add(*f)
         ops.replay_add(ring, *[dev(x) for x in f])
-    mt, omt = th.zeros(625, dtype=th.int32, device="cuda"), orc.MT19937(seed + N - 1)
+    mt, omt = th.zeros(628, dtype=th.int32, device="cuda"), orc.MT19937(seed + N - 1)
     ops.mt19937_seed(mt, seed + N - 1)  # effective stream seed of an end-to-end run (SURVEY a-6)
     bi, ei = th.empty(B, dtype=th.int64, device="cuda"), th.empty(B, dtype=th.int64, device="cuda")
     outs = [th.empty(B, D, device="cuda"), th.empty(B, 2, device="cuda"), th.empty(B, D, device="cuda"),
@@ -402,7 +402,7 @@ def test_ops_reject_bad_shapes(ops):
         ops.DeviceRing(4, 4, 5, 2, "cuda")
     ring = ops.DeviceRing(4, 4, 4, 2, "cuda")
     with pytest.raises(ValueError):
-        ops.replay_sample(ring, th.zeros(625, dtype=th.int32, device="cuda"), 1 << 15,
+        ops.replay_sample(ring, th.zeros(628, dtype=th.int32, device="cuda"), 1 << 15,
                           *(th.zeros(1 << 15, k, device="cuda") for k in (4, 2, 4, 1, 1)))
 
 
@@ -464,7 +464,7 @@ def test_twin_layout_vec_step_collect_and_sampler(ops):
     # make the oracle ring bit-identical to the device ring, then sample both
     oring.next_observations[...] = ring.next_observations.cpu().numpy()
     oring.rewards[...] = ring.rewards.cpu().numpy()
-    mt, omt = th.zeros(625, dtype=th.int32, device="cuda"), orc.MT19937(77)
+    mt, omt = th.zeros(628, dtype=th.int32, device="cuda"), orc.MT19937(77)
     ops.mt19937_seed(mt, 77)
     B = 200
     outs = [th.empty(B, 8, device="cuda"), th.empty(B, 4, device="cuda"), th.empty(B, 8, device="cuda"),
@@ -474,6 +474,48 @@ def test_twin_layout_vec_step_collect_and_sampler(ops):
         exp, _ = oring.sample(omt, B)
         for t, x in zip(outs, exp):
             np.testing.assert_array_equal(t.cpu().numpy(), x)
+
+
+@pytest.mark.parametrize("seed,act_dim,n_envs", [(0, 2, 4096), (7, 2, 1), (42, 3, 5), (123, 1, 33), (2**32 - 1, 4, 1024), (5, 2, 77)])
+def test_mt19937_legacy_normal_interleaved_with_sampler_vs_numpy(ops, seed, act_dim, n_envs):
+    """Exploration noise from the legacy global stream (noise.py:44-45, :141-142) interleaved with ReplayBuffer.sample's
+    index draws (buffers.py:113, :309), checked live against numpy's RandomState: f32 noise values, indices, the cached
+    second deviate of odd counts and the final key / position are all bit-identical."""
+    rs = np.random.RandomState(seed)
+    mt = th.zeros(628, dtype=th.int32, device="cuda")
+    ops.mt19937_seed(mt, seed)
+    mu, sigma = np.linspace(-0.5, 0.5, act_dim), np.linspace(0.1, 0.3, act_dim)
+    R, B = 16, 64
+    ring = _mk_ring(ops, R, n_envs, 4)
+    z = th.zeros(n_envs, 4, device="cuda")
+    ops.replay_add(ring, z, z, th.zeros(n_envs, 2, device="cuda"), th.zeros(n_envs, device="cuda"), th.zeros(n_envs, device="cuda"),
+                   th.zeros(n_envs, device="cuda"))
+    ring.ctl[0], ring.ctl[1] = 0, 1  # full ring: upper = R
+    outs = [th.empty(B, 4, device="cuda"), th.empty(B, 2, device="cuda"), th.empty(B, 4, device="cuda"),
+            th.empty(B, 1, device="cuda"), th.empty(B, 1, device="cuda")]
+    ri, ei = th.empty(B, dtype=th.int64, device="cuda"), th.empty(B, dtype=th.int64, device="cuda")
+    out = th.empty(n_envs, act_dim, device="cuda")
+    for it in range(6):
+        ops.mt19937_normal(mt, mu, sigma, out)
+        want = np.stack([rs.normal(mu, sigma).astype(np.float32) for _ in range(n_envs)])
+        np.testing.assert_array_equal(out.cpu().numpy(), want, err_msg=f"noise draw {it}")
+        ops.replay_sample(ring, mt, B, *outs, ri, ei)
+        np.testing.assert_array_equal(ri.cpu().numpy(), rs.randint(0, R, size=B))
+        np.testing.assert_array_equal(ei.cpu().numpy(), rs.randint(0, n_envs, size=B))
+    st, w = rs.get_state(), mt.cpu().numpy().view(np.uint32)
+    np.testing.assert_array_equal(w[:624], st[1])
+    assert (int(w[624]), int(w[625])) == (st[2], st[3])
+    assert abs(float(w[626:628].view(np.float64)[0]) - st[4]) <= 4e-16 * abs(st[4])
+
+
+def test_mt19937_normal_rejects_bad_arguments(ops):
+    mt = th.zeros(628, dtype=th.int32, device="cuda")
+    with pytest.raises(ValueError):
+        ops.mt19937_normal(mt, [0.0] * 9, [1.0] * 9, th.empty(4, 9, device="cuda"))
+    with pytest.raises(ValueError):
+        ops.mt19937_normal(mt, [0.0, 0.0], [1.0, -1.0], th.empty(4, 2, device="cuda"))
+    with pytest.raises(ValueError):
+        ops.mt19937_normal(th.zeros(625, dtype=th.int32, device="cuda"), [0.0], [1.0], th.empty(4, 1, device="cuda"))
 
 
 def test_twin_layout_reset_draw(ops):

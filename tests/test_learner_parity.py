@@ -437,18 +437,58 @@ def test_evaluate_policy_on_device_env():
 def test_td3_with_normal_action_noise_runs_on_device_and_in_graph():
     """The reference's own CSTR recipe uses TD3 + NormalActionNoise(sigma=0.1) (experiments/basic_test/
     TwoSeriesCSTR_TD3.py:31-36): the noise is drawn on the device, clipped into [-1, 1] by the collect kernel."""
-    from core.common.noise import DeviceNormalActionNoise, NormalActionNoise
+    from core.common.noise import DeviceNormalActionNoise
     from core.common.vec_env import CSTRVecEnv
     from core.td3 import TD3
 
     env = CSTRVecEnv(256)
-    model = TD3("MlpPolicy", env, seed=0, batch_size=64, buffer_size=256 * 16, action_noise=NormalActionNoise(np.zeros(2), 0.1 * np.ones(2)),
-                policy_kwargs=dict(net_arch=[32, 32]))
+    model = TD3("MlpPolicy", env, seed=0, batch_size=64, buffer_size=256 * 16,
+                action_noise=DeviceNormalActionNoise(np.zeros(2), 0.1 * np.ones(2), 256, "cuda"), policy_kwargs=dict(net_arch=[32, 32]))
     model.enable_graph_capture()
     model.learn(256 * 14)
     assert isinstance(model.action_noise, DeviceNormalActionNoise) and len(model._graph) == 2
     a = model.replay_buffer.actions
     assert float(a.abs().max()) <= 1.0 and float(a.std()) > 0.05 and model._n_updates == 14
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_td3_reference_noise_recipe_keeps_the_legacy_stream_bit_faithful(graph):
+    """TD3 + NormalActionNoise(sigma=0.1) is the reference's own CSTR recipe (TwoSeriesCSTR_TD3.py:31-36). Its noise is
+    n_envs np.random.normal calls per vec-step on the global stream the replay sampler also draws from: after a seeded
+    learn() the device stream must sit exactly where numpy's would (noise pairs, then the two randint draws of every
+    gradient step), and the warm-up actions in the ring must carry numpy's noise values."""
+    from core.common import legacy_rng
+    from core.common.noise import LegacyStreamNormalActionNoise, NormalActionNoise
+    from core.common.vec_env import CSTRVecEnv
+    from core.td3 import TD3
+
+    N, B, seed, iters, R = 64, 32, 5, 30, 40
+    env = CSTRVecEnv(N)
+    model = TD3("MlpPolicy", env, seed=seed, batch_size=B, buffer_size=N * R, learning_starts=N * 4,
+                action_noise=NormalActionNoise(np.zeros(2), 0.1 * np.ones(2)), policy_kwargs=dict(net_arch=[32, 32]))
+    if graph:
+        model.enable_graph_capture()
+    model.learn(N * iters)
+    assert isinstance(model.action_noise, LegacyStreamNormalActionNoise)
+    assert (len(model._graph) == 2) if graph else not model._graph
+    rs = np.random.RandomState(seed + N - 1)
+    noise = []
+    for k in range(1, iters + 1):
+        noise.append(np.stack([rs.normal(np.zeros(2), 0.1 * np.ones(2)).astype(np.float32) for _ in range(N)]))
+        if k * N > N * 4:  # trains once num_timesteps > learning_starts (off_policy_algorithm.py:343)
+            rs.randint(0, min(k, R), size=B)
+            rs.randint(0, N, size=B)
+    st, w = rs.get_state(), legacy_rng.global_stream(model.device).cpu().numpy().view(np.uint32)
+    np.testing.assert_array_equal(w[:624], st[1])
+    assert (int(w[624]), int(w[625])) == (st[2], st[3]) and model._n_updates == iters - 4
+    # warm-up rows: stored action = clip(scale(space sample) + noise, -1, 1) (off_policy_algorithm.py:386-399); the same
+    # seeded run without noise gives the space samples, numpy gives the noise
+    env0 = CSTRVecEnv(N)
+    m0 = TD3("MlpPolicy", env0, seed=seed, batch_size=B, buffer_size=N * R, learning_starts=10**9, policy_kwargs=dict(net_arch=[32, 32]))
+    m0.learn(N * 4)
+    a, a0 = model.replay_buffer.actions.cpu().numpy(), m0.replay_buffer.actions.cpu().numpy()
+    for k in range(4):
+        np.testing.assert_array_equal(a[k], np.clip(a0[k] + noise[k], np.float32(-1), np.float32(1)))
 
 
 def test_maddpg_hipgraph_capture():

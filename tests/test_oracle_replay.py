@@ -35,6 +35,23 @@ def test_mt19937_live_vs_numpy(seed):
     assert mt.pos == st[2]
 
 
+@pytest.mark.parametrize("seed,act_dim,n_envs", [(0, 2, 64), (7, 2, 1), (42, 3, 5), (123, 1, 33), (2**32 - 1, 4, 16)])
+def test_mt19937_legacy_normal_interleaved_with_randint_vs_numpy(seed, act_dim, n_envs):
+    """VectorizedActionNoise(NormalActionNoise) (noise.py:44-45, :141-142) draws n_envs x np.random.normal(mu, sigma) from
+    the SAME global stream as ReplayBuffer.sample's randint (buffers.py:113, :309): values (f32, bit-exact on this
+    libm), the cached second deviate (odd counts) and the stream position must all follow numpy."""
+    rs, mt = np.random.RandomState(seed), orc.MT19937(seed)
+    mu, sigma = np.linspace(-0.5, 0.5, act_dim), np.linspace(0.1, 0.3, act_dim)
+    for it in range(12):
+        want = np.stack([rs.normal(mu, sigma).astype(np.float32) for _ in range(n_envs)])
+        np.testing.assert_array_equal(mt.normal(mu, sigma, n_envs), want)
+        np.testing.assert_array_equal(mt.randint(244, 256), rs.randint(0, 244, size=256))
+        np.testing.assert_array_equal(mt.randint(n_envs, 256), rs.randint(0, n_envs, size=256))
+    st = rs.get_state()
+    np.testing.assert_array_equal(mt.key, st[1])
+    assert (mt.pos, int(mt.st.has_gauss), float(mt.st.gauss)) == (st[2], st[3], st[4])
+
+
 def test_survey_index_example():
     """seed 0, upper 244, B 256 -> 266 words; then n_envs 4096 -> 256 words."""
     mt = orc.MT19937(0)
