@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define CSTR_ABI_VERSION 1
+#define CSTR_ABI_VERSION 2
 
 #define CSTR_OK 0
 #define CSTR_E_BADARG (-1)      /* null pointer / non-positive size / misaligned buffer */
@@ -92,11 +92,13 @@ int cstr_vec_step_f32(const cstr_coef_t *coef, int integrator, int obs_dim, int 
                       int32_t *step_count, const float *reset_obs, float *next_obs, float *obs_after, float *reward,
                       float *done, float *timeout, int64_t n_envs, cstr_stream_t stream);
 
-/* TwoSeriesCSTREnv.reset draws for envs with mask[i] != 0 (mask NULL = all): generate_initial_state
- * with init_mode="random" (twoseriescstr.py:187-224, :267) from per-env numpy-PCG64 states that the
- * host seeds exactly like gymnasium.utils.seeding.np_random(seed + i) (:162). */
-int cstr_reset_draw_f32(uint64_t *pcg_state, const uint8_t *mask, int obs_dim, int act_dim, float *obs_out, int64_t n_envs,
-                        cstr_stream_t stream);
+/* TwoSeriesCSTREnv.reset draws for envs with mask[i] != 0 (mask NULL = all) from per-env numpy-PCG64 states that the
+ * host seeds exactly like gymnasium.utils.seeding.np_random(seed + i) (twoseriescstr.py:162):
+ *   static_init NULL: init_mode="random", generate_initial_state (twoseriescstr.py:187-224, :267);
+ *   static_init double[N][4 per train] i/o: init_mode="static" (:94-96, :246-255) -- the env's f64 `init_state`
+ *   (constructed as {0.45, 310, 0.25, 290}) takes an in-place uniform step at every reset, like the reference's. */
+int cstr_reset_draw_f32(uint64_t *pcg_state, const uint8_t *mask, double *static_init, int obs_dim, int act_dim,
+                        float *obs_out, int64_t n_envs, cstr_stream_t stream);
 
 /* ReplayBuffer.add (core/common/buffers.py:247-283) at the device-resident ring position; the last
  * workgroup advances ring_ctl (pos, full). */
@@ -116,6 +118,7 @@ int cstr_replay_add_f32(const cstr_ring_t *ring, int64_t *ring_ctl, const float 
  *   act_low/act_high [act_dim] in : HOST pointers, bounds of the algorithm-facing action space
  *   noise [N][act_dim] or NULL : added to the scaled action, then clip [-1,1] (off_policy_algorithm.py:401-402)
  *   reset_obs  [N][obs_dim] or NULL, pcg_state [N][4] or NULL: reset source (exactly one non-NULL)
+ *   static_init double[N][4 per train] or NULL: with pcg_state, init_mode="static" (see cstr_reset_draw_f32)
  *   reward_out/done_out [N] or NULL: per-env copies (what VecEnv.step would have returned)
  *   ep_return [N] + ep_stats double[4] = {episodes, sum of returns, sum of lengths, -} or both NULL: device-side
  *                                episode statistics (Monitor's info["episode"], core/common/monitor.py:96-109; the
@@ -123,8 +126,8 @@ int cstr_replay_add_f32(const cstr_ring_t *ring, int64_t *ring_ctl, const float 
 int cstr_collect_step_f32(const cstr_coef_t *coef, int integrator, const cstr_ring_t *ring, int64_t *ring_ctl,
                           float *env_obs, int32_t *step_count, const float *policy_out, int squashed,
                           const float *act_low, const float *act_high, const float *noise, const float *reset_obs,
-                          uint64_t *pcg_state, float *reward_out, float *done_out, float *ep_return, double *ep_stats,
-                          cstr_stream_t stream);
+                          uint64_t *pcg_state, double *static_init, float *reward_out, float *done_out, float *ep_return,
+                          double *ep_stats, cstr_stream_t stream);
 
 /* np.random.seed(seed) for the device-resident legacy MT19937 state (core/common/utils.py:46;
  * twoseriescstr.py:164 reseeds the same global stream). */

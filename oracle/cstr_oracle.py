@@ -196,11 +196,17 @@ def pcg64_states_from_seeds(seeds) -> np.ndarray:
     return out
 
 
-def reset_draw(pcg_states: np.ndarray, mask=None) -> np.ndarray:
+STATIC_INIT_STATE = (0.45, 310.0, 0.25, 290.0)  # twoseriescstr.py:96
+
+
+def reset_draw(pcg_states: np.ndarray, mask=None, static_init=None) -> np.ndarray:
+    """static_init: f64 [n, 4] = every env's `init_state` (init_mode="static"), updated in place; None = "random"."""
     n = len(pcg_states)
     obs = np.zeros((n, 4), np.float32)
     mk = None if mask is None else np.ascontiguousarray(mask, np.uint8)
-    lib().cstr_reset_draw_batch_cpu(_p(pcg_states), _p(mk), _p(obs), C.c_int64(n))
+    if static_init is not None:
+        assert static_init.dtype == np.float64 and static_init.shape == (n, 4) and static_init.flags.c_contiguous
+    lib().cstr_reset_draw_batch_cpu(_p(pcg_states), _p(mk), _p(static_init), _p(obs), C.c_int64(n))
     return obs
 
 

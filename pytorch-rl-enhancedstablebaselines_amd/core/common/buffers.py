@@ -85,6 +85,46 @@ class ReplayBuffer(BaseBuffer):
         self.rewards, self.dones, self.timeouts = r.rewards, r.dones, r.timeouts
         self._stream = sampler_stream
 
+    # ---- pickling (save_replay_buffer / load_replay_buffer, off_policy_algorithm.py:214-254) -------------
+    _FIELDS = ("observations", "next_observations", "actions", "rewards", "dones", "timeouts")
+
+    def __getstate__(self) -> dict:
+        """The pickled form carries the reference's attributes (buffers.py:212-234) as host NumPy arrays with the
+        reference's shapes [rows, n_envs, ...], `pos` and `full`; the HBM ring is rebuilt on load."""
+        st = {k: getattr(self, k) for k in ("buffer_size", "observation_space", "action_space", "obs_shape", "action_dim", "n_envs",
+                                            "optimize_memory_usage", "handle_timeout_termination")}
+        st.update({k: getattr(self, k).cpu().numpy() for k in self._FIELDS})
+        st.update(pos=self.pos, full=self.full, device=str(self.device), adds=self._adds,
+                  sampler_stream=None if self._stream is None else self._stream.cpu().numpy())
+        return st
+
+    def __setstate__(self, st: dict) -> None:
+        for k in ("buffer_size", "observation_space", "action_space", "obs_shape", "action_dim", "n_envs", "optimize_memory_usage",
+                  "handle_timeout_termination"):
+            setattr(self, k, st[k])
+        self.device = get_device(st.get("device", "auto"))
+        with th.cuda.device(self.device):
+            self.ring = hip_ops.DeviceRing(self.buffer_size, self.n_envs, self.obs_shape[0], self.action_dim, self.device)
+        r = self.ring
+        self.observations, self.next_observations, self.actions = r.observations, r.next_observations, r.actions
+        self.rewards, self.dones, self.timeouts = r.rewards, r.dones, r.timeouts
+        for k in self._FIELDS:
+            getattr(self, k).copy_(th.from_numpy(np.ascontiguousarray(st[k], dtype=np.float32)).reshape(getattr(self, k).shape))
+        # a pickle written by the reference has pos/full only; `adds` keeps the device's running add counter exact
+        self._adds = int(st.get("adds", st["pos"] + (self.buffer_size if st["full"] else 0)))
+        r.ctl.copy_(th.tensor([int(st["pos"]), int(bool(st["full"])), 0, self._adds], dtype=th.int64))
+        ss = st.get("sampler_stream")
+        self._stream = None if ss is None else th.from_numpy(np.ascontiguousarray(ss)).to(self.device)
+
+    def to(self, device) -> "ReplayBuffer":
+        """Move the ring to another GPU (load_replay_buffer: 'update saved replay buffer device', :252-253)."""
+        device = get_device(device)
+        if device != self.device:
+            st = self.__getstate__()
+            st["device"] = str(device)
+            self.__setstate__(st)
+        return self
+
     # ---- sampler stream ---------------------------------------------------------------------------------
     @property
     def sampler_stream(self) -> th.Tensor:

@@ -67,14 +67,15 @@ def vec_step(coef, integrator: str, obs, act, step_count, reset_obs, next_obs, o
                                      ptr(done), ptr(timeout), C.c_int64(n), stream_ptr()), "cstr_vec_step_f32")
 
 
-def reset_draw(pcg_state, mask, obs_out, act_dim: int = 2):
+def reset_draw(pcg_state, mask, obs_out, act_dim: int = 2, static_init=None):
     n, d = obs_out.shape
     if (d, act_dim) not in LAYOUTS:
         raise ValueError(f"(obs_dim, act_dim) = {(d, act_dim)} is not a CSTR layout {LAYOUTS}")
     _chk(pcg_state, "pcg_state", (n, nv.PCG_STATE_WORDS), th.int64), _chk(obs_out, "obs_out", (n, d), th.float32)
     _opt(mask, "mask", (n,), th.uint8)
-    check(nv.lib().cstr_reset_draw_f32(ptr(pcg_state), ptr(mask), C.c_int(d), C.c_int(act_dim), ptr(obs_out), C.c_int64(n), stream_ptr()),
-          "cstr_reset_draw_f32")
+    _opt(static_init, "static_init", (n, 8 if act_dim == 4 else 4), th.float64)
+    check(nv.lib().cstr_reset_draw_f32(ptr(pcg_state), ptr(mask), ptr(static_init), C.c_int(d), C.c_int(act_dim), ptr(obs_out),
+                                       C.c_int64(n), stream_ptr()), "cstr_reset_draw_f32")
 
 
 def replay_add(ring: DeviceRing, obs, next_obs, act, rew, done, timeout):
@@ -88,12 +89,15 @@ def replay_add(ring: DeviceRing, obs, next_obs, act, rew, done, timeout):
 
 def collect_step(coef, integrator: str, ring: DeviceRing, env_obs, step_count, policy_out, squashed, act_low,
                  act_high, noise=None, reset_obs=None, pcg_state=None, reward_out=None, done_out=None, ep_return=None,
-                 ep_stats=None):
+                 ep_stats=None, static_init=None):
     n, d, a = ring.n_envs, ring.obs_dim, ring.act_dim
     _chk(env_obs, "env_obs", (n, d), th.float32), _chk(step_count, "step_count", (n,), th.int32)
     _chk(policy_out, "policy_out", (n, a), th.float32)
     _opt(noise, "noise", (n, a), th.float32), _opt(reset_obs, "reset_obs", (n, d), th.float32)
     _opt(pcg_state, "pcg_state", (n, nv.PCG_STATE_WORDS), th.int64)
+    _opt(static_init, "static_init", (n, 8 if a == 4 else 4), th.float64)
+    if static_init is not None and pcg_state is None:
+        raise ValueError("static_init (init_mode='static') needs the per-env pcg_state reset source")
     _opt(reward_out, "reward_out", (n,), th.float32), _opt(done_out, "done_out", (n,), th.float32)
     _opt(ep_return, "ep_return", (n,), th.float32), _opt(ep_stats, "ep_stats", (4,), th.float64)
     if (ep_return is None) != (ep_stats is None):
@@ -106,7 +110,7 @@ def collect_step(coef, integrator: str, ring: DeviceRing, env_obs, step_count, p
     hi = (C.c_float * a)(*[float(v) for v in act_high])
     check(nv.lib().cstr_collect_step_f32(C.byref(coef), C.c_int(INTEGRATORS[integrator]), C.byref(ring.c), ptr(ring.ctl),
                                          ptr(env_obs), ptr(step_count), ptr(policy_out), C.c_int(int(squashed)), lo, hi,
-                                         ptr(noise), ptr(reset_obs), ptr(pcg_state), ptr(reward_out), ptr(done_out),
+                                         ptr(noise), ptr(reset_obs), ptr(pcg_state), ptr(static_init), ptr(reward_out), ptr(done_out),
                                          ptr(ep_return), ptr(ep_stats), stream_ptr()), "cstr_collect_step_f32")
 
 

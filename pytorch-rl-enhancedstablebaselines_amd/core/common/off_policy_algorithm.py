@@ -101,6 +101,22 @@ class OffPolicyAlgorithm(BaseAlgorithm):
         self._ep_return = th.zeros(n, dtype=th.float32, device=self.device)
         self._ep_stats = th.zeros(4, dtype=th.float64, device=self.device)
 
+    def save_replay_buffer(self, path) -> None:
+        """reference: off_policy_algorithm.py:214-222"""
+        from core.common.save_util import save_to_pkl
+
+        assert self.replay_buffer is not None, "The replay buffer is not defined"
+        save_to_pkl(path, self.replay_buffer, self.verbose)
+
+    def load_replay_buffer(self, path, truncate_last_traj: bool = True) -> None:
+        """reference: off_policy_algorithm.py:224-254 (HerReplayBuffer is out of scope)"""
+        from core.common.save_util import load_from_pkl
+
+        self.replay_buffer = load_from_pkl(path, self.verbose)
+        assert isinstance(self.replay_buffer, ReplayBuffer), "The replay buffer must inherit from ReplayBuffer class"
+        self.replay_buffer.to(self.device)  # :252-253
+        self._graph = None  # captured graphs hold the old ring's pointers
+
     def _fast_path(self) -> bool:
         rb = self.replay_buffer
         return (isinstance(self.env, CSTRVecEnv) and type(rb) is ReplayBuffer and rb.n_envs == self.env.num_envs
@@ -182,7 +198,7 @@ class OffPolicyAlgorithm(BaseAlgorithm):
         pol = self._policy_out_device(env.obs)
         noise = None if self.action_noise is None else self.action_noise().contiguous()
         hip_ops.collect_step(env.coef, env.integrator, rb.ring, env.obs, env.step_count, pol, self._action_mode(False),
-                             self.action_space.low, self.action_space.high, noise=noise, pcg_state=env.pcg_state, reward_out=env._rew, done_out=env._done,
+                             self.action_space.low, self.action_space.high, noise=noise, pcg_state=env.pcg_state, static_init=env.static_init, reward_out=env._rew, done_out=env._done,
                              ep_return=self._ep_return, ep_stats=self._ep_stats)
         self.policy.set_training_mode(True)
         self._train_device_only(self.gradient_steps, self.batch_size)
@@ -412,7 +428,7 @@ class OffPolicyAlgorithm(BaseAlgorithm):
             noise = noise.to(self.device, th.float32).reshape(n, -1).contiguous()
         with th.cuda.device(self.device):
             hip_ops.collect_step(env.coef, env.integrator, rb.ring, env.obs, env.step_count, pol, squashed,
-                                 self.action_space.low, self.action_space.high, noise=noise, pcg_state=env.pcg_state,
+                                 self.action_space.low, self.action_space.high, noise=noise, pcg_state=env.pcg_state, static_init=env.static_init,
                                  reward_out=env._rew, done_out=env._done, ep_return=self._ep_return, ep_stats=self._ep_stats)
         rb.note_fused_add()
         self._last_obs = env.obs

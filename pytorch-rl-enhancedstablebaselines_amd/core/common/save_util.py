@@ -84,3 +84,42 @@ def load_from_zip_file(path, device="cpu") -> Tuple[dict, dict, dict]:
             else:
                 params[name[:-4]] = obj
     return data, params, variables
+
+
+def _open_path(path, mode: str, suffix: str):
+    """reference: save_util.py:205-292 (open_path): str / pathlib paths get the suffix when they have none; parent
+    directories are created when writing; file objects pass through."""
+    import pathlib
+
+    if isinstance(path, (io.BufferedIOBase, io.RawIOBase)):
+        return path, False
+    path = pathlib.Path(path)
+    if path.suffix == "" and suffix:
+        path = path.with_suffix("." + suffix)
+    if "w" in mode:
+        path.parent.mkdir(parents=True, exist_ok=True)
+    return open(path, mode), True
+
+
+def save_to_pkl(path, obj: Any, verbose: int = 0) -> None:
+    """reference: save_util.py:349-367"""
+    import pickle
+
+    f, close = _open_path(path, "wb", "pkl")
+    try:
+        pickle.dump(obj, f, protocol=pickle.HIGHEST_PROTOCOL)
+    finally:
+        if close:
+            f.close()
+
+
+def load_from_pkl(path, verbose: int = 0) -> Any:
+    """reference: save_util.py:370-384. Unpickling executes code from the file: load your own files only."""
+    import pickle
+
+    f, close = _open_path(path, "rb", "pkl")
+    try:
+        return pickle.load(f)
+    finally:
+        if close:
+            f.close()

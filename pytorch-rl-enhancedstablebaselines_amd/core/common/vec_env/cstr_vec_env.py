@@ -45,9 +45,8 @@ class CSTRVecEnv(VecEnv):
             raise ValueError("twin=True needs obs_dim=8 (two 4-dim reactor trains per env)")
         if integrator not in nv.INTEGRATORS:
             raise ValueError(f"integrator must be one of {list(nv.INTEGRATORS)}, got {integrator!r}")
-        if init_mode != "random":
-            # twoseriescstr.py:254-255 raises for unknown modes; "static" (drifting init_state, :245-253) is not built yet
-            raise ValueError(f"init_mode={init_mode} is not supported, please choose 'random'")
+        if init_mode not in ("random", "static"):
+            raise ValueError(f"init_mode={init_mode} is not supported, please choose 'random' or 'static'")  # twoseriescstr.py:257
         from core.common.utils import get_device
 
         self.device = get_device(device)
@@ -73,6 +72,12 @@ class CSTRVecEnv(VecEnv):
             self._next_obs = th.zeros(n, obs_dim, dtype=th.float32, device=dev)
             self._reset_buf = th.zeros(n, obs_dim, dtype=th.float32, device=dev)
             self._rew, self._done, self._timeout = (th.zeros(n, dtype=th.float32, device=dev) for _ in range(3))
+            # init_mode="static": every env's f64 `init_state`, which each reset perturbs in place (twoseriescstr.py:94-96,
+            # :246-255); None = init_mode="random"
+            self.static_init = None
+            if init_mode == "static":
+                base = th.tensor([0.45, 310.0, 0.25, 290.0], dtype=th.float64, device=dev)
+                self.static_init = base.repeat(n, 2 if twin else 1).contiguous()
         self._rng_seeded = False
         self._pending_actions: Optional[th.Tensor] = None
         self.numpy_reseed: Optional[int] = None  # last `np.random.seed` a seeded reset performed (twoseriescstr.py:164)
@@ -111,7 +116,7 @@ class CSTRVecEnv(VecEnv):
         elif not self._rng_seeded:
             self._seed_rng([None] * self.num_envs)  # unseeded envs draw OS entropy, like gymnasium does
         with th.cuda.device(self.device):
-            hip_ops.reset_draw(self.pcg_state, None, self.obs, self.act_dim)
+            hip_ops.reset_draw(self.pcg_state, None, self.obs, self.act_dim, static_init=self.static_init)
             self.step_count.zero_()
         self._reset_seeds()
         self._reset_options()
@@ -150,7 +155,7 @@ class CSTRVecEnv(VecEnv):
             hip_ops.vec_step(self.coef, self.integrator, self.obs, actions, self.step_count, self.obs, self._next_obs,
                              self._reset_buf, self._rew, self._done, self._timeout)
             # _reset_buf now holds obs_after with the OLD obs where done; overwrite those rows with fresh draws
-            hip_ops.reset_draw(self.pcg_state, self._done.to(th.uint8), self._reset_buf, self.act_dim)
+            hip_ops.reset_draw(self.pcg_state, self._done.to(th.uint8), self._reset_buf, self.act_dim, static_init=self.static_init)
             self.obs.copy_(self._reset_buf)
         return self.obs, self._rew, self._done, self._timeout, self._next_obs
 

@@ -160,6 +160,22 @@ __device__ __forceinline__ void cstr_reset_draw_lane(uint64_t st[4], float o[4])
     }
 }
 
+// init_mode="static" (twoseriescstr.py:94-96, :246-255): the env's f64 `init_state` ([0.45, 310, 0.25, 290] at construction)
+// is perturbed IN PLACE by Generator.uniform([-0.05,-10,-0.05,-10], [0.05,10,0.05,10]) at every reset -- a per-env random
+// walk that is never clipped -- and then normalised in f64 against the f32 box.
+__device__ __forceinline__ void cstr_reset_static_lane(uint64_t st[4], double *init, float o[4])
+{
+    const float lo[4] = {0.0f, 273.15f, 0.0f, 273.15f}, hi[4] = {0.7f, 400.0f, 0.7f, 400.0f};
+    const double nlo[4] = {-0.05, -10.0, -0.05, -10.0}, nhi[4] = {0.05, 10.0, 0.05, 10.0};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const double s = init[i] + pcg64_uniform(st, nlo[i], nhi[i]);  // initial_state += noise (:255)
+        init[i] = s;
+        const float span = hi[i] - lo[i];
+        o[i] = (float)(2.0 * (s - (double)lo[i]) / (double)span - 1.0);  // :131-132
+    }
+}
+
 // raw half of the 8-dim observation of a freshly reset env: _denormalize_state of the normalised half
 __device__ __forceinline__ void denorm4(const cstr_coef_t &k, const float o[4], float raw[4])
 {
@@ -275,11 +291,16 @@ __device__ __forceinline__ bool env_step_lane(const cstr_coef_t &k, const float 
 }
 
 template <int L>
-__device__ __forceinline__ void reset_draw_env(const cstr_coef_t &k, uint64_t st[4], float o[2][4])
+__device__ __forceinline__ void reset_draw_env(const cstr_coef_t &k, uint64_t st[4], double *static_init, int64_t i, float o[2][4])
 {
-    cstr_reset_draw_lane(st, o[0]);
+    constexpr int TR = Lay<L>::TR;
+    if (static_init) cstr_reset_static_lane(st, static_init + 4 * TR * i, o[0]);
+    else cstr_reset_draw_lane(st, o[0]);
     if (L == 1) denorm4(k, o[0], o[1]);
-    if (L == 2) cstr_reset_draw_lane(st, o[1]);  // train B continues the env's stream
+    if (L == 2) {  // train B continues the env's stream
+        if (static_init) cstr_reset_static_lane(st, static_init + 4 * TR * i + 4, o[1]);
+        else cstr_reset_draw_lane(st, o[1]);
+    }
 }
 
 __device__ __forceinline__ void load_pcg(const uint64_t *pcg, int64_t i, uint64_t st[4])
@@ -334,14 +355,14 @@ __global__ void vec_step_kernel(const cstr_coef_t k, const float *__restrict__ o
 
 template <int L>
 __global__ void reset_draw_kernel(const cstr_coef_t k, uint64_t *__restrict__ pcg, const uint8_t *__restrict__ mask,
-                                  float *__restrict__ obs_out, int64_t n)
+                                  double *__restrict__ static_init, float *__restrict__ obs_out, int64_t n)
 {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         if (mask && !mask[i]) continue;
         uint64_t st[4];
         load_pcg(pcg, i, st);
         float o[2][4];
-        reset_draw_env<L>(k, st, o);
+        reset_draw_env<L>(k, st, static_init, i, o);
         store_obs<L>(obs_out, i, o);
         *reinterpret_cast<ulonglong2 *>(pcg + 4 * i) = make_ulonglong2(st[0], st[1]);
     }
@@ -357,8 +378,8 @@ __global__ void collect_step_kernel(const cstr_coef_t k, const cstr_ring_t ring,
                                     float *__restrict__ env_obs, int32_t *__restrict__ step_count,
                                     const float *__restrict__ policy_out, const int squashed, const ActBounds ab,
                                     const float *__restrict__ noise, const float *__restrict__ reset_obs,
-                                    uint64_t *__restrict__ pcg, float *__restrict__ reward_out, float *__restrict__ done_out,
-                                    float *__restrict__ ep_return, double *__restrict__ ep_stats)
+                                    uint64_t *__restrict__ pcg, double *__restrict__ static_init, float *__restrict__ reward_out,
+                                    float *__restrict__ done_out, float *__restrict__ ep_return, double *__restrict__ ep_stats)
 {
     constexpr int A = Lay<L>::A;
     const int64_t n = ring.n_envs;
@@ -417,7 +438,7 @@ __global__ void collect_step_kernel(const cstr_coef_t k, const cstr_ring_t ring,
                 uint64_t pst[4];
                 load_pcg(pcg, i, pst);
                 float ro[2][4];
-                reset_draw_env<L>(k, pst, ro);
+                reset_draw_env<L>(k, pst, static_init, i, ro);
                 store_obs<L>(env_obs, i, ro);
                 *reinterpret_cast<ulonglong2 *>(pcg + 4 * i) = make_ulonglong2(pst[0], pst[1]);
             }
@@ -494,8 +515,8 @@ extern "C" int cstr_vec_step_f32(const cstr_coef_t *coef, int integrator, int ob
     return (int)hipGetLastError();
 }
 
-extern "C" int cstr_reset_draw_f32(uint64_t *pcg_state, const uint8_t *mask, int obs_dim, int act_dim, float *obs_out,
-                                   int64_t n_envs, cstr_stream_t stream)
+extern "C" int cstr_reset_draw_f32(uint64_t *pcg_state, const uint8_t *mask, double *static_init, int obs_dim, int act_dim,
+                                   float *obs_out, int64_t n_envs, cstr_stream_t stream)
 {
     if (!pcg_state || !obs_out || n_envs <= 0 || !aligned16(obs_out) || !aligned16(pcg_state)) return CSTR_E_BADARG;
     const int layout = layout_of(obs_dim, act_dim);
@@ -505,9 +526,9 @@ extern "C" int cstr_reset_draw_f32(uint64_t *pcg_state, const uint8_t *mask, int
     hipStream_t s = (hipStream_t)stream;
     int block, grid;
     env_launch_shape(n_envs, block, grid);
-    if (layout == 0) reset_draw_kernel<0><<<grid, block, 0, s>>>(k, pcg_state, mask, obs_out, n_envs);
-    else if (layout == 1) reset_draw_kernel<1><<<grid, block, 0, s>>>(k, pcg_state, mask, obs_out, n_envs);
-    else reset_draw_kernel<2><<<grid, block, 0, s>>>(k, pcg_state, mask, obs_out, n_envs);
+    if (layout == 0) reset_draw_kernel<0><<<grid, block, 0, s>>>(k, pcg_state, mask, static_init, obs_out, n_envs);
+    else if (layout == 1) reset_draw_kernel<1><<<grid, block, 0, s>>>(k, pcg_state, mask, static_init, obs_out, n_envs);
+    else reset_draw_kernel<2><<<grid, block, 0, s>>>(k, pcg_state, mask, static_init, obs_out, n_envs);
     return (int)hipGetLastError();
 }
 
@@ -541,13 +562,14 @@ extern "C" int cstr_replay_add_f32(const cstr_ring_t *ring, int64_t *ring_ctl, c
 extern "C" int cstr_collect_step_f32(const cstr_coef_t *coef, int integrator, const cstr_ring_t *ring, int64_t *ring_ctl,
                                      float *env_obs, int32_t *step_count, const float *policy_out, int squashed,
                                      const float *act_low, const float *act_high, const float *noise,
-                                     const float *reset_obs, uint64_t *pcg_state, float *reward_out, float *done_out,
-                                     float *ep_return, double *ep_stats, cstr_stream_t stream)
+                                     const float *reset_obs, uint64_t *pcg_state, double *static_init, float *reward_out,
+                                     float *done_out, float *ep_return, double *ep_stats, cstr_stream_t stream)
 {
     int rc = check_ring(ring);
     if (rc) return rc;
     if (!coef || !ring_ctl || !env_obs || !step_count || !policy_out || !act_low || !act_high) return CSTR_E_BADARG;
     if ((reset_obs == nullptr) == (pcg_state == nullptr)) return CSTR_E_BADARG;  // exactly one reset source
+    if (static_init && !pcg_state) return CSTR_E_BADARG;
     if ((ep_return == nullptr) != (ep_stats == nullptr)) return CSTR_E_BADARG;
     if (integrator != CSTR_INTEGRATOR_EULER && integrator != CSTR_INTEGRATOR_RK4) return CSTR_E_UNSUPPORTED;
     const int A = ring->act_dim;
@@ -564,6 +586,6 @@ extern "C" int cstr_collect_step_f32(const cstr_coef_t *coef, int integrator, co
     int block, grid;
     env_launch_shape(ring->n_envs, block, grid);
     DISPATCH_L_INTEG(collect_step_kernel, *coef, *ring, ring_ctl, env_obs, step_count, policy_out, squashed, ab, noise, reset_obs,
-                     pcg_state, reward_out, done_out, ep_return, ep_stats);
+                     pcg_state, static_init, reward_out, done_out, ep_return, ep_stats);
     return (int)hipGetLastError();
 }

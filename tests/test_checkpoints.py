@@ -89,3 +89,45 @@ def test_save_load_round_trip_continues_identically(tmp_path, algo):
         outs.append([p.detach().clone() for p in m.policy.parameters()])
     for a, b in zip(*outs):
         assert th.equal(a, b)
+
+
+@pytest.mark.gpu
+def test_replay_buffer_save_load_round_trip(tmp_path):
+    """save_replay_buffer / load_replay_buffer (reference: off_policy_algorithm.py:214-254): the pickle carries the reference's
+    attribute set as host NumPy arrays; after loading, the ring, its position and the sampled batches are identical and
+    training continues from the loaded ring (also from a captured hipGraph)."""
+    import pickle
+
+    from core.common import legacy_rng
+    from core.common.vec_env import CSTRVecEnv
+    from core.sac import SAC
+
+    N, R = 32, 16
+    model = SAC("MlpPolicy", CSTRVecEnv(N), seed=5, batch_size=32, buffer_size=N * R, policy_kwargs=dict(net_arch=[32, 32]))
+    model.learn(N * 21)  # wraps the ring: pos 5, full
+    path = tmp_path / "sub" / "rb"
+    model.save_replay_buffer(path)
+    with open(str(path) + ".pkl", "rb") as f:
+        raw = pickle.load(f).__getstate__()
+    assert raw["observations"].shape == (R, N, 4) and raw["actions"].shape == (R, N, 2) and raw["rewards"].shape == (R, N)
+    assert isinstance(raw["observations"], np.ndarray) and (raw["pos"], raw["full"]) == (5, True)
+
+    other = SAC("MlpPolicy", CSTRVecEnv(N), seed=5, batch_size=32, buffer_size=N * R, policy_kwargs=dict(net_arch=[32, 32]))
+    other.enable_graph_capture()
+    other.learn(N * 8)  # captures graphs against the ring that is about to be replaced
+    other.load_replay_buffer(str(path) + ".pkl")
+    a, b = model.replay_buffer, other.replay_buffer
+    assert (b.pos, b.full, b.size(), b.buffer_size, b.n_envs) == (a.pos, a.full, a.size(), a.buffer_size, a.n_envs)
+    assert th.equal(a.ring.ctl, b.ring.ctl)
+    for name in ("observations", "next_observations", "actions", "rewards", "dones", "timeouts"):
+        assert th.equal(getattr(a, name), getattr(b, name)), name
+    legacy_rng.seed(11, a.device)
+    sa = a.sample(64)
+    legacy_rng.seed(11, a.device)
+    sb = b.sample(64)
+    for x, y in zip(sa, sb):
+        assert th.equal(x, y)
+    other.learn(N * 4, reset_num_timesteps=False)
+    assert other.replay_buffer.pos == (5 + 4) % R and int(other.replay_buffer.ring.ctl[0]) == (5 + 4) % R
+    for p in other.policy.parameters():
+        assert th.isfinite(p).all()

@@ -319,6 +319,54 @@ def test_collect_step_device_reset_rng(ops):
     np.testing.assert_array_equal(ring.dones.cpu().numpy()[0], fin.astype(np.float32))
 
 
+def test_static_init_mode_reset_vs_reference_golden(ops, golden):
+    """init_mode="static" (twoseriescstr.py:94-96, :246-255): seeded first reset then continuing resets, observations and
+    the drifting f64 init_state bit-identical to the reference run; "random" mode against the same fixture."""
+    g = golden("env_reset_kat.npz")
+    seeds = g["seeds"]
+    n = len(seeds)
+    for mode in ("random", "static"):
+        st = orc.pcg64_states_from_seeds(seeds)
+        dst = dev(st.view(np.uint64).reshape(n, 4).view(np.int64))
+        init = th.tensor(orc.STATIC_INIT_STATE, dtype=th.float64, device="cuda").repeat(n, 1).contiguous() if mode == "static" else None
+        out = th.zeros(n, 4, device="cuda")
+        for k in range(g[f"{mode}_obs"].shape[1]):
+            ops.reset_draw(dst, None, out, static_init=init)
+            np.testing.assert_array_equal(out.cpu().numpy(), g[f"{mode}_obs"][:, k])
+            if init is not None:
+                np.testing.assert_array_equal(init.cpu().numpy(), g["static_init_state"][:, k])
+
+
+def test_static_init_mode_through_fused_collect_and_vec_env(ops, golden):
+    """The reference's DummyVecEnv run with init_mode="static" (auto-reset draws continue each env's stream and init_state)
+    replayed through CSTRVecEnv.step AND through the fused collect kernel."""
+    from core import _native as nv
+    from core.common.vec_env import CSTRVecEnv
+
+    g = golden("env_reset_kat.npz")
+    n = g["vec_obs0"].shape[0]
+    for fused in (False, True):
+        env = CSTRVecEnv(n, init_mode="static")
+        env.seed(int(g["vec_seed"]))
+        np.testing.assert_array_equal(env.reset(), g["vec_obs0"])
+        env.step_count.copy_(dev(g["vec_step0"], th.int32))
+        ring = _mk_ring(ops, 8, n, 4)
+        for k in range(g["vec_actions"].shape[0]):
+            if fused:
+                ops.collect_step(env.coef, "euler", ring, env.obs, env.step_count, dev(g["vec_actions"][k]), True, [-1, -1], [1, 1],
+                                 pcg_state=env.pcg_state, static_init=env.static_init, done_out=env._done)
+                obs, done = env.obs.cpu().numpy(), env._done.cpu().numpy().astype(np.uint8)
+            else:
+                obs, _, done, _ = env.step(g["vec_actions"][k])
+            np.testing.assert_array_equal(done.astype(np.uint8), g["vec_done"][k])
+            d = g["vec_done"][k].astype(bool)
+            np.testing.assert_array_equal(obs[d], g["vec_obs"][k][d])  # reset draws: bit-exact
+            assert rel_err(obs, g["vec_obs"][k], OBS_FLOOR) < 1e-6
+        np.testing.assert_array_equal(env.static_init.cpu().numpy(), g["vec_init_state"])
+    with pytest.raises(ValueError):
+        CSTRVecEnv(2, init_mode="bogus")
+
+
 # --------------------------------------------------------------------------------- element-wise
 @pytest.mark.parametrize("n", [1, 3, 256, 135682, 369704, 1 << 22])
 def test_polyak_bit_exact(ops, n):

@@ -90,6 +90,43 @@ def test_vecenv_autoreset(golden):
     assert g["done"].sum() >= 4  # the fixture really exercises auto-reset
 
 
+def test_reset_draws_both_init_modes_vs_reference(golden):
+    """TwoSeriesCSTREnv.reset (twoseriescstr.py:226-269) run by the reference itself, seeded then continuing: the
+    "random" draw (generate_initial_state) and the "static" mode's drifting f64 init_state, both bit-exact."""
+    g = golden("env_reset_kat.npz")
+    seeds = g["seeds"]
+    st = orc.pcg64_states_from_seeds(seeds)
+    for k in range(g["random_obs"].shape[1]):
+        np.testing.assert_array_equal(orc.reset_draw(st), g["random_obs"][:, k])
+    st = orc.pcg64_states_from_seeds(seeds)
+    init = np.tile(np.array(orc.STATIC_INIT_STATE, np.float64), (len(seeds), 1))
+    for k in range(g["static_obs"].shape[1]):
+        np.testing.assert_array_equal(orc.reset_draw(st, static_init=init), g["static_obs"][:, k])
+        np.testing.assert_array_equal(init, g["static_init_state"][:, k])
+    assert np.abs(g["static_init_state"][:, -1] - np.array(orc.STATIC_INIT_STATE)).max() > 1.0  # it really drifts
+
+
+def test_static_mode_autoreset_through_vecenv(golden):
+    """DummyVecEnv auto-reset with init_mode="static" (dummy_vec_env.py:68-72): only finished envs draw."""
+    g = golden("env_reset_kat.npz")
+    n = g["vec_obs0"].shape[0]
+    st = orc.pcg64_states_from_seeds(int(g["vec_seed"]) + np.arange(n))
+    init = np.tile(np.array(orc.STATIC_INIT_STATE, np.float64), (n, 1))
+    obs = orc.reset_draw(st, static_init=init)
+    np.testing.assert_array_equal(obs, g["vec_obs0"])
+    steps = g["vec_step0"].copy()
+    for k in range(g["vec_actions"].shape[0]):
+        nxt, _, _, done, _, steps = orc.vec_step(obs, g["vec_actions"][k], steps, reset_obs=obs)
+        d = done.astype(np.uint8)
+        np.testing.assert_array_equal(d, g["vec_done"][k])
+        fresh = orc.reset_draw(st, d, static_init=init)
+        obs = np.where(d[:, None].astype(bool), fresh, nxt)
+        assert rel_err(obs, g["vec_obs"][k], OBS_FLOOR) < 1e-6
+        np.testing.assert_array_equal(obs[d.astype(bool)], g["vec_obs"][k][d.astype(bool)])
+    np.testing.assert_array_equal(init, g["vec_init_state"])
+    assert g["vec_done"].sum() == 3
+
+
 def test_rk4_consistency():
     """RK4 has no reference counterpart: check it is a 4th-order refinement of the
     same RHS -- one RK4 step must be far closer than one Euler step to 1024 Euler sub-steps."""

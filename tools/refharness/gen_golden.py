@@ -587,7 +587,52 @@ def gen_init():
     save("policy_init_kat.npz", **out)
 
 
-GENS = {"env": gen_env, "vecenv": gen_vecenv, "sampler": gen_sampler, "replay": gen_replay, "sac": gen_sac,
+def gen_resets():
+    """TwoSeriesCSTREnv.reset (twoseriescstr.py:226-269) in both init modes: seeded first reset, then unseeded resets that
+    continue the env's generator; "static" also records the drifting f64 init_state. The generator behind
+    `self.np_random` is the harness stand-in's Generator(PCG64(SeedSequence(seed))) = gymnasium's documented construction."""
+    from twoseriescstr import TwoSeriesCSTREnv
+
+    seeds, n_resets = [0, 1, 7, 42, 4095, 123456], 6
+    out = {"seeds": np.array(seeds, np.int64)}
+    for mode in ("random", "static"):
+        obs = np.zeros((len(seeds), n_resets, 4), np.float32)
+        init = np.zeros((len(seeds), n_resets, 4), np.float64)
+        for i, sd in enumerate(seeds):
+            env = TwoSeriesCSTREnv(init_mode=mode)
+            for k in range(n_resets):
+                o, info = env.reset(seed=sd) if k == 0 else env.reset()
+                assert o.dtype == np.float32
+                obs[i, k] = o
+                if mode == "static":
+                    init[i, k] = env.init_state
+            # a few steps between resets must not touch the reset stream
+        out[f"{mode}_obs"] = obs
+        if mode == "static":
+            out["static_init_state"] = init
+    # static mode through the vectorised env: auto-reset draws continue each env's own stream
+    from core.common.vec_env.dummy_vec_env import DummyVecEnv
+
+    N, T = 3, 5
+    venv = DummyVecEnv([lambda: TwoSeriesCSTREnv(init_mode="static") for _ in range(N)])
+    venv.seed(21)
+    o0 = venv.reset()
+    step0 = np.array([398, 399, 397], np.int32)
+    for i, e in enumerate(venv.envs):
+        e.current_step = int(step0[i])
+    rng = np.random.default_rng(3)
+    actions = rng.uniform(-1, 1, size=(T, N, 2)).astype(np.float32)
+    obs = np.zeros((T, N, 4), np.float32)
+    done = np.zeros((T, N), np.uint8)
+    for k in range(T):
+        o, r, d, infos = venv.step(actions[k])
+        obs[k], done[k] = o, d
+    out.update(vec_seed=np.int64(21), vec_obs0=o0, vec_step0=step0, vec_actions=actions, vec_obs=obs, vec_done=done,
+               vec_init_state=np.stack([e.init_state for e in venv.envs]))
+    save("env_reset_kat.npz", **out)
+
+
+GENS = {"env": gen_env, "resets": gen_resets, "vecenv": gen_vecenv, "sampler": gen_sampler, "replay": gen_replay, "sac": gen_sac,
         "td3": gen_td3, "init": gen_init, "maddpg": gen_maddpg, "iddpg": gen_iddpg, "checkpoint": gen_checkpoint}
 
 if __name__ == "__main__":
