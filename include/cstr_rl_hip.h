@@ -133,6 +133,33 @@ int cstr_collect_step_f32(const cstr_coef_t *coef, int integrator, const cstr_ri
  * twoseriescstr.py:164 reseeds the same global stream). */
 int cstr_mt19937_seed(uint32_t *mt_state, uint32_t seed, cstr_stream_t stream);
 
+/* ---- VecNormalize (core/common/vec_env/vec_normalize.py:174-290; core/common/running_mean_std.py:34-55) ----
+ * vn_state: double[CSTR_VECNORM_STATE_WORDS] in HBM = { obs mean[8], obs var[8], obs count, ret mean, ret var, ret count }
+ * (the reference's obs_rms / ret_rms, f64); returns: double[N] discounted returns (VecNormalize.returns). */
+#define CSTR_VECNORM_STATE_WORDS 20
+typedef struct {
+    int32_t training, norm_obs, norm_reward, obs_dim; /* obs_dim <= 8 */
+    double clip_obs, clip_reward, gamma, epsilon;
+} cstr_vecnorm_cfg_t;
+
+/* RunningMeanStd.__init__ for both statistics: mean 0, var 1, count 1e-4 (running_mean_std.py:5-15). */
+int cstr_vecnorm_init_f64(double *vn_state, cstr_stream_t stream);
+
+/* VecNormalize.step_wait (vec_normalize.py:174-204) on the raw outputs of the inner VecEnv, in the reference's order:
+ * obs_rms.update(obs) [training && norm_obs], norm_obs_out = clip((obs - mean) / sqrt(var + eps)), returns = returns*gamma
+ * + reward and ret_rms.update(returns) [training], norm_reward_out = clip(reward / sqrt(ret var + eps)), returns[done] = 0.
+ * reward == NULL is VecNormalize.reset (:291-307): observation part only and returns = 0.
+ *   obs [N][obs_dim] f32 raw; reward/done [N] f32 or NULL; norm_obs_out [N][obs_dim] / norm_reward_out [N] or NULL. */
+int cstr_vecnorm_step_f64(const cstr_vecnorm_cfg_t *cfg, double *vn_state, double *returns, const float *obs,
+                          const float *reward, const float *done, float *norm_obs_out, float *norm_reward_out,
+                          int64_t n_envs, cstr_stream_t stream);
+
+/* ReplayBuffer._get_samples(env=VecNormalize) (core/common/buffers.py:143-155, :312-323): normalize_obs on the sampled
+ * observations / next_observations [B][obs_dim] and normalize_reward on rewards [B], in place, with the current
+ * statistics. Each of obs / next_obs / reward may be NULL (at least one is not). */
+int cstr_vecnorm_apply_f32(const cstr_vecnorm_cfg_t *cfg, const double *vn_state, float *obs, float *next_obs,
+                           float *reward, int64_t batch, cstr_stream_t stream);
+
 /* Exploration noise from the SAME legacy stream as the replay sampler: the reference's
  * VectorizedActionNoise.__call__ -> n_envs x NormalActionNoise.__call__ = np.random.normal(mu, sigma).astype(float32)
  * (core/common/noise.py:44-45, :141-142; OU noise draws np.random.normal(size=) the same way, :85-89).

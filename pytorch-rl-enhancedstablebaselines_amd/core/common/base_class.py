@@ -13,7 +13,7 @@ from core.common.callbacks import BaseCallback, MaybeCallback, to_callback
 from core.common.logger import Logger, configure_logger
 from core.common.spaces import Box, as_box
 from core.common.utils import get_device, get_schedule_fn, set_random_seed, update_learning_rate
-from core.common.vec_env import CSTRVecEnv, VecEnv
+from core.common.vec_env import CSTRVecEnv, VecEnv, unwrap_vec_normalize
 
 
 class BaseAlgorithm:
@@ -62,6 +62,7 @@ class BaseAlgorithm:
             self.action_space = as_box(env.action_space)
             self.n_envs = env.num_envs
             self.env = env
+            self._vec_normalize_env = unwrap_vec_normalize(env)  # reference base_class.py:195
             if supported_action_spaces is not None and not isinstance(self.action_space, Box):
                 raise AssertionError(f"The algorithm only supports {supported_action_spaces} as action spaces")
             if not support_multi_env and self.n_envs > 1:
@@ -129,6 +130,17 @@ class BaseAlgorithm:
         if force_reset:
             self._last_obs = None
         self.env = env
+        self._vec_normalize_env = unwrap_vec_normalize(env)  # reference base_class.py:525
+
+    def get_vec_normalize_env(self):
+        """reference: base_class.py:491-498"""
+        return self._vec_normalize_env
+
+    @property
+    def _denv(self) -> Optional[CSTRVecEnv]:
+        """the device-resident env underneath `self.env` (itself, or the one a VecNormalize wraps); None otherwise"""
+        inner = getattr(self.env, "unwrapped", None)
+        return inner if isinstance(inner, CSTRVecEnv) else None
 
     @property
     def logger(self) -> Logger:
@@ -164,17 +176,17 @@ class BaseAlgorithm:
         self._num_timesteps_at_start = self.num_timesteps
         if reset_num_timesteps or self._last_obs is None:
             assert self.env is not None
-            self._last_obs = self.env.reset_device() if isinstance(self.env, CSTRVecEnv) else self.env.reset()
+            self._last_obs = self.env.reset_device() if self._denv is not None else self.env.reset()
             self._last_episode_starts = np.ones((self.env.num_envs,), dtype=bool)
             # a seeded TwoSeriesCSTREnv.reset re-seeds the GLOBAL numpy stream (twoseriescstr.py:164): the replay
             # sampler's stream ends up seeded with seed + n_envs - 1 (SURVEY a-6)
-            reseed = getattr(self.env, "numpy_reseed", None)
+            reseed = getattr(self._denv or self.env, "numpy_reseed", None)
             if reseed is not None:
                 from core.common import legacy_rng
 
                 np.random.seed(reseed)
                 legacy_rng.seed(reseed, self.device)
-                self.env.numpy_reseed = None
+                (self._denv or self.env).numpy_reseed = None
         if not self._custom_logger:
             self._logger = configure_logger(self.verbose, self.tensorboard_log, tb_log_name, reset_num_timesteps)
         callback = self._init_callback(callback)

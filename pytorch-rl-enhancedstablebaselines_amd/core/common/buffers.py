@@ -84,6 +84,7 @@ class ReplayBuffer(BaseBuffer):
         self.observations, self.next_observations, self.actions = r.observations, r.next_observations, r.actions
         self.rewards, self.dones, self.timeouts = r.rewards, r.dones, r.timeouts
         self._stream = sampler_stream
+        self.normalizer = None  # a VecNormalize whose statistics normalise every sampled batch (buffers.py:143-155)
 
     # ---- pickling (save_replay_buffer / load_replay_buffer, off_policy_algorithm.py:214-254) -------------
     _FIELDS = ("observations", "next_observations", "actions", "rewards", "dones", "timeouts")
@@ -115,6 +116,7 @@ class ReplayBuffer(BaseBuffer):
         r.ctl.copy_(th.tensor([int(st["pos"]), int(bool(st["full"])), 0, self._adds], dtype=th.int64))
         ss = st.get("sampler_stream")
         self._stream = None if ss is None else th.from_numpy(np.ascontiguousarray(ss)).to(self.device)
+        self.normalizer = None
 
     def to(self, device) -> "ReplayBuffer":
         """Move the ring to another GPU (load_replay_buffer: 'update saved replay buffer device', :252-253)."""
@@ -172,21 +174,22 @@ class ReplayBuffer(BaseBuffer):
         e = lambda *s: th.empty(*s, dtype=th.float32, device=dev)  # noqa: E731
         return ReplayBufferSamples(e(batch_size, d), e(batch_size, a), e(batch_size, d), e(batch_size, 1), e(batch_size, 1))
 
-    def sample_into(self, out: ReplayBufferSamples, row_idx=None, env_idx=None) -> ReplayBufferSamples:
+    def sample_into(self, out: ReplayBufferSamples, row_idx=None, env_idx=None, env=None) -> ReplayBufferSamples:
         """`sample` into caller-owned (static, graph-capturable) tensors."""
         if self.size() == 0:
             raise ValueError("high <= 0")  # what np.random.randint(0, 0) raises in the reference (:113)
         with th.cuda.device(self.device):
             hip_ops.replay_sample(self.ring, self.sampler_stream, out.observations.shape[0], out.observations, out.actions,
                                   out.next_observations, out.dones, out.rewards, row_idx, env_idx)
+        env = self.normalizer if env is None else env
+        if env is not None:  # _normalize_obs / _normalize_reward with the CURRENT statistics (:143-155, :312-323)
+            env.normalize_batch_(out.observations, out.next_observations, out.rewards)
         return out
 
     def sample(self, batch_size: int, env: Any = None) -> ReplayBufferSamples:
         """reference: buffers.py:106-115, :285-325. Returns fresh device tensors
         (observations, actions, next_observations, dones, rewards)."""
-        if env is not None:
-            raise NotImplementedError("VecNormalize is out of scope for the CSTR path (SURVEY 2); pass env=None")
-        return self.sample_into(self.alloc_batch(batch_size))
+        return self.sample_into(self.alloc_batch(batch_size), env=env)
 
     def sample_with_indices(self, batch_size: int):
         bi = th.empty(batch_size, dtype=th.int64, device=self.device)

@@ -12,8 +12,8 @@ from core.common.vec_env import CSTRVecEnv
 def evaluate_policy(model, env, n_eval_episodes: int = 10, deterministic: bool = True, render: bool = False,
                     callback: Optional[Callable] = None, reward_threshold: Optional[float] = None,
                     return_episode_rewards: bool = False, warn: bool = True) -> Union[Tuple[float, float], Tuple[list, list]]:
-    if not isinstance(env, CSTRVecEnv):
-        raise ValueError("evaluate_policy: this stack evaluates on a CSTRVecEnv")
+    if not isinstance(getattr(env, "unwrapped", None), CSTRVecEnv):
+        raise ValueError("evaluate_policy: this stack evaluates on a CSTRVecEnv (optionally wrapped in VecNormalize)")
     n = env.num_envs
     # reference :79-82: episodes are split over the envs as evenly as possible
     targets = th.tensor([(n_eval_episodes + i) // n for i in range(n)], device=env.device)

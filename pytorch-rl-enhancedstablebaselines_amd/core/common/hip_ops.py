@@ -151,6 +151,43 @@ def replay_sample(ring: DeviceRing, mt_state, batch: int, out_obs, out_act, out_
           "cstr_replay_sample_mt19937_f32")
 
 
+def vecnorm_init(vn_state):
+    _chk(vn_state, "vn_state", (nv.VECNORM_STATE_WORDS,), th.float64)
+    check(nv.lib().cstr_vecnorm_init_f64(ptr(vn_state), stream_ptr()), "cstr_vecnorm_init_f64")
+
+
+def vecnorm_step(cfg, vn_state, returns, obs, reward, done, norm_obs_out=None, norm_reward_out=None):
+    """VecNormalize.step_wait / reset (reward=None) on raw device tensors (reference: vec_normalize.py:174-204, :291-307)."""
+    n, d = obs.shape
+    if d != cfg.obs_dim:
+        raise ValueError(f"obs has {d} columns, VecNormalize was built for {cfg.obs_dim}")
+    _chk(vn_state, "vn_state", (nv.VECNORM_STATE_WORDS,), th.float64), _chk(returns, "returns", (n,), th.float64)
+    _chk(obs, "obs", (n, d), th.float32)
+    _opt(reward, "reward", (n,), th.float32), _opt(done, "done", (n,), th.float32)
+    _opt(norm_obs_out, "norm_obs_out", (n, d), th.float32), _opt(norm_reward_out, "norm_reward_out", (n,), th.float32)
+    if norm_obs_out is not None and norm_obs_out.data_ptr() == obs.data_ptr():
+        raise ValueError("norm_obs_out must not alias obs (the raw observation stays available as get_original_obs)")
+    if reward is None and (done is not None or norm_reward_out is not None):
+        raise ValueError("the reset form (reward=None) takes neither done nor norm_reward_out")
+    check(nv.lib().cstr_vecnorm_step_f64(C.byref(cfg), ptr(vn_state), ptr(returns), ptr(obs), ptr(reward), ptr(done),
+                                         ptr(norm_obs_out), ptr(norm_reward_out), C.c_int64(n), stream_ptr()), "cstr_vecnorm_step_f64")
+
+
+def vecnorm_apply(cfg, vn_state, obs, next_obs, reward):
+    """normalize_obs / normalize_reward of a sampled batch, in place (reference: buffers.py:143-155, :312-323)."""
+    _chk(vn_state, "vn_state", (nv.VECNORM_STATE_WORDS,), th.float64)
+    ref = next((t for t in (obs, next_obs, reward) if t is not None), None)
+    if ref is None:
+        raise ValueError("nothing to normalise")
+    b = ref.shape[0]
+    _opt(obs, "obs", (b, cfg.obs_dim), th.float32), _opt(next_obs, "next_obs", (b, cfg.obs_dim), th.float32)
+    if reward is not None and reward.numel() != b:
+        raise ValueError(f"reward has {reward.numel()} entries, batch is {b}")
+    _opt(reward, "reward", tuple(reward.shape) if reward is not None else (), th.float32)
+    check(nv.lib().cstr_vecnorm_apply_f32(C.byref(cfg), ptr(vn_state), ptr(obs), ptr(next_obs), ptr(reward), C.c_int64(b),
+                                          stream_ptr()), "cstr_vecnorm_apply_f32")
+
+
 def td_target_min(q1, q2, logp, rew, done, ent_coef, gamma: float, out):
     n = q1.numel()
     for t, nm in ((q1, "q1"), (q2, "q2"), (rew, "rew"), (done, "done"), (out, "out")):

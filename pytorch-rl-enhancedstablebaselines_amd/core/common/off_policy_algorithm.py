@@ -76,8 +76,8 @@ class OffPolicyAlgorithm(BaseAlgorithm):
         """reference: off_policy_algorithm.py:172-212"""
         self._setup_lr_schedule()
         blas.configure()
-        if self.world_size > 1 and isinstance(self.env, CSTRVecEnv):
-            self.env.seed_offset = self.rank * self.n_envs  # SURVEY 8e: seed_r = seed + rank * n_envs
+        if self.world_size > 1 and self._denv is not None:
+            self._denv.seed_offset = self.rank * self.n_envs  # SURVEY 8e: seed_r = seed + rank * n_envs
         self.set_random_seed(self.seed)
         if self.replay_buffer_class is None:
             self.replay_buffer_class = ReplayBuffer
@@ -115,18 +115,21 @@ class OffPolicyAlgorithm(BaseAlgorithm):
         self.replay_buffer = load_from_pkl(path, self.verbose)
         assert isinstance(self.replay_buffer, ReplayBuffer), "The replay buffer must inherit from ReplayBuffer class"
         self.replay_buffer.to(self.device)  # :252-253
+        self.replay_buffer.normalizer = self._vec_normalize_env
         self._graph = None  # captured graphs hold the old ring's pointers
 
     def _fast_path(self) -> bool:
         rb = self.replay_buffer
-        return (isinstance(self.env, CSTRVecEnv) and type(rb) is ReplayBuffer and rb.n_envs == self.env.num_envs
-                and rb.obs_shape[0] == self.env.obs_dim and rb.action_dim == self.env.act_dim and self._vec_normalize_env is None)
+        env = self._denv
+        return (env is not None and type(rb) is ReplayBuffer and rb.n_envs == env.num_envs
+                and rb.obs_shape[0] == env.obs_dim and rb.action_dim == env.act_dim)
 
     # ---- learn ----------------------------------------------------------------------------------------------------
     def _setup_learn(self, total_timesteps, callback=None, reset_num_timesteps=True, tb_log_name="run", progress_bar=False):
         from core.common.noise import (DeviceNormalActionNoise, LegacyStreamNormalActionNoise, NormalActionNoise,
                                        VectorizedActionNoise)
 
+        self.replay_buffer.normalizer = self._vec_normalize_env  # sample(..., env=self._vec_normalize_env), sac.py:215
         base = self.action_noise
         if isinstance(base, VectorizedActionNoise) and base.n_envs == self.env.num_envs:
             base = base.base_noise
@@ -193,19 +196,21 @@ class OffPolicyAlgorithm(BaseAlgorithm):
                 and self.num_timesteps + self.n_envs > self.learning_starts and not getattr(self, "debug_capture", False))
 
     def _graph_body(self) -> None:
-        env, rb = self.env, self.replay_buffer
+        env, rb, vn = self._denv, self.replay_buffer, self._vec_normalize_env
         self.policy.set_training_mode(False)
-        pol = self._policy_out_device(env.obs)
+        pol = self._policy_out_device(env.obs if vn is None else vn.norm_obs_dev)
         noise = None if self.action_noise is None else self.action_noise().contiguous()
         hip_ops.collect_step(env.coef, env.integrator, rb.ring, env.obs, env.step_count, pol, self._action_mode(False),
                              self.action_space.low, self.action_space.high, noise=noise, pcg_state=env.pcg_state, static_init=env.static_init, reward_out=env._rew, done_out=env._done,
                              ep_return=self._ep_return, ep_stats=self._ep_stats)
+        if vn is not None:
+            vn.after_device_step()
         self.policy.set_training_mode(True)
         self._train_device_only(self.gradient_steps, self.batch_size)
 
     def _graph_host_bookkeeping(self, log_interval: Optional[int]) -> None:
         self.replay_buffer.note_fused_add()
-        self._last_obs = self.env.obs
+        self._last_obs = self._denv.obs if self._vec_normalize_env is None else self._vec_normalize_env.norm_obs_dev
         self.num_timesteps += self.n_envs
         self._update_current_progress_remaining(self.num_timesteps, self._total_timesteps)
         self._train_host_only(self.gradient_steps)
@@ -217,7 +222,8 @@ class OffPolicyAlgorithm(BaseAlgorithm):
         return 0
 
     def _graph_iteration(self, log_interval: Optional[int]) -> None:
-        key = (id(self.env.coef), self.batch_size, self.gradient_steps, self._graph_phase())
+        vn = self._vec_normalize_env
+        key = (id(self._denv.coef), self.batch_size, self.gradient_steps, self._graph_phase(), None if vn is None else (id(vn), vn.cfg_key))
         if not isinstance(self._graph, dict):
             self._graph, self._graph_warm = {}, {}
         if key not in self._graph:
@@ -377,8 +383,8 @@ class OffPolicyAlgorithm(BaseAlgorithm):
         continue_training = True
         while should_collect_more_steps(train_freq, num_collected_steps, num_collected_episodes):
             if fast:
-                self._collect_one_fused(env, replay_buffer, action_noise, learning_starts)
-                new_obs, rewards, dones = env.obs, env._rew, env._done  # device tensors (for callbacks)
+                self._collect_one_fused(env.unwrapped, replay_buffer, action_noise, learning_starts)
+                new_obs, rewards, dones = self._last_obs, env._rew, env._done  # device tensors (for callbacks)
                 infos: Any = None
             else:
                 if isinstance(self._last_obs, th.Tensor):
@@ -413,13 +419,13 @@ class OffPolicyAlgorithm(BaseAlgorithm):
     def _collect_one_fused(self, env: CSTRVecEnv, rb: ReplayBuffer, action_noise, learning_starts: int) -> None:
         """One vec-step entirely in HBM: reference statements :561 (_sample_action), :564 (env.step), :580
         (_store_transition -> ReplayBuffer.add) in one HIP launch after the actor forward."""
-        n = env.num_envs
+        n, vn = env.num_envs, self._vec_normalize_env
         if self.num_timesteps < learning_starts:
             # warm-up: uniform actions from the action space's own generator (:386-388); drawn on the host
             pol = th.as_tensor(self.action_space.sample_batch(n)).to(self.device)
             squashed = self._action_mode(warmup=True)
         else:
-            pol = self._policy_out_device(env.obs)
+            pol = self._policy_out_device(env.obs if vn is None else vn.norm_obs_dev)
             squashed = self._action_mode(warmup=False)
         noise = None
         if action_noise is not None:
@@ -430,8 +436,10 @@ class OffPolicyAlgorithm(BaseAlgorithm):
             hip_ops.collect_step(env.coef, env.integrator, rb.ring, env.obs, env.step_count, pol, squashed,
                                  self.action_space.low, self.action_space.high, noise=noise, pcg_state=env.pcg_state, static_init=env.static_init,
                                  reward_out=env._rew, done_out=env._done, ep_return=self._ep_return, ep_stats=self._ep_stats)
+            if vn is not None:
+                vn.after_device_step()  # VecNormalize.step_wait on the raw outputs (vec_normalize.py:174-204)
         rb.note_fused_add()
-        self._last_obs = env.obs
+        self._last_obs = env.obs if vn is None else vn.norm_obs_dev
 
     # ---- data-parallel helper used by train() ----------------------------------------------------------------------
     def _allreduce_grads(self, arena) -> None:

@@ -632,7 +632,86 @@ def gen_resets():
     save("env_reset_kat.npz", **out)
 
 
-GENS = {"env": gen_env, "resets": gen_resets, "vecenv": gen_vecenv, "sampler": gen_sampler, "replay": gen_replay, "sac": gen_sac,
+def gen_vecnorm():
+    """The reference's VecNormalize / RunningMeanStd (core/common/vec_env/vec_normalize.py:174-290,
+    core/common/running_mean_std.py) driven by a replaying inner VecEnv: inputs are the raw obs / reward / done sequences,
+    outputs the normalised obs / rewards and the running statistics after every step, plus normalize_obs /
+    normalize_reward of a held-out batch as ReplayBuffer._get_samples applies them (buffers.py:143-155, :312-323)."""
+    from core.common.vec_env.base_vec_env import VecEnv
+    from core.common.vec_env.vec_normalize import VecNormalize
+    from gymnasium import spaces
+
+    N, D, T = 48, 4, 25
+    rng = np.random.default_rng(5)
+    scale, shift = np.array([0.3, 2.0, 0.05, 7.0]), np.array([0.1, -1.0, 0.0, 3.0])
+    raw_obs = (rng.normal(size=(T + 1, N, D)) * scale + shift).astype(np.float32)
+    raw_rew = (rng.normal(size=(T, N)) * 5.0 - 20.0).astype(np.float32)
+    done = (rng.uniform(size=(T, N)) < 0.08)
+
+    class Replay(VecEnv):
+        def __init__(self):
+            super().__init__(N, spaces.Box(-np.inf, np.inf, (D,), np.float32), spaces.Box(-1, 1, (2,), np.float32))
+            self.k = 0
+
+        def reset(self):
+            self.k = 0
+            return raw_obs[0].copy()
+
+        def step_async(self, actions):
+            pass
+
+        def step_wait(self):
+            k = self.k
+            self.k += 1
+            return raw_obs[k + 1].copy(), raw_rew[k].copy(), done[k].copy(), [{} for _ in range(N)]
+
+        def close(self):
+            pass
+
+        def get_attr(self, attr_name, indices=None):
+            return [None] * N
+
+        def set_attr(self, attr_name, value, indices=None):
+            pass
+
+        def env_method(self, method_name, *a, indices=None, **kw):
+            return [None] * N
+
+        def env_is_wrapped(self, wrapper_class, indices=None):
+            return [False] * N
+
+    out = dict(raw_obs=raw_obs, raw_rew=raw_rew, done=done.astype(np.uint8))
+    held_obs = (rng.normal(size=(64, D)) * scale * 3 + shift).astype(np.float32)
+    held_rew = (rng.normal(size=(64, 1)) * 30.0 - 20.0).astype(np.float32)
+    out.update(held_obs=held_obs, held_rew=held_rew)
+    for tag, kw in (("default", {}), ("tight", dict(clip_obs=1.5, clip_reward=0.8, gamma=0.9, epsilon=1e-4)),
+                    ("obs_only", dict(norm_reward=False)), ("rew_only", dict(norm_obs=False))):
+        vn = VecNormalize(Replay(), **kw)
+        o = vn.reset()
+        n_obs, n_rew = [o], []
+        stats = []
+        for k in range(T):
+            if tag == "default" and k == 18:
+                vn.training = False  # frozen statistics for the tail
+            o, r, d, _ = vn.step(np.zeros((N, 2), np.float32))
+            n_obs.append(o)
+            n_rew.append(r)
+            om = vn.obs_rms if vn.norm_obs else None
+            stats.append(np.concatenate([om.mean if om else np.zeros(D), om.var if om else np.ones(D), [om.count if om else 0.0],
+                                         [vn.ret_rms.mean, vn.ret_rms.var, vn.ret_rms.count]]))
+            assert np.array_equal(vn.get_original_obs(), raw_obs[k + 1]) and np.array_equal(vn.get_original_reward(), raw_rew[k])
+        out[f"{tag}_norm_obs"] = np.stack(n_obs).astype(np.float32)
+        out[f"{tag}_norm_rew"] = np.stack(n_rew).astype(np.float32)
+        out[f"{tag}_stats"] = np.stack(stats)
+        out[f"{tag}_returns"] = vn.returns.copy()
+        out[f"{tag}_held_obs"] = vn.normalize_obs(held_obs)
+        out[f"{tag}_held_rew"] = vn.normalize_reward(held_rew).astype(np.float32)
+        out[f"{tag}_unnorm_obs"] = np.asarray(vn.unnormalize_obs(out[f"{tag}_held_obs"]), np.float64)
+        out[f"{tag}_unnorm_rew"] = np.asarray(vn.unnormalize_reward(out[f"{tag}_held_rew"]), np.float64)
+    save("vecnormalize_kat.npz", **out)
+
+
+GENS = {"env": gen_env, "resets": gen_resets, "vecnorm": gen_vecnorm, "vecenv": gen_vecenv, "sampler": gen_sampler, "replay": gen_replay, "sac": gen_sac,
         "td3": gen_td3, "init": gen_init, "maddpg": gen_maddpg, "iddpg": gen_iddpg, "checkpoint": gen_checkpoint}
 
 if __name__ == "__main__":
