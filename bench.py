@@ -273,7 +273,7 @@ def main():
     _, callback = model._setup_learn(total, NoopCallback(), True, "bench", False)
     use_graph = bool(args.graph)  # world > 1: graph segments with the RCCL all-reduces between them
     model.enable_graph_capture(use_graph)
-    if args.tunable:
+    if args.tunable:  # development: record / eager-tune every GEMM shape (input of tools/tune_gemms.py)
         th.cuda.tunable.enable(True)
         th.cuda.tunable.tuning_enable(True)
         th.cuda.tunable.set_filename(os.path.join(ROOT, "gpurun_out", "tunableop_results.csv"))
