@@ -208,6 +208,18 @@ int cstr_bias_act_fwd_f32(float *y, const float *bias, int act, int64_t groups, 
 int cstr_bias_act_bwd_f32(const float *gy, const float *y, int act, float *gz, float *gbias, int64_t groups, int64_t m, int64_t n,
                           cstr_stream_t stream);
 
+/* Last hidden layer + scalar head of a Q network: create_mlp(..., output_dim = 1) (core/common/torch_layers.py:110-183;
+ * ContinuousCritic.forward, core/common/policies.py:960-987) ends in y = act(z + b1), q = y . w2 + b2. The head is a
+ * matrix-vector product, done in the epilogue of the previous GEMM: z [groups][m][k] is replaced by y IN PLACE and
+ * q [groups][m] is written. b1, w2 [groups][k]; b2 [groups]. */
+int cstr_hidden_head_fwd_f32(float *z, const float *b1, int act, const float *w2, const float *b2, float *q, int64_t groups,
+                             int64_t m, int64_t k, cstr_stream_t stream);
+
+/* Backward of the pair given gq = d(loss)/dq [groups][m]: dz = gq * w2 * act'(y) [groups][m][k] and, when the three
+ * parameter-gradient pointers are given (all or none), gb1[k] = sum_m dz, gw2[k] = sum_m gq * y, gb2 = sum_m gq. */
+int cstr_hidden_head_bwd_f32(const float *gq, const float *y, int act, const float *w2, float *dz, float *gb1, float *gw2,
+                             float *gb2, int64_t groups, int64_t m, int64_t k, cstr_stream_t stream);
+
 /* SquashedDiagGaussianDistribution (core/common/distributions.py:161-260) with SAC's log_std clamp
  * (core/sac/policies.py:20-22, :162-164): u = mean + exp(clamp(log_std_raw, -20, 2)) * eps, action = tanh(u),
  * logp = sum_j Normal.log_prob(u_j) - sum_j log(1 - action_j^2 + 1e-6). logp may be NULL (acting only).

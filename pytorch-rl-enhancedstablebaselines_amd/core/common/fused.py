@@ -7,6 +7,9 @@ a hand-written HIP kernel, and gradients are written STRAIGHT into the flat aren
     No AccumulateGrad adds, no zero_grad memsets: every parameter's gradient is (over)written exactly once per
     backward; frozen parameters (critic during the actor loss) skip the weight/bias GEMMs entirely.
   * twin critics = ONE chain of batched GEMMs over stacked arena views; the actor's mu / log_std heads = ONE GEMM;
+  * a Q network's last hidden layer + scalar head (`hidden_head`) = 1 GEMM + 1 launch: the n = 1 head is a matrix-vector
+    product folded into the hidden layer's epilogue (rocBLAS runs it as an 8 us degenerate GEMM); backward = 1 launch for
+    the head's three gradients and the activation gradient, + the hidden layer's two GEMMs;
   * `squashed_gaussian([mean | log_std], eps)` = 1 launch forward, 1 launch backward (analytic).
 
 The nn.Modules keep owning the parameters (state_dict / API); `FastMLP` only reads their tensors. Arithmetic per
@@ -90,8 +93,16 @@ class FastMLP:
             return False
 
     def __call__(self, x: th.Tensor, train_params: bool = True) -> th.Tensor:
-        for lin, act in self.layers:
+        layers = self.layers
+        scalar_head = len(layers) >= 2 and layers[-1][0].out_features == 1 and layers[-1][1] == ACT_NONE
+        for lin, act in (layers[:-2] if scalar_head else layers):
             x = linear(x, lin.weight, lin.bias, act, train_params)
+        if scalar_head:
+            (l1, act), (l2, _) = layers[-2:]
+            grads = (l1.weight.grad, l1.bias.grad, l2.weight.grad, l2.bias.grad) if train_params else None
+            if train_params and th.is_grad_enabled() and any(g is None for g in grads):
+                raise RuntimeError("fused linear: parameter gradients must be views of a ParamArena gradient buffer")
+            x = hidden_head(x, l1.weight, l1.bias, l2.weight, l2.bias, grads, act, train_params, (l1.weight, l2.weight))
         return x
 
 
@@ -172,6 +183,47 @@ def stacked_linear(x, weight, bias, wgrad, bgrad, act: int, train_params: bool, 
         y = th.bmm(x, weight.transpose(1, 2))
         return hip_ops.bias_act_fwd_(y, bias, act)
     return _StackedLinearFn.apply(x, weight, bias, wgrad, bgrad, act, train_params, *(owners if train_params else ()))
+
+
+class _HiddenHeadFn(th.autograd.Function):
+    """q = Linear_2(act(Linear_1(x))) with out_features(Linear_2) == 1, plain ([M, K]) or stacked ([G, M, K]) operands.
+    w1 [.., N, K], b1 [.., N], w2 [.., 1, N], b2 [.., 1] and their gradient views (None when frozen)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, grads, act: int, train_params: bool, *owners):
+        batched = x.dim() == 3
+        z = th.bmm(x, w1.transpose(1, 2)) if batched else th.mm(x, w1.t())
+        q = th.empty(*z.shape[:-1], 1, dtype=z.dtype, device=z.device)
+        hip_ops.hidden_head_fwd_(z, b1, act, w2, b2, q)  # z now holds y = act(z + b1)
+        ctx.act, ctx.train_params, ctx.batched, ctx.grads, ctx.n_owners = act, train_params, batched, grads, len(owners)
+        ctx.save_for_backward(x, w1, z, w2)
+        return q
+
+    @staticmethod
+    def backward(ctx, gq):
+        x, w1, y, w2 = ctx.saved_tensors
+        gw1, gb1, gw2, gb2 = ctx.grads if ctx.train_params else (None, None, None, None)
+        dz = th.empty_like(y)
+        hip_ops.hidden_head_bwd(gq.contiguous(), y, ctx.act, w2, dz, gb1, gw2, gb2)
+        if ctx.batched:
+            if ctx.train_params:
+                th.bmm(dz.transpose(1, 2), x, out=gw1)
+            dx = th.bmm(dz, w1) if ctx.needs_input_grad[0] else None
+        else:
+            if ctx.train_params:
+                th.mm(dz.t(), x, out=gw1)
+            dx = th.mm(dz, w1) if ctx.needs_input_grad[0] else None
+        return (dx,) + (None,) * (7 + ctx.n_owners)
+
+
+def hidden_head(x, w1, b1, w2, b2, grads, act: int, train_params: bool, owners=()):
+    """The last two layers of a Q network in one GEMM + one launch. `grads` = (w1.grad, b1.grad, w2.grad, b2.grad) views of
+    the gradient arena (or None when the parameters are frozen)."""
+    if th.is_grad_enabled() and (x.requires_grad or train_params):
+        return _HiddenHeadFn.apply(x, w1, b1, w2, b2, grads, act, train_params, *(owners if train_params else ()))
+    z = th.bmm(x, w1.transpose(1, 2)) if x.dim() == 3 else th.mm(x, w1.t())
+    q = th.empty(*z.shape[:-1], 1, dtype=z.dtype, device=z.device)
+    return hip_ops.hidden_head_fwd_(z, b1, act, w2, b2, q)
 
 
 class FastSacActor:
@@ -263,11 +315,18 @@ class FastTwinCritic:
             return QOut(net(x, train_params) for net in nets)
         g = 1 if only_first else len(self.nets)
         h = x.unsqueeze(0).expand(g, -1, -1)
-        for li, (w, wg, b, bg) in enumerate(self.stack):
-            if train_params and g != w.shape[0]:
-                raise RuntimeError("stacked critic: parameter gradients need all Q networks in the pass")
-            h = stacked_linear(h, w[:g], b[:g], None if wg is None else wg[:g], None if bg is None else bg[:g], self.acts[li],
-                               train_params, self.owners[li][:g])
+        stack = self.stack
+        scalar_head = len(stack) >= 2 and stack[-1][0].shape[1] == 1 and self.acts[-1] == ACT_NONE
+        if train_params and g != stack[0][0].shape[0]:
+            raise RuntimeError("stacked critic: parameter gradients need all Q networks in the pass")
+        cut = lambda t: None if t is None else t[:g]  # noqa: E731
+        for li, (w, wg, b, bg) in enumerate(stack[:-2] if scalar_head else stack):
+            h = stacked_linear(h, w[:g], b[:g], cut(wg), cut(bg), self.acts[li], train_params, self.owners[li][:g])
+        if scalar_head:
+            (w1, wg1, b1, bg1), (w2, wg2, b2, bg2) = stack[-2:]
+            grads = (cut(wg1), cut(bg1), cut(wg2), cut(bg2)) if train_params else None
+            h = hidden_head(h, w1[:g], b1[:g], w2[:g], b2[:g], grads, self.acts[-2], train_params,
+                            self.owners[-2][:g] + self.owners[-1][:g])
         out = QOut(h[i] for i in range(g))
         out.stacked = h
         return out

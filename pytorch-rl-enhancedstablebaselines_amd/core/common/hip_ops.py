@@ -278,6 +278,35 @@ def bias_act_bwd(gy, y, act: int, gz, gbias):
                                          stream_ptr()), "cstr_bias_act_bwd_f32")
 
 
+def hidden_head_fwd_(z, b1, act: int, w2, b2, q):
+    """y = act(z + b1) in place on z [G, m, k] (or [m, k]); q [G, m, 1] = y . w2 + b2 (a Q network's scalar head)."""
+    g, m, k = _gmn(z)
+    for t, nm, numel in ((z, "z", g * m * k), (b1, "b1", g * k), (w2, "w2", g * k), (b2, "b2", g), (q, "q", g * m)):
+        if _f32c(t, nm).numel() != numel:
+            raise ValueError(f"{nm} has {t.numel()} elements, expected {numel}")
+    check(nv.lib().cstr_hidden_head_fwd_f32(ptr(z), ptr(b1), C.c_int(act), ptr(w2), ptr(b2), ptr(q), C.c_int64(g), C.c_int64(m),
+                                            C.c_int64(k), stream_ptr()), "cstr_hidden_head_fwd_f32")
+    return q
+
+
+def hidden_head_bwd(gq, y, act: int, w2, dz, gb1=None, gw2=None, gb2=None):
+    """dz = gq * w2 * act'(y); with parameter gradients: gb1 = sum_m dz, gw2 = sum_m gq * y, gb2 = sum_m gq."""
+    g, m, k = _gmn(y)
+    _chk(dz, "dz", y.shape, th.float32)
+    for t, nm, numel in ((gq, "gq", g * m), (y, "y", g * m * k), (w2, "w2", g * k)):
+        if _f32c(t, nm).numel() != numel:
+            raise ValueError(f"{nm} has {t.numel()} elements, expected {numel}")
+    grads = (gb1, gw2, gb2)
+    if any(t is None for t in grads) != all(t is None for t in grads):
+        raise ValueError("gb1, gw2 and gb2 go together")
+    if gb1 is not None:
+        for t, nm, numel in ((gb1, "gb1", g * k), (gw2, "gw2", g * k), (gb2, "gb2", g)):
+            if _f32c(t, nm).numel() != numel:
+                raise ValueError(f"{nm} has {t.numel()} elements, expected {numel}")
+    check(nv.lib().cstr_hidden_head_bwd_f32(ptr(gq), ptr(y), C.c_int(act), ptr(w2), ptr(dz), ptr(gb1), ptr(gw2), ptr(gb2),
+                                            C.c_int64(g), C.c_int64(m), C.c_int64(k), stream_ptr()), "cstr_hidden_head_bwd_f32")
+
+
 def _rows(t, name, b, a):
     """A [b, a] float32 device matrix whose rows may be strided (a column slice of a wider row-major matrix)."""
     if not (isinstance(t, th.Tensor) and t.is_cuda and t.dtype == th.float32 and tuple(t.shape) == (b, a) and t.stride(1) == 1

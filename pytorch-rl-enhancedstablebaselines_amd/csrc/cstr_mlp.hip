@@ -114,6 +114,105 @@ __device__ __forceinline__ float block_sum_256(float v, float *sm)
     return r;
 }
 
+// ---- last hidden layer + scalar head of a Q network ------------------------------------------------------------
+// create_mlp(..., output_dim = 1) ends in  y = act(z + b1);  q = y . w2 + b2  (core/common/torch_layers.py:110-183,
+// ContinuousCritic: core/common/policies.py:960-987). The head is a matrix-VECTOR product (n = 1), which rocBLAS runs
+// as an 8 us degenerate GEMM; here it rides the epilogue of the previous layer: one wave per row applies bias +
+// activation to the GEMM output z IN PLACE and reduces the dot product with w2 in the same pass.
+// Grouped: z [G][m][k], b1 [G][k], w2 [G][k], b2 [G], q [G][m].
+template <int ACT, bool VEC4>
+__global__ __launch_bounds__(256) void hidden_head_fwd_kernel(float *__restrict__ z, const float *__restrict__ b1,
+                                                              const float *__restrict__ w2, const float *__restrict__ b2,
+                                                              float *__restrict__ q, const int64_t rows, const int m, const int k)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t row = blockIdx.x * (int64_t)(blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= rows) return;  // whole waves leave together; no barrier below
+    const int64_t g = row / m;
+    float *zr = z + row * k;
+    const float *br = b1 + g * k, *wr = w2 + g * k;
+    float acc = 0.0f;
+    if (VEC4) {
+        for (int c = lane * 4; c < k; c += 256) {
+            float4 v = *reinterpret_cast<const float4 *>(zr + c);
+            const float4 b = *reinterpret_cast<const float4 *>(br + c), w = *reinterpret_cast<const float4 *>(wr + c);
+            v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+            if (ACT == ACT_RELU) { v.x = fmaxf(v.x, 0.0f); v.y = fmaxf(v.y, 0.0f); v.z = fmaxf(v.z, 0.0f); v.w = fmaxf(v.w, 0.0f); }
+            if (ACT == ACT_TANH) { v.x = tanhf(v.x); v.y = tanhf(v.y); v.z = tanhf(v.z); v.w = tanhf(v.w); }
+            *reinterpret_cast<float4 *>(zr + c) = v;
+            acc += (v.x * w.x + v.y * w.y) + (v.z * w.z + v.w * w.w);
+        }
+    } else {
+        for (int c = lane; c < k; c += 64) {
+            float v = zr[c] + br[c];
+            if (ACT == ACT_RELU) v = fmaxf(v, 0.0f);
+            if (ACT == ACT_TANH) v = tanhf(v);
+            zr[c] = v;
+            acc += v * wr[c];
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if (lane == 0) q[row] = acc + b2[g];
+}
+
+// Backward of the pair, given gq = d(loss)/dq [G][m]:
+//   dz[m][c]  = gq[m] * w2[c] * act'(y[m][c])      (head's input gradient folded into the activation gradient)
+//   gb1[c]    = sum_m dz[m][c]                      gw2[c] = sum_m gq[m] * y[m][c]       gb2 = sum_m gq[m]
+// Same ownership as bias_act_bwd_kernel: a workgroup owns 64 columns of one group, WAVES waves stride over the rows with
+// eight rows of loads in flight; every output is written exactly once (deterministic, no atomics).
+template <int ACT, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void hidden_head_bwd_kernel(const float *__restrict__ gq, const float *__restrict__ y,
+                                                                     const float *__restrict__ w2, float *__restrict__ dz,
+                                                                     float *__restrict__ gb1, float *__restrict__ gw2,
+                                                                     float *__restrict__ gb2, const int m, const int k)
+{
+    __shared__ float part[3][WAVES][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + lane;
+    const int64_t g = blockIdx.y, goff = g * (int64_t)m * k;
+    gq += g * m;
+    y += goff;
+    dz += goff;
+    const float w = col < k ? w2[g * k + col] : 0.0f;
+    float s_b1 = 0.0f, s_w2 = 0.0f, s_b2 = 0.0f;
+    constexpr int FLY = 8;
+    for (int r0 = wave; r0 < m; r0 += FLY * WAVES) {
+        float t[FLY], u[FLY];
+#pragma unroll
+        for (int j = 0; j < FLY; ++j) {
+            const int r = r0 + j * WAVES;
+            t[j] = (r < m && col < k) ? y[(int64_t)r * k + col] : 0.0f;
+            u[j] = r < m ? gq[r] : 0.0f;
+        }
+#pragma unroll
+        for (int j = 0; j < FLY; ++j) {
+            const int r = r0 + j * WAVES;
+            float d = u[j] * w;
+            if (ACT == ACT_RELU) d = t[j] > 0.0f ? d : 0.0f;
+            if (ACT == ACT_TANH) d = d * (1.0f - t[j] * t[j]);
+            if (r < m && col < k) dz[(int64_t)r * k + col] = d;
+            s_b1 += d;
+            s_w2 += u[j] * t[j];
+            s_b2 += u[j];
+        }
+    }
+    part[0][wave][lane] = s_b1;
+    part[1][wave][lane] = s_w2;
+    part[2][wave][lane] = s_b2;
+    __syncthreads();
+    if (wave == 0 && gw2) {
+        float a = 0.0f, b = 0.0f, c = 0.0f;
+#pragma unroll
+        for (int v = 0; v < WAVES; ++v) { a += part[0][v][lane]; b += part[1][v][lane]; c += part[2][v][lane]; }
+        if (col < k) {
+            gb1[g * k + col] = a;
+            gw2[g * k + col] = b;
+        }
+        if (blockIdx.x == 0 && lane == 0) gb2[g] = c;  // every lane of a wave saw the same gq rows
+    }
+}
+
 // ---- squashed diagonal Gaussian (core/common/distributions.py:161-260) ----------------------------------
 
 constexpr float LOG_STD_MIN = -20.0f, LOG_STD_MAX = 2.0f;  // core/sac/policies.py:20-22
@@ -365,5 +464,36 @@ extern "C" int cstr_neg_mean_loss_f32(const float *q, float *gq, float *loss_out
     if (!q || !gq || batch <= 0) return CSTR_E_BADARG;
     if (batch > CSTR_MAX_SAMPLE_BATCH) return CSTR_E_UNSUPPORTED;
     neg_mean_loss_kernel<<<1, 256, 0, (hipStream_t)stream>>>(q, gq, loss_out, loss_sum, (int)batch);
+    return (int)hipGetLastError();
+}
+
+extern "C" int cstr_hidden_head_fwd_f32(float *z, const float *b1, int act, const float *w2, const float *b2, float *q, int64_t groups,
+                                        int64_t m, int64_t k, cstr_stream_t stream)
+{
+    if (!z || !b1 || !w2 || !b2 || !q || groups <= 0 || m <= 0 || k <= 0) return CSTR_E_BADARG;
+    if (act < 0 || act > 2 || m > 0x7fffffff || k > 0x7fffffff) return CSTR_E_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t rows = groups * m;
+    const unsigned grid = (unsigned)((rows + 3) / 4);
+    const bool v4 = (k & 3) == 0 && aligned16(z) && aligned16(b1) && aligned16(w2);
+#define HH_FWD(A, V) hidden_head_fwd_kernel<A, V><<<grid, 256, 0, s>>>(z, b1, w2, b2, q, rows, (int)m, (int)k)
+    if (v4) { if (act == 0) HH_FWD(0, true); else if (act == 1) HH_FWD(1, true); else HH_FWD(2, true); }
+    else { if (act == 0) HH_FWD(0, false); else if (act == 1) HH_FWD(1, false); else HH_FWD(2, false); }
+#undef HH_FWD
+    return (int)hipGetLastError();
+}
+
+extern "C" int cstr_hidden_head_bwd_f32(const float *gq, const float *y, int act, const float *w2, float *dz, float *gb1, float *gw2,
+                                        float *gb2, int64_t groups, int64_t m, int64_t k, cstr_stream_t stream)
+{
+    if (!gq || !y || !w2 || !dz || groups <= 0 || m <= 0 || k <= 0) return CSTR_E_BADARG;
+    if ((gb1 == nullptr) != (gw2 == nullptr) || (gw2 == nullptr) != (gb2 == nullptr)) return CSTR_E_BADARG;  // all three or none
+    if (act < 0 || act > 2 || m > 0x7fffffff || k > 0x7fffffff || groups > 65535) return CSTR_E_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid((unsigned)((k + 63) / 64), (unsigned)groups);
+#define HH_BWD(A, W) hidden_head_bwd_kernel<A, W><<<grid, W * 64, 0, s>>>(gq, y, w2, dz, gb1, gw2, gb2, (int)m, (int)k)
+    if (m >= 64) { if (act == 0) HH_BWD(0, 16); else if (act == 1) HH_BWD(1, 16); else HH_BWD(2, 16); }
+    else { if (act == 0) HH_BWD(0, 4); else if (act == 1) HH_BWD(1, 4); else HH_BWD(2, 4); }
+#undef HH_BWD
     return (int)hipGetLastError();
 }

@@ -212,3 +212,39 @@ def test_stacked_twin_critic_and_merged_heads_equal_per_network_path():
     assert rel_err(lp1.detach().cpu().numpy(), lp2.detach().cpu().numpy(), 1.0) < 1e-5
     gref = pol.actor_arena.grad.cpu().numpy()
     assert rel_err(g_merged.cpu().numpy(), gref, float(np.abs(gref).mean())) < 3e-5
+
+
+@pytest.mark.parametrize("G,M,K,act", [(1, 256, 256, 1), (2, 256, 256, 1), (2, 256, 300, 1), (1, 5, 37, 2), (3, 70, 64, 0), (2, 33, 400, 2)])
+def test_hidden_layer_plus_scalar_head_kernels(ops, G, M, K, act):
+    """cstr_hidden_head_{fwd,bwd}_f32 = bias + activation of the last hidden layer fused with the Q network's Linear(K -> 1)
+    head (torch_layers.py:110-183 with output_dim 1), against plain torch ops / autograd in fp64."""
+    g = th.Generator(device="cuda").manual_seed(G * 1000 + K)
+    z = th.randn(G, M, K, device="cuda", generator=g)
+    b1, w2 = th.randn(G, K, device="cuda", generator=g) * 0.3, th.randn(G, K, device="cuda", generator=g) / K ** 0.5
+    b2, gq = th.randn(G, device="cuda", generator=g), th.randn(G, M, device="cuda", generator=g)
+    zd, b1d, w2d, b2d = (t.double().requires_grad_(True) for t in (z, b1, w2, b2))
+    pre = zd + b1d[:, None, :]
+    yd = th.relu(pre) if act == 1 else (th.tanh(pre) if act == 2 else pre)
+    qd = (yd * w2d[:, None, :]).sum(-1) + b2d[:, None]
+    qd.backward(gq.double())
+    y, q = z.clone(), th.empty(G, M, 1, device="cuda")
+    ops.hidden_head_fwd_(y, b1, act, w2, b2, q)
+    assert rel_err(y.cpu().numpy(), yd.detach().cpu().numpy(), 1.0) < 1e-6
+    assert rel_err(q.cpu().numpy().reshape(G, M), qd.detach().cpu().numpy(), 1.0) < 3e-6
+    dz, gb1, gw2, gb2 = th.empty_like(y), th.full((G, K), 9.0, device="cuda"), th.full((G, K), 9.0, device="cuda"), th.full((G,), 9.0, device="cuda")
+    ops.hidden_head_bwd(gq, y, act, w2, dz, gb1, gw2, gb2)
+    assert rel_err(dz.cpu().numpy(), zd.grad.cpu().numpy(), 1.0) < 1e-6
+    scale = float(M) ** 0.5
+    assert rel_err(gb1.cpu().numpy(), b1d.grad.cpu().numpy(), scale) < 2e-6
+    assert rel_err(gw2.cpu().numpy(), w2d.grad.cpu().numpy(), scale) < 2e-6
+    assert rel_err(gb2.cpu().numpy(), b2d.grad.cpu().numpy(), scale) < 2e-6
+    dz2 = th.empty_like(y)
+    ops.hidden_head_bwd(gq, y, act, w2, dz2)  # frozen parameters: input gradient only
+    assert th.equal(dz, dz2)
+    with pytest.raises(ValueError):
+        ops.hidden_head_bwd(gq, y, act, w2, dz2, gb1, None, None)
+    if G == 1:  # 2-D operands
+        q2 = th.empty(M, 1, device="cuda")
+        y2 = z[0].clone()
+        ops.hidden_head_fwd_(y2, b1[0], act, w2[0], b2, q2)
+        assert th.equal(q2, q[0]) and th.equal(y2, y[0])
