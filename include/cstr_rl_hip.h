@@ -177,6 +177,15 @@ int cstr_replay_sample_mt19937_f32(const cstr_ring_t *ring, const int64_t *ring_
                                    float *out_obs, float *out_act, float *out_next_obs, float *out_done,
                                    float *out_rew, int64_t *out_row_idx, int64_t *out_env_idx, cstr_stream_t stream);
 
+/* The same draw, gathered straight into the critics' input rows -- ReplayBuffer.sample + the th.cat([obs, actions], dim=1)
+ * of ContinuousCritic.forward (core/common/policies.py:975-981) without the cat launches. Row width W = obs_dim + act_dim:
+ *   x_data [B][W] <- (observations | actions)          the critic input of the Bellman error
+ *   x_next [B][W] <- (next_observations | untouched)   the target critic's input; the actor head writes the action columns
+ *   x_pi   [B][W] <- (observations | untouched)        the critic input of the actor loss; may be NULL */
+int cstr_replay_sample_packed_mt19937_f32(const cstr_ring_t *ring, const int64_t *ring_ctl, uint32_t *mt_state, int64_t batch,
+                                          float *x_data, float *x_next, float *x_pi, float *out_done, float *out_rew,
+                                          int64_t *out_row_idx, int64_t *out_env_idx, cstr_stream_t stream);
+
 /* Target-Q: SAC core/sac/sac.py:250-254 (logp, ent_coef non-NULL), TD3 core/td3/td3.py:174-176 (both NULL):
  * out = rew + (1 - done) * gamma * (min(q1, q2) - ent_coef[0] * logp). ent_coef is a DEVICE scalar. */
 int cstr_td_target_min_f32(const float *q1, const float *q2, const float *logp, const float *rew, const float *done,
@@ -232,6 +241,23 @@ int cstr_squashed_gaussian_fwd_f32(const float *mean, const float *log_std_raw, 
 int cstr_squashed_gaussian_bwd_f32(const float *g_action, const float *g_logp, const float *action, const float *log_std_raw,
                                    const float *eps, float *g_mean, float *g_log_std_raw, int64_t batch, int act_dim,
                                    int in_stride, int g_action_stride, cstr_stream_t stream);
+
+/* The SAC actor's merged (mu | log_std) head in one pass (core/sac/policies.py:162-175; core/common/distributions.py:161-260):
+ * params [B][2A] = the head GEMM's output, gets `bias` [2A] added in place (NULL: already biased); eps [B][A] ~ N(0,1) is READ
+ * when rng_ctl is NULL and DRAWN (and written, for the backward) when rng_ctl is given; action = tanh(mean + exp(clamp(
+ * log_std)) * eps) with row stride `action_stride` (>= A: it may be a column block of the critic's input); logp [B] or NULL.
+ * rng_ctl: uint64[CSTR_RNG_CTL_WORDS] in HBM = { seed, offset, ticket, - }: Philox4x32-10 counter RNG + Box-Muller, the
+ * offset advances by B per launch on the device (graph-replay safe). */
+#define CSTR_RNG_CTL_WORDS 4
+#define CSTR_MAX_HEAD_ACT 4
+int cstr_gaussian_head_fwd_f32(float *params, const float *bias, float *eps, uint64_t *rng_ctl, float *action,
+                               int64_t action_stride, float *logp, int64_t batch, int act_dim, cstr_stream_t stream);
+
+/* Backward: g_params [B][2A] = d/d(mean | log_std_raw) from g_action (row stride ga_stride, or NULL) and g_logp ([B] or
+ * NULL); g_bias [2A] = column sums over the batch (or NULL). */
+int cstr_gaussian_head_bwd_f32(const float *g_action, int64_t ga_stride, const float *g_logp, const float *action,
+                               int64_t action_stride, const float *params, const float *eps, float *g_params, float *g_bias,
+                               int64_t batch, int act_dim, cstr_stream_t stream);
 
 /* SAC entropy coefficient (core/sac/sac.py:230-243): ent_coef_out = exp(log_alpha); grad_out = d/dlog_alpha of
  * -mean(log_alpha * (logp + target_entropy)) = -mean(logp + target_entropy). loss_sum / ent_coef_sum (device scalars,

@@ -117,6 +117,13 @@ class BaseAlgorithm:
         self.action_space.seed(seed)
         if self.env is not None:
             self.env.seed(seed)
+        self._reseed_device_rng(seed)
+
+    def _reseed_device_rng(self, seed: int) -> None:
+        """Device-resident counter RNG streams of the fused kernels follow `set_random_seed` like torch's generator does."""
+        fa = getattr(self, "_fast_actor", None)
+        if fa is not None and hasattr(fa, "seed_rng"):
+            fa.seed_rng(seed + 1000003 * self.rank)
 
     def get_env(self):
         return self.env

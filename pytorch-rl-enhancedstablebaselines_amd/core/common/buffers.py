@@ -186,6 +186,22 @@ class ReplayBuffer(BaseBuffer):
             env.normalize_batch_(out.observations, out.next_observations, out.rewards)
         return out
 
+    # ---- packed batches: sampled rows land directly in the critics' input buffers -------------------------------
+    def alloc_packed_batch(self, batch_size: int, with_pi: bool = True) -> "PackedBatch":
+        return PackedBatch(batch_size, self.obs_shape[0], self.action_dim, self.device, with_pi)
+
+    def sample_packed_into(self, pb: "PackedBatch", row_idx=None, env_idx=None) -> "PackedBatch":
+        """`sample` + the critics' torch.cat([obs, actions], 1) (core/common/policies.py:975-981) in one launch. Not
+        available with a VecNormalize normaliser (its kernel works on contiguous observation batches)."""
+        if self.size() == 0:
+            raise ValueError("high <= 0")
+        if self.normalizer is not None:
+            raise ValueError("packed batches do not go through VecNormalize; use sample_into")
+        with th.cuda.device(self.device):
+            hip_ops.replay_sample_packed(self.ring, self.sampler_stream, pb.x_data.shape[0], pb.x_data, pb.x_next, pb.x_pi,
+                                         pb.samples.dones, pb.samples.rewards, row_idx, env_idx)
+        return pb
+
     def sample(self, batch_size: int, env: Any = None) -> ReplayBufferSamples:
         """reference: buffers.py:106-115, :285-325. Returns fresh device tensors
         (observations, actions, next_observations, dones, rewards)."""
@@ -195,3 +211,18 @@ class ReplayBuffer(BaseBuffer):
         bi = th.empty(batch_size, dtype=th.int64, device=self.device)
         ei = th.empty(batch_size, dtype=th.int64, device=self.device)
         return self.sample_into(self.alloc_batch(batch_size), bi, ei), bi, ei
+
+
+class PackedBatch:
+    """Static critic-input buffers of one sampled batch, W = obs_dim + act_dim columns each:
+    x_data = (obs | act), x_next = (next_obs | next action, written by the actor head), x_pi = (obs | pi(obs), likewise).
+    `samples` exposes the usual ReplayBufferSamples fields as (row-strided) views of them."""
+
+    def __init__(self, batch_size: int, obs_dim: int, act_dim: int, device, with_pi: bool = True):
+        e = lambda *s: th.zeros(*s, dtype=th.float32, device=device)  # noqa: E731
+        w = obs_dim + act_dim
+        self.obs_dim, self.act_dim = obs_dim, act_dim
+        self.x_data, self.x_next = e(batch_size, w), e(batch_size, w)
+        self.x_pi = e(batch_size, w) if with_pi else None
+        self.samples = ReplayBufferSamples(self.x_data[:, :obs_dim], self.x_data[:, obs_dim:], self.x_next[:, :obs_dim],
+                                           e(batch_size, 1), e(batch_size, 1))

@@ -236,11 +236,17 @@ class FastSacActor:
         self.mu, self.log_std = actor.mu, actor.log_std
         self.act_dim = actor.mu.weight.shape[0]
         self.head = head
+        self.rng_ctl = None  # in-kernel Philox stream of the sampling head, seeded from torch's seed at first use
         if head is not None:
             w, wg, b, bg = head
             a2 = 2 * self.act_dim
             self._hw, self._hb = w.view(a2, -1), b.view(a2)
             self._hwg, self._hbg = wg.view(a2, -1), bg.view(a2)
+
+    def seed_rng(self, seed: int) -> None:
+        """Restart the sampling head's in-kernel Philox stream (keeps the tensor: captured graphs hold its address)."""
+        if self.rng_ctl is not None:
+            self.rng_ctl.copy_(hip_ops.new_rng_ctl(seed, self.rng_ctl.device))
 
     def dist_params(self, obs: th.Tensor, train_params: bool = True) -> th.Tensor:
         """[B, 2A] = [mean | log_std_raw]"""
@@ -252,11 +258,33 @@ class FastSacActor:
             return hip_ops.bias_act_fwd_(th.mm(h, self._hw.t()), self._hb, ACT_NONE)
         return _MergedHeadFn.apply(h, self._hw, self._hb, self._hwg, self._hbg, train_params, self.mu.weight, self.log_std.weight)
 
-    def action_log_prob(self, obs: th.Tensor, eps: Optional[th.Tensor] = None, train_params: bool = True, want_logp: bool = True):
-        params = self.dist_params(obs, train_params)
-        if eps is None:
-            eps = self.actor.action_dist.draw_eps((params.shape[0], self.act_dim), params.device)
-        return squashed_gaussian(params, eps, self.act_dim, want_logp)
+    def action_log_prob(self, obs: th.Tensor, eps: Optional[th.Tensor] = None, train_params: bool = True, want_logp: bool = True,
+                        xbuf: Optional[th.Tensor] = None):
+        """`xbuf`: a critic input buffer [B, D + A] (observation columns already filled): the action is written into its last
+        A columns and the BUFFER is returned in place of the action (torch.cat((obs, action)) without the launch)."""
+        dist = self.actor.action_dist
+        if eps is None and dist.eps_queue:  # teacher-forced draw (tests)
+            eps = dist.draw_eps((obs.shape[0], self.act_dim), obs.device)
+        if self.head is None or self.act_dim > hip_ops.nv.MAX_HEAD_ACT:
+            params = self.dist_params(obs, train_params)
+            if eps is None:
+                eps = dist.draw_eps((params.shape[0], self.act_dim), params.device)
+            action, logp = squashed_gaussian(params, eps, self.act_dim, want_logp)
+            if xbuf is not None:
+                return th.cat((xbuf[:, :xbuf.shape[1] - self.act_dim], action), dim=1), logp
+            return action, logp
+        h = self.latent(obs, train_params)
+        if self.rng_ctl is None:
+            self.rng_ctl = hip_ops.new_rng_ctl(th.initial_seed(), obs.device)
+        grad = th.is_grad_enabled() and (h.requires_grad or train_params)
+        tp = train_params and grad
+        args = (h, self._hw, self._hb, self._hwg if tp else None, self._hbg if tp else None, eps, self.rng_ctl, xbuf, tp, want_logp)
+        if grad:
+            out = _GaussianHeadFn.apply(*args, *((self.mu.weight, self.log_std.weight) if tp else ()))
+        else:
+            with th.no_grad():
+                out = _GaussianHeadFn.apply(*args)
+        return (out[0], out[1]) if want_logp else (out[0], None)
 
 
 class _MergedHeadFn(th.autograd.Function):
@@ -276,6 +304,50 @@ class _MergedHeadFn(th.autograd.Function):
             th.mm(gy.t(), h, out=ctx.wg)
         dx = th.mm(gy, w) if ctx.needs_input_grad[0] else None
         return dx, None, None, None, None, None, None, None
+
+
+class _GaussianHeadFn(th.autograd.Function):
+    """Merged (mu | log_std) head GEMM + ONE launch for bias, rsample, tanh and log-prob (noise drawn in the kernel unless
+    `eps` is given); backward = ONE launch (d params + bias gradient) + the head's two GEMMs."""
+
+    @staticmethod
+    def forward(ctx, h, w, b, wg, bg, eps, rng_ctl, xbuf, train_params: bool, want_logp: bool, *owners):
+        params = th.mm(h, w.t())
+        n, a = params.shape[0], params.shape[1] // 2
+        # xbuf: a critic input [B, D + A] whose LAST A columns receive the action (no torch.cat); the whole buffer is the
+        # output then, so the critic's input gradient comes back as one tensor and its action columns are read in place
+        action = xbuf[:, xbuf.shape[1] - a:] if xbuf is not None else th.empty(n, a, dtype=params.dtype, device=params.device)
+        logp = th.empty(n, dtype=params.dtype, device=params.device) if want_logp else None
+        if eps is None:
+            eps = th.empty(n, a, dtype=params.dtype, device=params.device)
+        else:
+            rng_ctl = None
+        hip_ops.gaussian_head_fwd_(params, b, eps, rng_ctl, action, logp)
+        ctx.train_params, ctx.wg, ctx.bg, ctx.n_owners = train_params, wg, bg, len(owners)
+        ctx.save_for_backward(h, w, params, eps)
+        ctx.action, ctx.a = action.detach(), a
+        ctx.set_materialize_grads(False)
+        out = action
+        if xbuf is not None:
+            ctx.mark_dirty(xbuf)
+            out = xbuf
+        return (out, logp) if want_logp else (out,)
+
+    @staticmethod
+    def backward(ctx, g_action, g_logp=None):
+        h, w, params, eps = ctx.saved_tensors
+        action = ctx.action
+        g_params = th.empty_like(params)
+        if g_action is not None:
+            if g_action.stride(1) != 1:
+                g_action = g_action.contiguous()
+            g_action = g_action[:, g_action.shape[1] - ctx.a:]  # the action columns of d(loss)/d(critic input)
+        hip_ops.gaussian_head_bwd(g_action, None if g_logp is None else g_logp.contiguous(), action, params, eps, g_params,
+                                  ctx.bg if ctx.train_params else None)
+        if ctx.train_params:
+            th.mm(g_params.t(), h, out=ctx.wg)
+        dx = th.mm(g_params, w) if ctx.needs_input_grad[0] else None
+        return (dx,) + (None,) * (9 + ctx.n_owners)
 
 
 class QOut(tuple):

@@ -188,6 +188,21 @@ def vecnorm_apply(cfg, vn_state, obs, next_obs, reward):
                                           stream_ptr()), "cstr_vecnorm_apply_f32")
 
 
+def replay_sample_packed(ring: DeviceRing, mt_state, batch: int, x_data, x_next, x_pi, out_done, out_rew, out_row_idx=None,
+                         out_env_idx=None):
+    """ReplayBuffer.sample gathered straight into the critic-input rows (obs | act), (next_obs | .), (obs | .)."""
+    w = ring.obs_dim + ring.act_dim
+    _chk(mt_state, "mt_state", (nv.MT_STATE_WORDS,), th.int32)
+    _chk(x_data, "x_data", (batch, w), th.float32), _chk(x_next, "x_next", (batch, w), th.float32), _opt(x_pi, "x_pi", (batch, w), th.float32)
+    _chk(out_done, "out_done", (batch, 1), th.float32), _chk(out_rew, "out_rew", (batch, 1), th.float32)
+    _opt(out_row_idx, "out_row_idx", (batch,), th.int64), _opt(out_env_idx, "out_env_idx", (batch,), th.int64)
+    if not 0 < batch <= nv.MAX_SAMPLE_BATCH:
+        raise ValueError(f"batch_size must be in [1, {nv.MAX_SAMPLE_BATCH}], got {batch}")
+    check(nv.lib().cstr_replay_sample_packed_mt19937_f32(C.byref(ring.c), ptr(ring.ctl), ptr(mt_state), C.c_int64(batch), ptr(x_data),
+                                                         ptr(x_next), ptr(x_pi), ptr(out_done), ptr(out_rew), ptr(out_row_idx),
+                                                         ptr(out_env_idx), stream_ptr()), "cstr_replay_sample_packed_mt19937_f32")
+
+
 def td_target_min(q1, q2, logp, rew, done, ent_coef, gamma: float, out):
     n = q1.numel()
     for t, nm in ((q1, "q1"), (q2, "q2"), (rew, "rew"), (done, "done"), (out, "out")):
@@ -276,6 +291,39 @@ def bias_act_bwd(gy, y, act: int, gz, gbias):
             raise ValueError(f"gbias has {gbias.numel()} elements, expected {g * n}")
     check(nv.lib().cstr_bias_act_bwd_f32(ptr(gy), ptr(y), C.c_int(act), ptr(gz), ptr(gbias), C.c_int64(g), C.c_int64(m), C.c_int64(n),
                                          stream_ptr()), "cstr_bias_act_bwd_f32")
+
+
+def new_rng_ctl(seed: int, device) -> th.Tensor:
+    """{seed, offset, ticket, -} of the in-kernel Philox stream (cstr_gaussian_head_fwd_f32), int64 bit patterns"""
+    return th.tensor([int(seed) & 0x7FFFFFFFFFFFFFFF, 0, 0, 0], dtype=th.int64).to(device)
+
+
+def gaussian_head_fwd_(params, bias, eps, rng_ctl, action, logp):
+    """params [B, 2A] += bias in place; action [B, A] (row-strided view allowed) = tanh(mean + std * eps); eps is drawn in
+    the kernel when rng_ctl is given (and stored for the backward), read otherwise."""
+    b, a2 = params.shape
+    a = a2 // 2
+    _chk(params, "params", (b, 2 * a), th.float32), _chk(eps, "eps", (b, a), th.float32)
+    if bias is not None:
+        _chk(bias, "bias", (2 * a,), th.float32)
+    _opt(rng_ctl, "rng_ctl", (nv.RNG_CTL_WORDS,), th.int64), _opt(logp, "logp", (b,), th.float32)
+    stride = _rows(action, "action", b, a)
+    if a > nv.MAX_HEAD_ACT:
+        raise ValueError(f"gaussian head supports up to {nv.MAX_HEAD_ACT} action dimensions, got {a}")
+    check(nv.lib().cstr_gaussian_head_fwd_f32(ptr(params), ptr(bias), ptr(eps), ptr(rng_ctl), ptr(action), C.c_int64(stride), ptr(logp),
+                                              C.c_int64(b), C.c_int(a), stream_ptr()), "cstr_gaussian_head_fwd_f32")
+
+
+def gaussian_head_bwd(g_action, g_logp, action, params, eps, g_params, g_bias):
+    b, a2 = params.shape
+    a = a2 // 2
+    _chk(params, "params", (b, 2 * a), th.float32), _chk(eps, "eps", (b, a), th.float32), _chk(g_params, "g_params", (b, 2 * a), th.float32)
+    _opt(g_logp, "g_logp", (b,), th.float32), _opt(g_bias, "g_bias", (2 * a,), th.float32)
+    stride = _rows(action, "action", b, a)
+    ga_stride = 0 if g_action is None else _rows(g_action, "g_action", b, a)
+    check(nv.lib().cstr_gaussian_head_bwd_f32(ptr(g_action), C.c_int64(ga_stride), ptr(g_logp), ptr(action), C.c_int64(stride),
+                                              ptr(params), ptr(eps), ptr(g_params), ptr(g_bias), C.c_int64(b), C.c_int(a), stream_ptr()),
+          "cstr_gaussian_head_bwd_f32")
 
 
 def hidden_head_fwd_(z, b1, act: int, w2, b2, q):

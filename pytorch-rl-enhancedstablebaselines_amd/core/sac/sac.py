@@ -76,7 +76,7 @@ class SAC(OffPolicyAlgorithm):
         self._loss_sums = dict(actor=sb[0:1], critic=sb[1:2], ent_coef_loss=sb[2:3], ent_coef=sb[3:4])
         self._loss_now = dict(actor=z(), critic=z())
         self._ent_coef_buf = z()
-        self._static_batch = None
+        self._static_batch, self._packed = None, None
         # fused learner path (core/common/fused.py): GEMMs in rocBLAS, everything else hand-written HIP
         self.fused_learner = self._fused_supported()
         if self.fused_learner:
@@ -103,10 +103,26 @@ class SAC(OffPolicyAlgorithm):
         self.critic_target = self.policy.critic_target
 
     def _batch(self, batch_size: int):
-        if self._static_batch is None or self._static_batch.observations.shape[0] != batch_size:
-            self._static_batch = self.replay_buffer.alloc_batch(batch_size)
+        if self._static_batch is None or self._static_batch.observations.shape[0] != batch_size or self._packed is not None:
+            self._static_batch, self._packed = self.replay_buffer.alloc_batch(batch_size), None
             self._target_q = th.empty(batch_size, 1, dtype=th.float32, device=self.device)
         return self._static_batch
+
+    def _use_packed_batch(self) -> bool:
+        """Sample straight into the critics' input rows (no torch.cat launches): the fused path with the merged actor head and
+        the stock ReplayBuffer without a VecNormalize normaliser."""
+        from core.common.buffers import ReplayBuffer
+
+        rb = self.replay_buffer
+        return (self.fused_learner and self._fast_actor.head is not None and type(rb) is ReplayBuffer and rb.normalizer is None
+                and self._fast_actor.act_dim <= hip_ops.nv.MAX_HEAD_ACT)
+
+    def _packed_batch(self, batch_size: int):
+        if self._packed is None or self._packed.x_data.shape[0] != batch_size:
+            self._packed = self.replay_buffer.alloc_packed_batch(batch_size)
+            self._static_batch = self._packed.samples
+            self._target_q = th.empty(batch_size, 1, dtype=th.float32, device=self.device)
+        return self._packed
 
     def train(self, gradient_steps: int, batch_size: int = 64) -> None:
         """reference: sac.py:199-296 = host prologue (lr schedule) + device work + host epilogue (logger)."""
@@ -145,7 +161,12 @@ class SAC(OffPolicyAlgorithm):
         """The same statements as `_gradient_step_aten` (sac.py:215-287), evaluated on the fused path: losses are
         backward roots whose kernels emit d(loss)/d(inputs) directly; parameter gradients land in the arenas."""
         s, pol = self._loss_sums, self.policy
-        rd = self.replay_buffer.sample_into(self._batch(batch_size))  # :215
+        pb = None
+        if self._use_packed_batch():
+            pb = self.replay_buffer.sample_packed_into(self._packed_batch(batch_size))  # :215 + the critics' cat([obs, act])
+            rd = pb.samples
+        else:
+            rd = self.replay_buffer.sample_into(self._batch(batch_size))  # :215
         B = rd.observations.shape[0]
         if not hasattr(self, "_g_bufs") or self._g_bufs[0].shape[0] != B:
             e = lambda *sh: th.empty(*sh, dtype=th.float32, device=self.device)  # noqa: E731
@@ -153,7 +174,10 @@ class SAC(OffPolicyAlgorithm):
         gq, g_lp = self._g_bufs
         gq1, gq2 = gq[0], gq[1]
 
-        actions_pi, log_prob = self._fast_actor.action_log_prob(rd.observations)  # :222
+        if pb is not None:  # x_pi = (obs | pi(obs)): the actor head writes the action columns of the critic input itself
+            x_pi, log_prob = self._fast_actor.action_log_prob(rd.observations, xbuf=pb.x_pi.detach())  # :222
+        else:
+            actions_pi, log_prob = self._fast_actor.action_log_prob(rd.observations)  # :222
 
         if self.ent_coef_optimizer is not None:  # :230-243
             # ent_coef = exp(log_ent_coef) BEFORE the update (:230); the updated value is first used by the next gradient
@@ -169,11 +193,15 @@ class SAC(OffPolicyAlgorithm):
             s["ent_coef"] += ent_coef
 
         with th.no_grad():  # :245-254
-            next_actions, next_log_prob = self._fast_actor.action_log_prob(rd.next_observations, train_params=False)
-            q1_t, q2_t = self._fast_critic_target(rd.next_observations, next_actions, train_params=False)
+            if pb is not None:
+                x_next, next_log_prob = self._fast_actor.action_log_prob(rd.next_observations, train_params=False, xbuf=pb.x_next)
+                q1_t, q2_t = self._fast_critic_target.forward_input(x_next, train_params=False)
+            else:
+                next_actions, next_log_prob = self._fast_actor.action_log_prob(rd.next_observations, train_params=False)
+                q1_t, q2_t = self._fast_critic_target(rd.next_observations, next_actions, train_params=False)
             hip_ops.td_target_min(q1_t, q2_t, next_log_prob, rd.rewards, rd.dones, ent_coef, self.gamma, self._target_q)
 
-        qs = self._fast_critic(rd.observations, rd.actions)  # :258
+        qs = self._fast_critic.forward_input(pb.x_data) if pb is not None else self._fast_critic(rd.observations, rd.actions)  # :258
         q1, q2 = qs
         hip_ops.twin_q_loss(q1, q2, self._target_q, 0.5, gq1, gq2, self._loss_now["critic"], s["critic"])  # :261
         fused.backward_q(qs, gq)  # :266-268
@@ -182,7 +210,9 @@ class SAC(OffPolicyAlgorithm):
             self.ent_coef_optimizer.step()  # :240-243, gradient averaged by the critic's collective
         self.critic.optimizer.step()
 
-        qs_pi = self._fast_critic(rd.observations, actions_pi, train_params=False)  # :273-275 (critic weights frozen)
+        # :273-275 (critic weights frozen)
+        qs_pi = (self._fast_critic.forward_input(x_pi, train_params=False) if pb is not None
+                 else self._fast_critic(rd.observations, actions_pi, train_params=False))
         q1_pi, q2_pi = qs_pi
         hip_ops.sac_actor_loss(log_prob, q1_pi, q2_pi, ent_coef, g_lp, gq1, gq2, self._loss_now["actor"], s["actor"])
         if qs_pi.stacked is not None:  # :279-281

@@ -268,6 +268,112 @@ __global__ void squashed_gaussian_bwd_kernel(const float *__restrict__ g_action,
     }
 }
 
+// ---- SAC actor head: bias + rsample + tanh + log-prob in one pass, noise from an in-kernel counter RNG ----------------
+// The merged mu / log_std GEMM output z [B][2A] gets its bias here (no separate epilogue launch); eps ~ N(0, 1) is either
+// given (teacher-forced tests) or drawn in the kernel: Philox4x32-10 keyed by rng_ctl[0], counter = (rng_ctl[1] + row, pair)
+// -> Box-Muller, so no ATen generator launch (and none of the two generator-state fills PyTorch issues before every replay
+// of a graph that captured torch.randn). rng_ctl = {seed, offset, ticket, -} lives in HBM; the last workgroup advances the
+// offset, so graph replays continue the stream. `action` may be a column block of a wider row (the critic's input buffer).
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t out[4])
+{
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        c1 = (uint32_t)p1; c3 = (uint32_t)p0; c0 = n0; c2 = n2;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float &z0, float &z1)
+{
+    const float u1 = ((float)(a >> 8) + 0.5f) * (1.0f / 16777216.0f);  // (0, 1): 24 random bits, never 0
+    const float u2 = ((float)(b >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    const float r = sqrtf(-2.0f * logf(u1)), t = 6.28318530717958647692f * u2;
+    z0 = r * cosf(t);
+    z1 = r * sinf(t);
+}
+
+__global__ __launch_bounds__(64) void gaussian_head_fwd_kernel(float *__restrict__ params, const float *__restrict__ bias,
+                                                               float *__restrict__ eps, uint64_t *__restrict__ rng_ctl,
+                                                               float *__restrict__ action, const int64_t action_stride,
+                                                               float *__restrict__ logp, const int64_t batch, const int act_dim)
+{
+    const float half_log_2pi = 0.91893853320467274178f;
+    const uint64_t seed = rng_ctl ? rng_ctl[0] : 0ull, base = rng_ctl ? rng_ctl[1] : 0ull;
+    for (int64_t b = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; b < batch; b += (int64_t)gridDim.x * blockDim.x) {
+        float *pr = params + b * 2 * act_dim;
+        float lp = 0.0f, corr = 0.0f;
+        for (int j0 = 0; j0 < act_dim; j0 += 2) {
+            float e[2];
+            if (rng_ctl) {
+                const uint64_t ctr = base + (uint64_t)b;
+                uint32_t r[4];
+                philox4x32_10((uint32_t)ctr, (uint32_t)(ctr >> 32), (uint32_t)(j0 >> 1), 0u, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+                box_muller(r[0], r[1], e[0], e[1]);
+            }
+            for (int jj = 0; jj < 2 && j0 + jj < act_dim; ++jj) {
+                const int j = j0 + jj;
+                if (rng_ctl) eps[b * act_dim + j] = e[jj];
+                else e[jj] = eps[b * act_dim + j];
+                float mu = pr[j], raw = pr[act_dim + j];
+                if (bias) { mu += bias[j]; raw += bias[act_dim + j]; pr[j] = mu; pr[act_dim + j] = raw; }
+                const float ls = fminf(fmaxf(raw, LOG_STD_MIN), LOG_STD_MAX);  // core/sac/policies.py:173
+                const float s = expf(ls);
+                const float u = mu + s * e[jj];  // Normal.rsample (distributions.py:183)
+                const float a = tanhf(u);
+                action[b * action_stride + j] = a;
+                const float d = u - mu, var = s * s;
+                lp += -(d * d) / (2.0f * var) - logf(s) - half_log_2pi;
+                corr += logf(1.0f - a * a + 1e-6f);  // distributions.py:232
+            }
+        }
+        if (logp) logp[b] = lp - corr;
+    }
+    if (rng_ctl && last_block_ticket(reinterpret_cast<unsigned long long *>(rng_ctl + 2)) && threadIdx.x == 0)
+        rng_ctl[1] = base + (uint64_t)batch;
+}
+
+// Backward (same algebra as squashed_gaussian_bwd_kernel) + the merged head's bias gradient (column sums over the batch).
+// One workgroup: the batch is a few hundred rows.
+__global__ __launch_bounds__(256) void gaussian_head_bwd_kernel(const float *__restrict__ g_action, const int64_t ga_stride,
+                                                                const float *__restrict__ g_logp, const float *__restrict__ action,
+                                                                const int64_t action_stride, const float *__restrict__ params,
+                                                                const float *__restrict__ eps, float *__restrict__ g_params,
+                                                                float *__restrict__ g_bias, const int64_t batch, const int act_dim)
+{
+    __shared__ float sm[4];
+    float col[2 * CSTR_MAX_HEAD_ACT];
+#pragma unroll
+    for (int j = 0; j < 2 * CSTR_MAX_HEAD_ACT; ++j) col[j] = 0.0f;
+    for (int64_t b = threadIdx.x; b < batch; b += 256) {
+        const float gl = g_logp ? g_logp[b] : 0.0f;
+#pragma unroll
+        for (int j = 0; j < CSTR_MAX_HEAD_ACT; ++j) {
+            if (j >= act_dim) break;
+            const float a = action[b * action_stride + j], raw = params[b * 2 * act_dim + act_dim + j];
+            const float s = expf(fminf(fmaxf(raw, LOG_STD_MIN), LOG_STD_MAX));
+            const float one_m = 1.0f - a * a;
+            const float ga = g_action ? g_action[b * ga_stride + j] : 0.0f;
+            const float gu = ga * one_m + gl * (2.0f * a * one_m / (one_m + 1e-6f));
+            const float gls = (raw >= LOG_STD_MIN && raw <= LOG_STD_MAX) ? gu * eps[b * act_dim + j] * s - gl : 0.0f;
+            g_params[b * 2 * act_dim + j] = gu;
+            g_params[b * 2 * act_dim + act_dim + j] = gls;
+            col[j] += gu;
+            col[CSTR_MAX_HEAD_ACT + j] += gls;
+        }
+    }
+    if (g_bias) {
+#pragma unroll
+        for (int j = 0; j < CSTR_MAX_HEAD_ACT; ++j) {
+            if (j >= act_dim) break;
+            const float m = block_sum_256(col[j], sm), l = block_sum_256(col[CSTR_MAX_HEAD_ACT + j], sm);
+            if (threadIdx.x == 0) { g_bias[j] = m; g_bias[act_dim + j] = l; }
+        }
+    }
+}
+
 // ---- loss heads (single workgroup; batch <= 16384) -----------------------------------------------------
 
 // SAC entropy coefficient (core/sac/sac.py:230-243): ent_coef = exp(log_alpha); loss = -mean(log_alpha * (logp + H));
@@ -495,5 +601,28 @@ extern "C" int cstr_hidden_head_bwd_f32(const float *gq, const float *y, int act
     if (m >= 64) { if (act == 0) HH_BWD(0, 16); else if (act == 1) HH_BWD(1, 16); else HH_BWD(2, 16); }
     else { if (act == 0) HH_BWD(0, 4); else if (act == 1) HH_BWD(1, 4); else HH_BWD(2, 4); }
 #undef HH_BWD
+    return (int)hipGetLastError();
+}
+
+extern "C" int cstr_gaussian_head_fwd_f32(float *params, const float *bias, float *eps, uint64_t *rng_ctl, float *action,
+                                          int64_t action_stride, float *logp, int64_t batch, int act_dim, cstr_stream_t stream)
+{
+    if (!params || !eps || !action || batch <= 0 || act_dim <= 0 || action_stride < act_dim) return CSTR_E_BADARG;
+    if (act_dim > CSTR_MAX_HEAD_ACT) return CSTR_E_UNSUPPORTED;
+    const int64_t g = (batch + 63) / 64;
+    gaussian_head_fwd_kernel<<<(unsigned)(g < 4096 ? g : 4096), 64, 0, (hipStream_t)stream>>>(params, bias, eps, rng_ctl, action,
+                                                                                             action_stride, logp, batch, act_dim);
+    return (int)hipGetLastError();
+}
+
+extern "C" int cstr_gaussian_head_bwd_f32(const float *g_action, int64_t ga_stride, const float *g_logp, const float *action,
+                                          int64_t action_stride, const float *params, const float *eps, float *g_params,
+                                          float *g_bias, int64_t batch, int act_dim, cstr_stream_t stream)
+{
+    if (!action || !params || !eps || !g_params || batch <= 0 || act_dim <= 0 || action_stride < act_dim) return CSTR_E_BADARG;
+    if (g_action && ga_stride < act_dim) return CSTR_E_BADARG;
+    if (act_dim > CSTR_MAX_HEAD_ACT || batch > 65536) return CSTR_E_UNSUPPORTED;
+    gaussian_head_bwd_kernel<<<1, 256, 0, (hipStream_t)stream>>>(g_action, ga_stride, g_logp, action, action_stride, params, eps,
+                                                                 g_params, g_bias, batch, act_dim);
     return (int)hipGetLastError();
 }

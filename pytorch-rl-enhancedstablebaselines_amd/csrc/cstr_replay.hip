@@ -109,7 +109,11 @@ __device__ int mt_randint_fill(SampleShared &sh, int pos, uint32_t rng, int coun
     return pos;
 }
 
-template <int D, int A>
+// PACKED: the batch is gathered straight into the critics' input rows (ContinuousCritic.forward's th.cat([obs, actions], 1),
+// core/common/policies.py:975-981, without the cat launches): out_obs = x_data [B][D+A] <- (obs | action),
+// out_next_obs = x_next [B][D+A] <- (next_obs | .), out_act = x_pi [B][D+A] or NULL <- (obs | .); the '.' columns belong
+// to the actor head kernel. Rows are (D+A)*4 bytes apart (8-byte aligned), so the stores are float2.
+template <int D, int A, bool PACKED = false>
 __global__ __launch_bounds__(TPB) void replay_sample_kernel(const cstr_ring_t ring, const int64_t *__restrict__ ring_ctl,
                                                             uint32_t *__restrict__ mt_state, const int batch,
                                                             float *__restrict__ out_obs, float *__restrict__ out_act,
@@ -139,6 +143,28 @@ __global__ __launch_bounds__(TPB) void replay_sample_kernel(const cstr_ring_t ri
         const float4 x0 = *reinterpret_cast<const float4 *>(ring.obs + o * D);
         const float4 y0 = *reinterpret_cast<const float4 *>(ring.next_obs + o * D);
         const float dn = ring.done[o], to = ring.timeout[o], rw = ring.rew[o];
+        if (PACKED) {
+            constexpr int W = D + A;
+            float *xd = out_obs + (int64_t)b * W, *xn = out_next_obs + (int64_t)b * W, *xp = out_act ? out_act + (int64_t)b * W : nullptr;
+            const float2 x01 = make_float2(x0.x, x0.y), x23 = make_float2(x0.z, x0.w);
+            reinterpret_cast<float2 *>(xd)[0] = x01; reinterpret_cast<float2 *>(xd)[1] = x23;
+            reinterpret_cast<float2 *>(xn)[0] = make_float2(y0.x, y0.y); reinterpret_cast<float2 *>(xn)[1] = make_float2(y0.z, y0.w);
+            if (xp) { reinterpret_cast<float2 *>(xp)[0] = x01; reinterpret_cast<float2 *>(xp)[1] = x23; }
+            if (D == 8) {
+                const float4 x1 = *reinterpret_cast<const float4 *>(ring.obs + o * D + 4), y1 = *reinterpret_cast<const float4 *>(ring.next_obs + o * D + 4);
+                reinterpret_cast<float2 *>(xd)[2] = make_float2(x1.x, x1.y); reinterpret_cast<float2 *>(xd)[3] = make_float2(x1.z, x1.w);
+                reinterpret_cast<float2 *>(xn)[2] = make_float2(y1.x, y1.y); reinterpret_cast<float2 *>(xn)[3] = make_float2(y1.z, y1.w);
+                if (xp) { reinterpret_cast<float2 *>(xp)[2] = make_float2(x1.x, x1.y); reinterpret_cast<float2 *>(xp)[3] = make_float2(x1.z, x1.w); }
+            }
+#pragma unroll
+            for (int j = 0; j < A; j += 2)
+                *reinterpret_cast<float2 *>(xd + D + j) = *reinterpret_cast<const float2 *>(ring.act + o * A + j);
+            out_done[b] = dn * (1.0f - to);  // buffers.py:322
+            out_rew[b] = rw;
+            if (out_row_idx) out_row_idx[b] = r;
+            if (out_env_idx) out_env_idx[b] = e;
+            continue;
+        }
         *reinterpret_cast<float4 *>(out_obs + (int64_t)b * D) = x0;
         *reinterpret_cast<float4 *>(out_next_obs + (int64_t)b * D) = y0;
         if (D == 8) {
@@ -325,6 +351,28 @@ extern "C" int cstr_replay_sample_mt19937_f32(const cstr_ring_t *ring, const int
     if (ring->obs_dim == 4) replay_sample_kernel<4, 2><<<1, TPB, dyn, s>>>(SAMPLE_ARGS);
     else if (!a4) replay_sample_kernel<8, 2><<<1, TPB, dyn, s>>>(SAMPLE_ARGS);
     else replay_sample_kernel<8, 4><<<1, TPB, dyn, s>>>(SAMPLE_ARGS);
+#undef SAMPLE_ARGS
+    return (int)hipGetLastError();
+}
+
+extern "C" int cstr_replay_sample_packed_mt19937_f32(const cstr_ring_t *ring, const int64_t *ring_ctl, uint32_t *mt_state,
+                                                     int64_t batch, float *x_data, float *x_next, float *x_pi, float *out_done,
+                                                     float *out_rew, int64_t *out_row_idx, int64_t *out_env_idx, cstr_stream_t stream)
+{
+    if (!ring || !ring->obs || !ring->next_obs || !ring->act || !ring->rew || !ring->done || !ring->timeout) return CSTR_E_BADARG;
+    if (!ring_ctl || !mt_state || !x_data || !x_next || !out_done || !out_rew || batch <= 0) return CSTR_E_BADARG;
+    const bool lay_ok = (ring->obs_dim == 4 && ring->act_dim == 2) || (ring->obs_dim == 8 && (ring->act_dim == 2 || ring->act_dim == 4));
+    if (!lay_ok) return CSTR_E_UNSUPPORTED;
+    if (batch > CSTR_MAX_SAMPLE_BATCH || ring->rows >= 0xFFFFFFFFLL || ring->n_envs >= 0xFFFFFFFFLL) return CSTR_E_UNSUPPORTED;
+    if (!aligned16(ring->obs) || !aligned16(ring->next_obs) || !aligned8(ring->act) || !aligned8(x_data) || !aligned8(x_next) ||
+        (x_pi && !aligned8(x_pi)))
+        return CSTR_E_BADARG;
+    const size_t dyn = sizeof(int32_t) * 2 * (size_t)batch;
+    hipStream_t s = (hipStream_t)stream;
+#define SAMPLE_ARGS *ring, ring_ctl, mt_state, (int)batch, x_data, x_pi, x_next, out_done, out_rew, out_row_idx, out_env_idx
+    if (ring->obs_dim == 4) replay_sample_kernel<4, 2, true><<<1, TPB, dyn, s>>>(SAMPLE_ARGS);
+    else if (ring->act_dim == 2) replay_sample_kernel<8, 2, true><<<1, TPB, dyn, s>>>(SAMPLE_ARGS);
+    else replay_sample_kernel<8, 4, true><<<1, TPB, dyn, s>>>(SAMPLE_ARGS);
 #undef SAMPLE_ARGS
     return (int)hipGetLastError();
 }

@@ -566,6 +566,37 @@ def test_mt19937_normal_rejects_bad_arguments(ops):
         ops.mt19937_normal(th.zeros(625, dtype=th.int32, device="cuda"), [0.0], [1.0], th.empty(4, 1, device="cuda"))
 
 
+@pytest.mark.parametrize("D,A", [(4, 2), (8, 2), (8, 4)])
+def test_packed_sampler_equals_plain_sampler(ops, D, A):
+    """cstr_replay_sample_packed_mt19937_f32 draws the same indices and lays the same values out as (obs | act),
+    (next_obs | .), (obs | .) rows -- ReplayBuffer.sample + the critics' cat([obs, actions], 1) (policies.py:975-981)."""
+    R, N, B = 7, 50, 96
+    ring = _mk_ring(ops, R, N, D, A)
+    g = th.Generator(device="cuda").manual_seed(D * 10 + A)
+    for t in (ring.observations, ring.next_observations, ring.actions, ring.rewards):
+        t.copy_(th.randn(t.shape, device="cuda", generator=g))
+    ring.dones.copy_((th.rand(R, N, device="cuda", generator=g) < 0.3).float())
+    ring.timeouts.copy_((th.rand(R, N, device="cuda", generator=g) < 0.5).float() * ring.dones)
+    ring.ctl[0], ring.ctl[1] = 3, 1
+    mt1, mt2 = th.zeros(628, dtype=th.int32, device="cuda"), th.zeros(628, dtype=th.int32, device="cuda")
+    ops.mt19937_seed(mt1, 5), ops.mt19937_seed(mt2, 5)
+    plain = [th.empty(B, D, device="cuda"), th.empty(B, A, device="cuda"), th.empty(B, D, device="cuda"), th.empty(B, 1, device="cuda"),
+             th.empty(B, 1, device="cuda")]
+    W = D + A
+    xd, xn, xp = (th.full((B, W), 9.0, device="cuda") for _ in range(3))
+    dn, rw = th.empty(B, 1, device="cuda"), th.empty(B, 1, device="cuda")
+    ri, ei = th.empty(B, dtype=th.int64, device="cuda"), th.empty(B, dtype=th.int64, device="cuda")
+    for rnd in range(3):
+        ops.replay_sample(ring, mt1, B, *plain)
+        ops.replay_sample_packed(ring, mt2, B, xd, xn, xp if rnd != 1 else None, dn, rw, ri, ei)
+        assert th.equal(xd[:, :D], plain[0]) and th.equal(xd[:, D:], plain[1]) and th.equal(xn[:, :D], plain[2])
+        assert th.equal(dn, plain[3]) and th.equal(rw, plain[4]) and th.equal(mt1, mt2)
+        assert th.equal(ring.observations[ri, ei], plain[0])
+        assert float(xn[:, D:].min()) == 9.0 and float(xp[:, D:].min()) == 9.0  # the action columns are not the sampler's
+        if rnd != 1:
+            assert th.equal(xp[:, :D], plain[0])
+
+
 def test_twin_layout_reset_draw(ops):
     """Train B continues the env's PCG64 stream after train A: two consecutive generate_initial_state draws."""
     n = 64

@@ -248,3 +248,54 @@ def test_hidden_layer_plus_scalar_head_kernels(ops, G, M, K, act):
         y2 = z[0].clone()
         ops.hidden_head_fwd_(y2, b1[0], act, w2[0], b2, q2)
         assert th.equal(q2, q[0]) and th.equal(y2, y[0])
+
+
+def test_gaussian_head_kernels_match_unfused_path_and_rng_statistics(ops):
+    """cstr_gaussian_head_{fwd,bwd}_f32 = head bias + squashed-Gaussian sampling in one launch. With eps GIVEN it must equal
+    bias_act_fwd + squashed_gaussian_fwd/bwd (+ the bias gradient's column sum); with the in-kernel Philox stream the noise
+    must be standard normal, reproducible from (seed, offset) and advance across launches."""
+    from core.common import hip_ops
+
+    B, A = 256, 2
+    g = th.Generator(device="cuda").manual_seed(3)
+    z, bias = th.randn(B, 2 * A, device="cuda", generator=g), th.randn(2 * A, device="cuda", generator=g) * 0.2
+    z[:, A:] = z[:, A:] * 8  # exercise the log-std clamp
+    eps = th.randn(B, A, device="cuda", generator=g)
+    ref_p = ops.bias_act_fwd_(z.clone(), bias, 0)
+    ref_a, ref_lp = th.empty(B, A, device="cuda"), th.empty(B, device="cuda")
+    ops.squashed_gaussian_fwd(ref_p[:, :A], ref_p[:, A:], eps, ref_a, ref_lp)
+    p = z.clone()
+    xbuf = th.full((B, 4 + A), 7.0, device="cuda")
+    lp = th.empty(B, device="cuda")
+    hip_ops.gaussian_head_fwd_(p, bias, eps, None, xbuf[:, 4:], lp)
+    assert th.equal(p, ref_p) and th.equal(xbuf[:, 4:], ref_a) and th.equal(lp, ref_lp) and float(xbuf[:, :4].min()) == 7.0
+    ga_full, glp = th.randn(B, 4 + A, device="cuda", generator=g), th.randn(B, device="cuda", generator=g)
+    ref_gp = th.empty(B, 2 * A, device="cuda")
+    ops.squashed_gaussian_bwd(ga_full[:, 4:].contiguous(), glp, ref_a, ref_p[:, A:], eps, ref_gp[:, :A], ref_gp[:, A:])
+    gp, gb = th.empty(B, 2 * A, device="cuda"), th.empty(2 * A, device="cuda")
+    hip_ops.gaussian_head_bwd(ga_full[:, 4:], glp, xbuf[:, 4:], p, eps, gp, gb)
+    assert th.equal(gp, ref_gp)
+    assert rel_err(gb.cpu().numpy(), ref_gp.double().sum(0).cpu().numpy(), float(B) ** 0.5) < 2e-6
+    # in-kernel RNG
+    n = 1 << 19
+    ctl = hip_ops.new_rng_ctl(1234, "cuda")
+    pz = th.zeros(n, 2 * A, device="cuda")
+    e1, e2, act = th.empty(n, A, device="cuda"), th.empty(n, A, device="cuda"), th.empty(n, A, device="cuda")
+    hip_ops.gaussian_head_fwd_(pz, None, e1, ctl, act, None)
+    assert ctl.cpu().tolist() == [1234, n, 0, 0]
+    hip_ops.gaussian_head_fwd_(pz, None, e2, ctl, act, None)
+    assert ctl.cpu().tolist() == [1234, 2 * n, 0, 0]
+    assert th.equal(act, th.tanh(e2))  # mean 0, log_std 0: action = tanh(eps)
+    x = th.cat([e1, e2]).double().flatten()
+    assert abs(float(x.mean())) < 4e-3 and abs(float(x.var()) - 1.0) < 6e-3
+    assert abs(float((x ** 4).mean()) - 3.0) < 0.05 and abs(float((x ** 3).mean())) < 0.02
+    assert abs(float((e1[:, 0] * e1[:, 1]).mean())) < 5e-3 and abs(float((e1 * e2).mean())) < 5e-3  # pairs / launches independent
+    assert float(x.abs().max()) > 4.0
+    ctl2 = hip_ops.new_rng_ctl(1234, "cuda")
+    ctl2[1] = n
+    e3 = th.empty(n, A, device="cuda")
+    hip_ops.gaussian_head_fwd_(pz, None, e3, ctl2, act, None)
+    assert th.equal(e3, e2)  # a pure function of (seed, offset)
+    e4 = th.empty(n, A, device="cuda")
+    hip_ops.gaussian_head_fwd_(pz, None, e4, hip_ops.new_rng_ctl(1235, "cuda"), act, None)
+    assert abs(float((e4 * e1).mean())) < 5e-3 and not th.equal(e4, e1)
