@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--obs-dim", type=int, default=4, choices=[4, 8])
     ap.add_argument("--integrator", default="euler", choices=["euler", "rk4"])
     ap.add_argument("--graph", type=int, default=int(os.environ.get("CSTR_BENCH_GRAPH", "1")))
+    ap.add_argument("--graph-unroll", type=int, default=int(os.environ.get("CSTR_GRAPH_UNROLL", "1")),
+                    help="iterations recorded per hipGraph (the inter-graph launch gap is paid once per replay)")
     ap.add_argument("--blas", default=os.environ.get("CSTR_BLAS", "rocblas"), choices=["rocblas", "hipblaslt", "default"])
     ap.add_argument("--tunable", type=int, default=int(os.environ.get("CSTR_BENCH_TUNABLE", "0")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -272,14 +274,18 @@ def main():
     total = (args.warmup + args.steps) * N
     _, callback = model._setup_learn(total, NoopCallback(), True, "bench", False)
     use_graph = bool(args.graph)  # world > 1: graph segments with the RCCL all-reduces between them
-    model.enable_graph_capture(use_graph)
+    model.enable_graph_capture(use_graph, unroll=args.graph_unroll if world == 1 else 1)
     if args.tunable:  # development: record / eager-tune every GEMM shape (input of tools/tune_gemms.py)
         th.cuda.tunable.enable(True)
         th.cuda.tunable.tuning_enable(True)
         th.cuda.tunable.set_filename(os.path.join(ROOT, "gpurun_out", "tunableop_results.csv"))
 
-    def iteration():  # exactly the body of OffPolicyAlgorithm.learn()'s while loop
-        model._learn_iteration(callback, None)
+    def run_steps(k):  # exactly OffPolicyAlgorithm.learn()'s while loop, for k vec-steps (one call may replay several)
+        target = model.num_timesteps + k * N
+        model._total_timesteps = target  # learn(total_timesteps): unrolled graphs never run past it
+        while model.num_timesteps < target:
+            model._learn_iteration(callback, None)
+        assert model.num_timesteps == target
 
     def barrier():
         th.cuda.synchronize()
@@ -287,12 +293,10 @@ def main():
             th.distributed.barrier()
         th.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        iteration()
+    run_steps(args.warmup)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        iteration()
+    run_steps(args.steps)
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -308,7 +312,7 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.algo.upper()} MlpPolicy class defaults on {N} vectorised two-series CSTR envs per GPU "
                                f"(obs {args.obs_dim}/act 2, {args.integrator}, batch 256, ring 244x{N}, 1 gradient step per vec-step)",
-                   "n_envs_per_gpu": N, "global_batch": B * world, "parallelism": f"dp{world}", "hip_graph": use_graph, "blas": args.blas,
+                   "n_envs_per_gpu": N, "global_batch": B * world, "parallelism": f"dp{world}", "hip_graph": use_graph, "graph_unroll": model.graph_unroll if use_graph else 0, "blas": args.blas,
                    "n_updates": model._n_updates},
     }
     if rank == 0:

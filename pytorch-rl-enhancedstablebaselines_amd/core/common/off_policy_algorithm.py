@@ -8,6 +8,7 @@ sample, 4 `.item()` syncs per gradient step. Here, when the env is a `CSTRVecEnv
 returns to the host except, every `stats_sync_interval` vec-steps, four doubles of episode statistics.
 Any other VecEnv goes through the NumPy compatibility path with the reference's exact semantics.
 """
+import os
 import sys
 import time
 from typing import Any, Optional, Union
@@ -177,14 +178,19 @@ class OffPolicyAlgorithm(BaseAlgorithm):
         return True
 
     # ---- hipGraph capture of the steady-state iteration ------------------------------------------------------------
-    def enable_graph_capture(self, enabled: bool = True) -> None:
+    def enable_graph_capture(self, enabled: bool = True, unroll: Optional[int] = None) -> None:
         """Replay the steady-state iteration (actor forward, fused collect, `gradient_steps` gradient steps) from a
         captured hipGraph: ~250 launches become one host call. Every per-call control word the kernels need (ring
         position, Adam step, MT19937 stream, learning rate, env / RNG state) lives in HBM, so a replay is exact.
-        Falls back to the eager path whenever the iteration is not capturable (warm-up, callbacks, action noise,
-        data-parallel all-reduce, episodic train_freq)."""
+        Falls back to the eager path whenever the iteration is not capturable (warm-up, callbacks, host-side action noise,
+        episodic train_freq).
+
+        `unroll` (default 1, env CSTR_GRAPH_UNROLL): consecutive iterations recorded into ONE graph -- the ~10 us the GPU
+        idles between two graph launches is paid once per `unroll` iterations. Used on one GPU with a constant learning
+        rate while at least `unroll` iterations remain; otherwise single-iteration graphs are replayed."""
         self._graph_enabled = enabled
         self._graph = None
+        self.graph_unroll = max(1, int(unroll if unroll is not None else os.environ.get("CSTR_GRAPH_UNROLL", "1")))
 
     def _graph_eligible(self, callback: BaseCallback) -> bool:
         from core.common.noise import DeviceNormalActionNoise, LegacyStreamNormalActionNoise
@@ -221,9 +227,18 @@ class OffPolicyAlgorithm(BaseAlgorithm):
         update happens every `policy_delay`-th gradient step)."""
         return 0
 
+    def _graph_unroll_now(self) -> int:
+        u = getattr(self, "graph_unroll", 1)
+        if u <= 1 or self.world_size > 1 or getattr(self, "_force_segment_boundaries", False) or not isinstance(self.learning_rate, float):
+            return 1
+        remaining = (self._total_timesteps - self.num_timesteps) // self.n_envs
+        return u if remaining >= u else 1
+
     def _graph_iteration(self, log_interval: Optional[int]) -> None:
         vn = self._vec_normalize_env
-        key = (id(self._denv.coef), self.batch_size, self.gradient_steps, self._graph_phase(), None if vn is None else (id(vn), vn.cfg_key))
+        unroll = self._graph_unroll_now()
+        key = (id(self._denv.coef), self.batch_size, self.gradient_steps, self._graph_phase(), None if vn is None else (id(vn), vn.cfg_key),
+               unroll)
         if not isinstance(self._graph, dict):
             self._graph, self._graph_warm = {}, {}
         if key not in self._graph:
@@ -241,7 +256,7 @@ class OffPolicyAlgorithm(BaseAlgorithm):
                 return
             self._train_host_pre()
             try:
-                self._graph[key] = self._capture_segments()
+                self._graph[key] = self._capture_segments(unroll)
             except Exception as exc:  # something in the iteration is not capturable: run eagerly from now on
                 import warnings
 
@@ -252,9 +267,10 @@ class OffPolicyAlgorithm(BaseAlgorithm):
         self._train_host_pre()
         for item in self._graph[key]:  # hipGraph segments interleaved with the eager collectives that separate them
             item.replay() if isinstance(item, th.cuda.CUDAGraph) else item()
-        self._graph_host_bookkeeping(log_interval)
+        for _ in range(unroll):
+            self._graph_host_bookkeeping(log_interval)
 
-    def _capture_segments(self) -> list:
+    def _capture_segments(self, unroll: int = 1) -> list:
         """Record the iteration as hipGraph segments. A data-parallel run has an RCCL all-reduce between backward and
         the optimiser step (three per SAC gradient step); collectives stay OUTSIDE the captured graphs -- every
         `_eager_boundary` closes the current segment, runs the collective eagerly and opens the next segment in the same
@@ -267,8 +283,11 @@ class OffPolicyAlgorithm(BaseAlgorithm):
         with th.cuda.stream(side):
             self._cap = dict(pool=th.cuda.graph_pool_handle(), graph=th.cuda.CUDAGraph(), items=items)
             self._cap["graph"].capture_begin(pool=self._cap["pool"], capture_error_mode="thread_local")
+            n_updates = self._n_updates
             try:
-                self._graph_body()
+                for _ in range(unroll):
+                    self._graph_body()
+                    self._n_updates += self.gradient_steps  # the next body sees its own policy-delay phase
                 self._cap["graph"].capture_end()
                 items.append(self._cap["graph"])
             except Exception:
@@ -279,6 +298,7 @@ class OffPolicyAlgorithm(BaseAlgorithm):
                 raise
             finally:
                 self._cap = None
+                self._n_updates = n_updates  # nothing ran while recording
         th.cuda.current_stream(self.device).wait_stream(side)
         th.cuda.synchronize(self.device)
         return items

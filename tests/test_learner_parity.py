@@ -551,3 +551,34 @@ def test_learning_improves_episode_return(algo):
     eval_env.seed(1234)
     after, _ = evaluate_policy(model, eval_env, n_eval_episodes=64)
     assert before < -200 and after > before + 150, (before, after)
+
+
+@pytest.mark.parametrize("algo", ["sac", "td3"])
+def test_unrolled_hipgraph_equals_single_iteration_graphs(algo):
+    """enable_graph_capture(unroll=U) records U consecutive iterations (TD3: both policy-delay phases) into one graph; the
+    run must end exactly at total_timesteps with the same sampler stream, ring and counters as single-iteration graphs."""
+    from core.common import legacy_rng
+    from core.common.vec_env import CSTRVecEnv
+    from core.sac import SAC
+    from core.td3 import TD3
+
+    N, B, iters = 64, 32, 23
+    res = []
+    for unroll in (1, 4):
+        env = CSTRVecEnv(N)
+        cls = SAC if algo == "sac" else TD3
+        model = cls("MlpPolicy", env, seed=2, batch_size=B, buffer_size=N * 16, learning_starts=N, policy_kwargs=dict(net_arch=[32, 32]))
+        model.enable_graph_capture(True, unroll=unroll)
+        model.learn(N * iters)
+        assert model.num_timesteps == N * iters and model._n_updates == iters - 1
+        if unroll > 1:
+            assert any(k[-1] == unroll for k in model._graph) and model.critic.optimizer.step_count == iters - 1
+        th.cuda.synchronize()
+        res.append(dict(mt=legacy_rng.global_stream(model.device).cpu().numpy().copy(), ctl=model.replay_buffer.ring.ctl.cpu().numpy(),
+                        steps=env.step_count.cpu().numpy(), actor=model.policy.actor_arena.flat.cpu().numpy(),
+                        critic=model.policy.critic_arena.flat.cpu().numpy(), ring=model.replay_buffer.actions.cpu().numpy()))
+    a, b = res
+    for k in ("mt", "ctl", "steps"):
+        np.testing.assert_array_equal(a[k], b[k])
+    for k in ("actor", "critic", "ring"):
+        np.testing.assert_allclose(a[k], b[k], rtol=2e-3, atol=2e-4, err_msg=k)
