@@ -52,6 +52,7 @@ def parse():
     ap.add_argument("--tunable", type=int, default=int(os.environ.get("CSTR_BENCH_TUNABLE", "0")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-variant", action="store_true", help="skip the secondary north_star-shaped run (obs 8, RK4)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
 
@@ -241,6 +242,31 @@ def cpu_baseline(n_envs, batch, seconds):
                 env_only_value=round(env_only, 1), ms_per_iteration=round(1e3 * dt / n, 3))
 
 
+def north_star_variant(n_envs: int, device: str, graph: bool) -> dict:
+    """BASELINE.json's north_star wording (8-dim state, batched RK4) differs from the reference (4-dim obs, forward Euler;
+    SURVEY D1/D2). The headline value is measured on the reference-true shape; this is the same loop on the north_star shape:
+    obs = [normalised | raw] (8 columns), RK4 integrator. Rank 0, one GPU, short run."""
+    from core.common.callbacks import NoopCallback
+    from core.common.vec_env import CSTRVecEnv
+    from core.sac import SAC
+
+    warm, steps = 30, 150
+    env = CSTRVecEnv(n_envs, obs_dim=8, integrator="rk4", device=device)
+    model = SAC("MlpPolicy", env, seed=0, device=device)
+    _, cb = model._setup_learn((warm + steps) * n_envs, NoopCallback(), True, "bench", False)
+    model.enable_graph_capture(graph)
+    for _ in range(warm):
+        model._learn_iteration(cb, None)
+    th.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        model._learn_iteration(cb, None)
+    th.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return dict(workload=f"SAC class defaults, {n_envs} envs, obs 8 ([normalised | raw]) / act 2, rk4, batch 256", steps=steps,
+                value=round(steps * n_envs / dt, 1), unit="env-steps/s", ms_per_step=round(1e3 * dt / steps, 4))
+
+
 def main():
     args = parse()
     from core.common import distributed as dist_util
@@ -323,6 +349,9 @@ def main():
                                         "the bandwidth-bound regime of the same kernel")
             line["roofline_stream"] = roofline_collect(1 << 22, args.obs_dim, args.integrator, 30)
             line["kernels"] = other_kernels(model, B)
+        if world == 1 and not args.no_variant and args.algo == "sac" and (args.obs_dim, args.integrator) == (4, "euler"):
+            del model, env
+            line["north_star_variant"] = north_star_variant(N, f"cuda:{local_rank}", use_graph)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(N, B, args.cpu_seconds)
             line["speedup_vs_cpu_port"] = round(value / line["cpu_baseline"]["value"], 2)

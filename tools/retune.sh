@@ -5,7 +5,7 @@
 set -e
 mkdir -p gpurun_out
 rm -f gpurun_out/tunableop_results*.csv
-B="python bench.py --tunable 1 --no-cpu-baseline --no-roofline --steps 20 --warmup 10"
+B="python bench.py --tunable 1 --no-cpu-baseline --no-roofline --no-variant --steps 20 --warmup 10"
 export CSTR_TUNABLEOP_FILE=0
 $B > gpurun_out/k1.log 2>&1
 $B --algo td3 > gpurun_out/k2.log 2>&1
