@@ -259,6 +259,13 @@ int cstr_gaussian_head_bwd_f32(const float *g_action, int64_t ga_stride, const f
                                int64_t action_stride, const float *params, const float *eps, float *g_params, float *g_bias,
                                int64_t batch, int act_dim, cstr_stream_t stream);
 
+/* TD3 / MADDPG target policy smoothing (core/td3/td3.py:167-173; core/maddpg/maddpg.py:131-142) in one launch:
+ * noise = clamp(N(0, sigma), -clip, clip); out = clamp(action + noise, -1, 1). action [B][A] contiguous (the target
+ * actor's output); `noise` [B][A] (already scaled by sigma) is read when rng_ctl is NULL, otherwise sigma * N(0,1) is drawn
+ * from the Philox stream rng_ctl (see cstr_gaussian_head_fwd_f32). out rows are out_stride floats apart. */
+int cstr_target_smooth_f32(const float *action, const float *noise, uint64_t *rng_ctl, float sigma, float clip, float *out,
+                           int64_t out_stride, int64_t batch, int act_dim, cstr_stream_t stream);
+
 /* SAC entropy coefficient (core/sac/sac.py:230-243): ent_coef_out = exp(log_alpha); grad_out = d/dlog_alpha of
  * -mean(log_alpha * (logp + target_entropy)) = -mean(logp + target_entropy). loss_sum / ent_coef_sum (device scalars,
  * may be NULL) accumulate the values train() logs (:232, :236) without a host sync. */

@@ -124,6 +124,19 @@ class BaseAlgorithm:
         fa = getattr(self, "_fast_actor", None)
         if fa is not None and hasattr(fa, "seed_rng"):
             fa.seed_rng(seed + 1000003 * self.rank)
+        ctl = getattr(self, "_rng_ctl", None)  # target-smoothing noise stream (TD3 / MADDPG)
+        if ctl is not None:
+            from core.common import hip_ops
+
+            ctl.copy_(hip_ops.new_rng_ctl(seed + 1000003 * self.rank, ctl.device))
+
+    def _device_rng(self):
+        """In-kernel Philox stream for this algorithm's own noise kernels, seeded from torch's seed at first use."""
+        if getattr(self, "_rng_ctl", None) is None:
+            from core.common import hip_ops
+
+            self._rng_ctl = hip_ops.new_rng_ctl(th.initial_seed(), self.device)
+        return self._rng_ctl
 
     def get_env(self):
         return self.env

@@ -326,6 +326,19 @@ def gaussian_head_bwd(g_action, g_logp, action, params, eps, g_params, g_bias):
           "cstr_gaussian_head_bwd_f32")
 
 
+def target_smooth(action, noise, rng_ctl, sigma: float, clip: float, out):
+    """out = clamp(action + clamp(noise, -clip, clip), -1, 1); noise given ([B, A], already scaled) or drawn (rng_ctl)."""
+    b, a = action.shape
+    _chk(action, "action", (b, a), th.float32), _opt(noise, "noise", (b, a), th.float32)
+    _opt(rng_ctl, "rng_ctl", (nv.RNG_CTL_WORDS,), th.int64)
+    if (noise is None) == (rng_ctl is None):
+        raise ValueError("target_smooth needs exactly one noise source: a noise tensor or rng_ctl")
+    stride = _rows(out, "out", b, a)
+    check(nv.lib().cstr_target_smooth_f32(ptr(action), ptr(noise), ptr(rng_ctl), C.c_float(sigma), C.c_float(clip), ptr(out),
+                                          C.c_int64(stride), C.c_int64(b), C.c_int(a), stream_ptr()), "cstr_target_smooth_f32")
+    return out
+
+
 def hidden_head_fwd_(z, b1, act: int, w2, b2, q):
     """y = act(z + b1) in place on z [G, m, k] (or [m, k]); q [G, m, 1] = y . w2 + b2 (a Q network's scalar head)."""
     g, m, k = _gmn(z)

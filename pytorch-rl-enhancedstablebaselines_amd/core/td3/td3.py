@@ -41,9 +41,10 @@ class TD3(OffPolicyAlgorithm):
         self.actor, self.actor_target = self.policy.actor, self.policy.actor_target
         self.critic, self.critic_target = self.policy.critic, self.policy.critic_target
         z = lambda: th.zeros(1, dtype=th.float32, device=self.device)  # noqa: E731
-        self._loss_sums = dict(actor=z(), critic=z())
+        self._loss_sum_buf = th.zeros(2, dtype=th.float32, device=self.device)  # one fill per train() instead of two
+        self._loss_sums = dict(actor=self._loss_sum_buf[0:1], critic=self._loss_sum_buf[1:2])
         self._loss_now = dict(actor=z(), critic=z())
-        self._static_batch = None
+        self._static_batch, self._packed = None, None
         from core.common.arena import FlatAdam
 
         self.fused_learner = (isinstance(self.actor.optimizer, FlatAdam) and isinstance(self.critic.optimizer, FlatAdam)
@@ -59,10 +60,25 @@ class TD3(OffPolicyAlgorithm):
             return self._fast_actor(obs, train_params=False)
 
     def _batch(self, batch_size: int):
-        if self._static_batch is None or self._static_batch.observations.shape[0] != batch_size:
-            self._static_batch = self.replay_buffer.alloc_batch(batch_size)
+        if self._static_batch is None or self._static_batch.observations.shape[0] != batch_size or self._packed is not None:
+            self._static_batch, self._packed = self.replay_buffer.alloc_batch(batch_size), None
             self._target_q = th.empty(batch_size, 1, dtype=th.float32, device=self.device)
         return self._static_batch
+
+    def _use_packed_batch(self) -> bool:
+        """Sample straight into the critics' input rows (no torch.cat launches) on the fused path with the stock buffer."""
+        from core.common.buffers import ReplayBuffer
+
+        rb = self.replay_buffer
+        return self.fused_learner and type(rb) is ReplayBuffer and rb.normalizer is None
+
+    def _packed_batch(self, batch_size: int):
+        if self._packed is None or self._packed.x_data.shape[0] != batch_size:
+            self._packed = self.replay_buffer.alloc_packed_batch(batch_size, with_pi=False)
+            self._static_batch = self._packed.samples
+            self._target_q = th.empty(batch_size, 1, dtype=th.float32, device=self.device)
+            self._act_t = th.empty(batch_size, self._packed.act_dim, dtype=th.float32, device=self.device)
+        return self._packed
 
     def train(self, gradient_steps: int, batch_size: int = 100) -> None:
         """reference: td3.py:154-211"""
@@ -90,8 +106,7 @@ class TD3(OffPolicyAlgorithm):
         self.logger.record("train/critic_loss", DeviceMean(self._loss_sums["critic"], gradient_steps))
 
     def _train_device_only(self, gradient_steps: int, batch_size: int) -> None:
-        for v in self._loss_sums.values():
-            v.zero_()
+        self._loss_sum_buf.zero_()
         n_updates = self._n_updates  # host counter advances in _train_host_only
         for _ in range(gradient_steps):
             n_updates += 1
@@ -136,19 +151,32 @@ class TD3(OffPolicyAlgorithm):
     def _gradient_step_fused(self, batch_size: int, n_updates: int) -> None:
         """td3.py:161-206 on the fused path (core/common/fused.py)."""
         s, pol = self._loss_sums, self.policy
-        rd = self.replay_buffer.sample_into(self._batch(batch_size))
+        pb = None
+        if self._use_packed_batch():
+            pb = self.replay_buffer.sample_packed_into(self._packed_batch(batch_size))  # :161 + the critics' cat([obs, act])
+            rd = pb.samples
+        else:
+            rd = self.replay_buffer.sample_into(self._batch(batch_size))
         B = rd.observations.shape[0]
         if not hasattr(self, "_g_bufs") or self._g_bufs[0].shape[0] != B:
             self._g_bufs = th.empty(2, B, 1, device=self.device)
         gq = self._g_bufs
         gq1, gq2 = gq[0], gq[1]
         with th.no_grad():  # :167-176
-            noise = self.noise_queue.pop(0).to(self.device) if self.noise_queue else rd.actions.clone().normal_(0, self.target_policy_noise)
-            noise = noise.clamp(-self.target_noise_clip, self.target_noise_clip)
-            next_actions = (self._fast_actor_target(rd.next_observations, train_params=False) + noise).clamp(-1, 1)
-            qs = self._fast_critic_target(rd.next_observations, next_actions, train_params=False)
+            if pb is not None:
+                # target smoothing in ONE launch (clone + normal_ + clamp + add + clamp), written into x_next's action columns
+                a_t = self._fast_actor_target(rd.next_observations, train_params=False)
+                queued = self.noise_queue.pop(0).to(self.device, th.float32).contiguous() if self.noise_queue else None
+                hip_ops.target_smooth(a_t, queued, None if queued is not None else self._device_rng(), self.target_policy_noise,
+                                      self.target_noise_clip, pb.x_next[:, pb.obs_dim:])
+                qs = self._fast_critic_target.forward_input(pb.x_next, train_params=False)
+            else:
+                noise = self.noise_queue.pop(0).to(self.device) if self.noise_queue else rd.actions.clone().normal_(0, self.target_policy_noise)
+                noise = noise.clamp(-self.target_noise_clip, self.target_noise_clip)
+                next_actions = (self._fast_actor_target(rd.next_observations, train_params=False) + noise).clamp(-1, 1)
+                qs = self._fast_critic_target(rd.next_observations, next_actions, train_params=False)
             hip_ops.td_target_min(qs[0], qs[-1], None, rd.rewards, rd.dones, None, self.gamma, self._target_q)
-        qs = self._fast_critic(rd.observations, rd.actions)  # :179
+        qs = self._fast_critic.forward_input(pb.x_data) if pb is not None else self._fast_critic(rd.observations, rd.actions)  # :179
         q1, q2 = qs[0], qs[-1]
         # n_critics == 1 (DDPG): loss = mse(q1, t) -> scale 0.5 of the doubled term
         hip_ops.twin_q_loss(q1, q2, self._target_q, 1.0 if len(qs) == 2 else 0.5, gq1, gq2, self._loss_now["critic"], s["critic"])

@@ -335,6 +335,39 @@ __global__ __launch_bounds__(64) void gaussian_head_fwd_kernel(float *__restrict
         rng_ctl[1] = base + (uint64_t)batch;
 }
 
+// TD3 / MADDPG target policy smoothing (core/td3/td3.py:167-173; core/maddpg/maddpg.py:131-142):
+//   noise = clamp(N(0, sigma), -clip, clip);  out = clamp(action + noise, -1, 1)
+// in one launch (the reference's clone + normal_ + clamp + add + clamp). The noise is read when given (teacher-forced tests)
+// and drawn from the same in-kernel Philox stream as the SAC head otherwise. `out` may be a column block of a wider row.
+__global__ __launch_bounds__(64) void target_smooth_kernel(const float *__restrict__ action, const float *__restrict__ noise,
+                                                           uint64_t *__restrict__ rng_ctl, const float sigma, const float clip,
+                                                           float *__restrict__ out, const int64_t out_stride, const int64_t batch,
+                                                           const int act_dim)
+{
+    const uint64_t seed = rng_ctl ? rng_ctl[0] : 0ull, base = rng_ctl ? rng_ctl[1] : 0ull;
+    for (int64_t b = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; b < batch; b += (int64_t)gridDim.x * blockDim.x) {
+        for (int j0 = 0; j0 < act_dim; j0 += 2) {
+            float e[2] = {0.0f, 0.0f};
+            if (rng_ctl) {
+                const uint64_t ctr = base + (uint64_t)b;
+                uint32_t r[4];
+                philox4x32_10((uint32_t)ctr, (uint32_t)(ctr >> 32), (uint32_t)(j0 >> 1), 0u, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+                box_muller(r[0], r[1], e[0], e[1]);
+                e[0] *= sigma;
+                e[1] *= sigma;
+            }
+            for (int jj = 0; jj < 2 && j0 + jj < act_dim; ++jj) {
+                const int j = j0 + jj;
+                const float z = rng_ctl ? e[jj] : noise[b * act_dim + j];
+                const float nz = fminf(fmaxf(z, -clip), clip);
+                out[b * out_stride + j] = fminf(fmaxf(action[b * act_dim + j] + nz, -1.0f), 1.0f);
+            }
+        }
+    }
+    if (rng_ctl && last_block_ticket(reinterpret_cast<unsigned long long *>(rng_ctl + 2)) && threadIdx.x == 0)
+        rng_ctl[1] = base + (uint64_t)batch;
+}
+
 // Backward (same algebra as squashed_gaussian_bwd_kernel) + the merged head's bias gradient (column sums over the batch).
 // One workgroup: the batch is a few hundred rows.
 __global__ __launch_bounds__(256) void gaussian_head_bwd_kernel(const float *__restrict__ g_action, const int64_t ga_stride,
@@ -624,5 +657,17 @@ extern "C" int cstr_gaussian_head_bwd_f32(const float *g_action, int64_t ga_stri
     if (act_dim > CSTR_MAX_HEAD_ACT || batch > 65536) return CSTR_E_UNSUPPORTED;
     gaussian_head_bwd_kernel<<<1, 256, 0, (hipStream_t)stream>>>(g_action, ga_stride, g_logp, action, action_stride, params, eps,
                                                                  g_params, g_bias, batch, act_dim);
+    return (int)hipGetLastError();
+}
+
+extern "C" int cstr_target_smooth_f32(const float *action, const float *noise, uint64_t *rng_ctl, float sigma, float clip, float *out,
+                                      int64_t out_stride, int64_t batch, int act_dim, cstr_stream_t stream)
+{
+    if (!action || !out || batch <= 0 || act_dim <= 0 || out_stride < act_dim) return CSTR_E_BADARG;
+    if ((noise == nullptr) == (rng_ctl == nullptr)) return CSTR_E_BADARG;  // exactly one noise source
+    if (!(sigma >= 0.0f) || !(clip >= 0.0f)) return CSTR_E_BADARG;
+    const int64_t g = (batch + 63) / 64;
+    target_smooth_kernel<<<(unsigned)(g < 4096 ? g : 4096), 64, 0, (hipStream_t)stream>>>(action, noise, rng_ctl, sigma, clip, out,
+                                                                                         out_stride, batch, act_dim);
     return (int)hipGetLastError();
 }

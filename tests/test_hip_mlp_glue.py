@@ -299,3 +299,29 @@ def test_gaussian_head_kernels_match_unfused_path_and_rng_statistics(ops):
     e4 = th.empty(n, A, device="cuda")
     hip_ops.gaussian_head_fwd_(pz, None, e4, hip_ops.new_rng_ctl(1235, "cuda"), act, None)
     assert abs(float((e4 * e1).mean())) < 5e-3 and not th.equal(e4, e1)
+
+
+def test_target_smoothing_kernel(ops):
+    """cstr_target_smooth_f32 = td3.py:167-173 (noise.clamp(-c, c); (a + noise).clamp(-1, 1)) with the noise given, and the
+    same with sigma * N(0, 1) drawn in the kernel."""
+    from core.common import hip_ops
+
+    B, A, D = 300, 2, 4
+    g = th.Generator(device="cuda").manual_seed(0)
+    a = th.tanh(th.randn(B, A, device="cuda", generator=g) * 2)
+    noise = th.randn(B, A, device="cuda", generator=g) * 0.4
+    x = th.full((B, D + A), 5.0, device="cuda")
+    hip_ops.target_smooth(a, noise, None, 0.2, 0.5, x[:, D:])
+    assert th.equal(x[:, D:], (a + noise.clamp(-0.5, 0.5)).clamp(-1, 1)) and float(x[:, :D].min()) == 5.0
+    ctl = hip_ops.new_rng_ctl(9, "cuda")
+    n = 1 << 18
+    big, out = th.zeros(n, A, device="cuda"), th.empty(n, A, device="cuda")
+    hip_ops.target_smooth(big, None, ctl, 0.2, 0.5, out)
+    assert ctl.cpu().tolist() == [9, n, 0, 0]
+    z = out.double().flatten()
+    assert abs(float(z.mean())) < 2e-3 and abs(float(z.std()) - 0.2 * 0.98872) < 1e-3  # N(0, 0.2) clamped at 2.5 sigma
+    assert float(z.abs().max()) == 0.5
+    hip_ops.target_smooth(big, None, ctl, 0.0, 0.5, out)  # DDPG: no smoothing
+    assert float(out.abs().max()) == 0.0
+    with pytest.raises(ValueError):
+        hip_ops.target_smooth(a, noise, ctl, 0.2, 0.5, x[:, D:])
