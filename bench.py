@@ -88,11 +88,18 @@ def event_time_us(fn, n_launch, stream, in_graph=False):
         side = th.cuda.Stream()
         side.wait_stream(th.cuda.current_stream())
         g = th.cuda.CUDAGraph()
-        with th.cuda.stream(side):
-            g.capture_begin(capture_error_mode="thread_local")
-            for _ in range(n_launch):
-                fn()
-            g.capture_end()
+        import gc
+
+        gc.collect()  # a collection that frees device memory in the middle of a capture aborts the process
+        gc.disable()
+        try:
+            with th.cuda.stream(side):
+                g.capture_begin(capture_error_mode="thread_local")
+                for _ in range(n_launch):
+                    fn()
+                g.capture_end()
+        finally:
+            gc.enable()
         th.cuda.current_stream().wait_stream(side)
         g.replay()
         stream.synchronize()

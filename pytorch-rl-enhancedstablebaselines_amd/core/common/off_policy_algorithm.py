@@ -276,6 +276,13 @@ class OffPolicyAlgorithm(BaseAlgorithm):
         `_eager_boundary` closes the current segment, runs the collective eagerly and opens the next segment in the same
         memory pool (activations saved for a later segment's backward stay alive). Single-GPU runs have no boundary and
         get one graph. Nothing executes while recording."""
+        import gc
+
+        # like torch.cuda.graph(): collect garbage BEFORE recording and keep the collector off while recording -- a cycle
+        # collection that destroys another model's CUDAGraph (or frees device memory) in the middle of a capture aborts
+        gc.collect()
+        gc_was_enabled = gc.isenabled()
+        gc.disable()
         th.cuda.synchronize(self.device)
         side = th.cuda.Stream(device=self.device)
         side.wait_stream(th.cuda.current_stream(self.device))
@@ -299,6 +306,8 @@ class OffPolicyAlgorithm(BaseAlgorithm):
             finally:
                 self._cap = None
                 self._n_updates = n_updates  # nothing ran while recording
+                if gc_was_enabled:
+                    gc.enable()
         th.cuda.current_stream(self.device).wait_stream(side)
         th.cuda.synchronize(self.device)
         return items

@@ -99,8 +99,10 @@ class MADDPG(OffPolicyAlgorithm):
         self.actor, self.actor_target = self.policy.actor, self.policy.actor_target
         self.critic, self.critic_target = self.policy.critic, self.policy.critic_target
         z = lambda: th.zeros(1, dtype=th.float32, device=self.device)  # noqa: E731
-        self._loss_sums = {f"{k}{i}": z() for k in ("actor", "critic") for i in range(self.n_agents)}
-        self._static_batch = None
+        names = [f"{k}{i}" for k in ("actor", "critic") for i in range(self.n_agents)]
+        self._loss_sum_buf = th.zeros(len(names), dtype=th.float32, device=self.device)  # one fill per train()
+        self._loss_sums = {nm: self._loss_sum_buf[j:j + 1] for j, nm in enumerate(names)}
+        self._static_batch, self._packed = None, None
         self._loss_now = z()
         pol = self.policy
         self.fused_learner = (all(fused.FastMLP.supported(m) for m in self.actor.mu_list)
@@ -154,8 +156,26 @@ class MADDPG(OffPolicyAlgorithm):
                 update_learning_rate(opt, lr)
                 opt.sync_lr()
 
+    def _use_packed_batch(self) -> bool:
+        """Joint critics whose input is exactly (obs | actions): sample straight into the critic-input rows and let the
+        target-smoothing kernel write every agent's next action into its columns (no gathers, no torch.cat)."""
+        from core.common.buffers import ReplayBuffer
+
+        rb, C = self.replay_buffer, self.critic
+        return (self.fused_learner and not C.local and type(rb) is ReplayBuffer and rb.normalizer is None
+                and C._tiles_in_order("obs") and C._tiles_in_order("act")
+                and all(C._range("act", i) is not None and C._range("obs", i) is not None for i in range(self.n_agents)))
+
+    def _packed_batch(self, batch_size: int):
+        if self._packed is None or self._packed.x_data.shape[0] != batch_size:
+            self._packed = self.replay_buffer.alloc_packed_batch(batch_size, with_pi=False)
+            self._static_batch = self._packed.samples
+            self._target_q = [th.empty(batch_size, 1, dtype=th.float32, device=self.device) for _ in range(self.n_agents)]
+        return self._packed
+
     def _batch(self, batch_size: int):
-        if self._static_batch is None or self._static_batch.observations.shape[0] != batch_size:
+        if self._static_batch is None or self._static_batch.observations.shape[0] != batch_size or self._packed is not None:
+            self._packed = None
             self._static_batch = self.replay_buffer.alloc_batch(batch_size)
             self._target_q = [th.empty(batch_size, 1, dtype=th.float32, device=self.device) for _ in range(self.n_agents)]
         return self._static_batch
@@ -187,8 +207,7 @@ class MADDPG(OffPolicyAlgorithm):
             self.logger.record(f"train/agent_{i}_critic_loss", DeviceMean(self._loss_sums[f"critic{i}"], gradient_steps))
 
     def _train_device_only(self, gradient_steps: int, batch_size: int) -> None:
-        for v in self._loss_sums.values():
-            v.zero_()
+        self._loss_sum_buf.zero_()
         n_updates = self._n_updates
         A, C = self.actor, self.critic
         for _ in range(gradient_steps):
@@ -253,14 +272,29 @@ class MADDPG(OffPolicyAlgorithm):
         """maddpg.py:127-185 on the fused path (core/common/fused.py): the same statements and quirks, GEMMs in rocBLAS,
         epilogues / loss roots in HIP, gradients written into the arenas, only the updating agent's networks evaluated."""
         pol, A, C = self.policy, self.actor, self.critic
-        rd = self.replay_buffer.sample_into(self._batch(batch_size))
+        pb = None
+        if self._use_packed_batch():
+            pb = self.replay_buffer.sample_packed_into(self._packed_batch(batch_size))
+            rd = pb.samples
+        else:
+            rd = self.replay_buffer.sample_into(self._batch(batch_size))
         B = rd.observations.shape[0]
         if not hasattr(self, "_g_bufs") or self._g_bufs.shape[1] != B:
             self._g_bufs = th.empty(2, B, 1, device=self.device)
         gq = self._g_bufs
+        shared_next = shared_cur = None
+        if pb is not None:
+            with th.no_grad():  # :131-144, one smoothing launch per agent, written into x_next's action columns
+                for i in range(self.n_agents):
+                    a_t = self._fast_actor_targets[i](A._agent_obs_tensor_extract(i, rd.next_observations), train_params=False)
+                    queued = self.noise_queue.pop(0).to(self.device, th.float32).contiguous() if self.noise_queue else None
+                    lo, hi = C._range("act", i)
+                    hip_ops.target_smooth(a_t, queued, None if queued is not None else self._device_rng(), self.target_policy_noise,
+                                          self.target_noise_clip, pb.x_next[:, pb.obs_dim + lo:pb.obs_dim + hi])
+            shared_next, shared_cur = pb.x_next, pb.x_data
         with th.no_grad():  # :131-144
             nxt = []
-            for i in range(self.n_agents):
+            for i in range(self.n_agents if pb is None else 0):
                 agent_next_obs = A._agent_obs_tensor_extract(i, rd.next_observations)
                 if self.noise_queue:
                     noise = self.noise_queue.pop(0).to(self.device)
@@ -268,9 +302,11 @@ class MADDPG(OffPolicyAlgorithm):
                     noise = th.empty(B, len(self.action_splits[i]), device=self.device).normal_(0, self.target_policy_noise)
                 noise = noise.clamp(-self.target_noise_clip, self.target_noise_clip)
                 nxt.append((self._fast_actor_targets[i](agent_next_obs, train_params=False) + noise).clamp(-1, 1))
-            next_actions = th.cat(nxt, dim=-1)
-            shared_next = None if C.local else self.critic_target._input(0, rd.next_observations, next_actions)
-        shared_cur = None if C.local else C._input(0, rd.observations, rd.actions)
+            if pb is None:
+                next_actions = th.cat(nxt, dim=-1)
+                shared_next = None if C.local else self.critic_target._input(0, rd.next_observations, next_actions)
+        if pb is None:
+            shared_cur = None if C.local else C._input(0, rd.observations, rd.actions)
         captured = []
         for i in range(self.n_agents):
             with th.no_grad():  # :148-151
@@ -296,8 +332,11 @@ class MADDPG(OffPolicyAlgorithm):
                 else:
                     acts = [self._fast_actors[j](A._agent_obs_tensor_extract(j, rd.observations), train_params=(j == i))
                             for j in range(self.n_agents)]
-                actions = th.cat(acts, dim=-1)
-                qs_pi = self._fast_critics[i].forward_input(C._input(i, rd.observations, actions), train_params=False, only_first=True)
+                if pb is not None:  # (obs | all agents' actions) in ONE cat
+                    x_pi = th.cat([rd.observations] + acts, dim=1)
+                else:
+                    x_pi = C._input(i, rd.observations, th.cat(acts, dim=-1))
+                qs_pi = self._fast_critics[i].forward_input(x_pi, train_params=False, only_first=True)
                 hip_ops.neg_mean_loss(qs_pi[0], gq[0], self._loss_now, self._loss_sums[f"actor{i}"])
                 fused.backward_q(qs_pi, gq)
                 self._allreduce_grads(pol.actor_slices[i])

@@ -54,10 +54,32 @@ class _MultiAgentModule(nn.Module):
             cache[key] = th.as_tensor([int(i) for i in sp.indices], dtype=th.long, device=device)
         return cache[key]
 
+    def _range(self, kind: str, agent_id: int):
+        """(start, stop) when the agent's indices are one ascending run -- the slice is then a VIEW (no gather launch)"""
+        cache = self.__dict__.setdefault("_range_cache", {})
+        key = (kind, agent_id)
+        if key not in cache:
+            idx = [int(i) for i in (self.observation_space_list if kind == "obs" else self.action_space_list)[agent_id].indices]
+            cache[key] = (idx[0], idx[-1] + 1) if idx and idx == list(range(idx[0], idx[0] + len(idx))) else None
+        return cache[key]
+
+    def _tiles_in_order(self, kind: str) -> bool:
+        """the agents' slices, in agent order, are exactly columns 0..width-1 (so cat(slices) IS the global tensor)"""
+        spaces, width = ((self.observation_space_list, self.observation_space.shape[0]) if kind == "obs"
+                         else (self.action_space_list, self.action_space.shape[0]))
+        flat = [int(i) for sp in spaces for i in sp.indices]
+        return flat == list(range(width))
+
     def _agent_obs_tensor_extract(self, agent_id: int, global_observation: th.Tensor) -> th.Tensor:
+        r = self._range("obs", agent_id)
+        if r is not None:
+            return global_observation[..., r[0]:r[1]]
         return global_observation.index_select(-1, self._index("obs", agent_id, global_observation.device))
 
     def _agent_action_tensor_extract(self, agent_id: int, global_action: th.Tensor) -> th.Tensor:
+        r = self._range("act", agent_id)
+        if r is not None:
+            return global_action[..., r[0]:r[1]]
         return global_action.index_select(-1, self._index("act", agent_id, global_action.device))
 
     def set_training_mode(self, mode: bool) -> None:
@@ -114,6 +136,8 @@ class ContinuousCritic(_MultiAgentModule):
     def _input(self, agent_id: int, obs: th.Tensor, actions: th.Tensor) -> th.Tensor:
         if self.local:
             return th.cat((self._agent_obs_tensor_extract(agent_id, obs).float(), self._agent_action_tensor_extract(agent_id, actions)), dim=-1)
+        if self._tiles_in_order("obs"):  # cat(all agents' features) is the observation itself
+            return th.cat([obs.float(), actions], dim=1)
         feats = [self._agent_obs_tensor_extract(i, obs).float() for i in range(self.n_agents)]
         return th.cat([th.cat(feats, dim=-1), actions], dim=1)
 
