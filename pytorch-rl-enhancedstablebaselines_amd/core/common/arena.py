@@ -18,7 +18,6 @@ from typing import Iterable, List, Optional
 import torch as th
 from torch import nn
 
-from core import _native as nv
 from core.common import hip_ops
 
 _ALIGN = 64  # floats (256 B)

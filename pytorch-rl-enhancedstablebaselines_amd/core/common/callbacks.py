@@ -1,5 +1,5 @@
 """Callback protocol of the reference (core/common/callbacks.py:30-170): hook points only."""
-from typing import Any, Callable, Optional, Union
+from typing import Callable, Optional, Union
 
 
 class BaseCallback:
@@ -134,7 +134,3 @@ def to_callback(callback: MaybeCallback) -> BaseCallback:
     if not isinstance(callback, BaseCallback):
         return ConvertCallback(callback)
     return callback
-
-
-def _unused(*_: Any) -> None:
-    pass

@@ -1,5 +1,5 @@
 """Policy base classes and the continuous critic (reference: core/common/policies.py:39-414, :912-987)."""
-from typing import Optional, Union
+from typing import Optional
 
 import numpy as np
 import torch as th
@@ -125,7 +125,3 @@ class ContinuousCritic(BaseModel):
         with th.no_grad():
             features = self.extract_features(obs, self.features_extractor)
         return self.q_networks[0](th.cat([features, actions], dim=1))
-
-
-def _unused(_: Union[int, None] = None) -> None:
-    pass

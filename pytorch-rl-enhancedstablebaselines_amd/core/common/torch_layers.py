@@ -1,6 +1,6 @@
 """MLP builders (reference: core/common/torch_layers.py:33-46, :110-183, :316-373). Module construction order
 is the reference's, so `th.manual_seed(s)` yields the same initial weights (tests/golden/policy_init_kat.npz)."""
-from typing import Optional, Union
+from typing import Union
 
 import torch as th
 from torch import nn
@@ -38,7 +38,3 @@ def get_actor_critic_arch(net_arch: Union[list, dict]) -> tuple:
     assert "pi" in net_arch, "Error: no key 'pi' was provided in net_arch for the actor network"
     assert "qf" in net_arch, "Error: no key 'qf' was provided in net_arch for the critic network"
     return net_arch["pi"], net_arch["qf"]
-
-
-def _unused(_: Optional[int] = None) -> None:
-    pass

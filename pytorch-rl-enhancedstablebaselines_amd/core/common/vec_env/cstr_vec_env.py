@@ -8,7 +8,7 @@ Two faces:
   * fast path           -- `step_device(actions)` and the fused `collect_step` used by the off-policy
     loop keep everything in HBM and never synchronise with the host.
 """
-from typing import Any, Optional, Sequence
+from typing import Optional, Sequence
 
 import numpy as np
 import torch as th

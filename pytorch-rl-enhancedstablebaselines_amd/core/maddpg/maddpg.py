@@ -15,7 +15,6 @@ Each quirk is reproduced (the golden vectors come from the unmodified reference)
 """
 from typing import List, Optional, Union
 
-import numpy as np
 import torch as th
 from torch.nn import functional as F
 
@@ -26,7 +25,7 @@ from core.common.off_policy_algorithm import OffPolicyAlgorithm
 from core.common.spaces import split_spaces
 from core.common.utils import get_schedule_fn, update_learning_rate
 from core.common.vec_env import CSTRVecEnv
-from core.maddpg.policies import MADDPGPolicy, MlpPolicy
+from core.maddpg.policies import MlpPolicy
 
 
 class MADDPG(OffPolicyAlgorithm):
@@ -359,7 +358,3 @@ class MADDPG(OffPolicyAlgorithm):
               reset_num_timesteps: bool = True, progress_bar: bool = False):
         return super().learn(total_timesteps=total_timesteps, callback=callback, log_interval=log_interval,
                              tb_log_name=tb_log_name, reset_num_timesteps=reset_num_timesteps, progress_bar=progress_bar)
-
-
-def _unused(_: Optional[np.ndarray] = None) -> MADDPGPolicy:  # keeps the policy class importable from this module
-    return MADDPGPolicy

@@ -4,7 +4,7 @@ Agents are index slices of ONE global observation / action vector (`IndexedBox.i
 own deterministic actor on its observation slice and its own twin critics on cat(all features, all actions).
 All actor parameters live in one flat HBM arena (agent-major), all critic parameters in another: each agent's
 optimiser is a `FlatAdam` over its slice, and polyak over ALL agents' parameters is one launch per arena."""
-from typing import List, Optional, Union
+from typing import List, Optional
 
 import numpy as np
 import torch as th
@@ -275,7 +275,3 @@ class MADDPGPolicy(nn.Module):
 
 
 MlpPolicy = MADDPGPolicy
-
-
-def _unused(_: Union[int, None] = None) -> None:
-    pass

@@ -16,7 +16,7 @@ from core.common import fused, hip_ops
 from core.common.arena import FlatAdam, ParamArena
 from core.common.logger import DeviceMean
 from core.common.off_policy_algorithm import OffPolicyAlgorithm
-from core.sac.policies import MlpPolicy, SACPolicy
+from core.sac.policies import MlpPolicy
 
 
 class SAC(OffPolicyAlgorithm):

@@ -2,7 +2,6 @@
 GPU tests: (a) an archive WRITTEN BY THE REFERENCE is loaded (weights_only tensors + plain JSON, nothing unpickled) and
 reproduces the reference's predictions, Q-values and optimiser state; (b) save -> load round trip continues training
 bit-identically; (c) the archive members and optimiser state-dict layout are the reference's."""
-import io
 import os
 import zipfile
 

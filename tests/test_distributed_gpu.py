@@ -5,7 +5,6 @@ Checks SURVEY 8e: identical weights on every rank after training (same averaged 
 import os
 import socket
 
-import numpy as np
 import pytest
 import torch as th
 import torch.multiprocessing as mp

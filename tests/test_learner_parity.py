@@ -254,7 +254,6 @@ def test_hipgraph_iteration_equals_eager():
     models, 12 iterations each (3 side-stream warm-ups + capture + replays on the graph side): the sampler's
     MT19937 stream, the ring, env state and step counters must be bit-identical; weights agree to fp32 noise."""
     from core.common import legacy_rng
-    from core.common.callbacks import NoopCallback
     from core.common.vec_env import CSTRVecEnv
     from core.sac import SAC
 

@@ -5,7 +5,6 @@ import numpy as np
 import pytest
 import torch as th
 
-from conftest import rel_err
 from oracle import cstr_oracle as orc
 
 
