@@ -217,6 +217,13 @@ int cstr_bias_act_fwd_f32(float *y, const float *bias, int act, int64_t groups, 
 int cstr_bias_act_bwd_f32(const float *gy, const float *y, int act, float *gz, float *gbias, int64_t groups, int64_t m, int64_t n,
                           cstr_stream_t stream);
 
+/* nn.Linear + the activation create_mlp puts behind it (core/common/torch_layers.py:110-183), forward, in ONE launch for the
+ * learners' small shapes: y[g][m][n] = act(sum_k x[g][m][k] * w[g][n][k] + bias[g][n]) on the f32 matrix cores (exact f32 fma
+ * chains). x rows are ldx floats apart and groups x_group_stride floats apart (0 = every group reads the same input); w
+ * [groups][n][k], bias [groups][n], y [groups][m][n] contiguous. The backward keeps the rocBLAS GEMMs + cstr_bias_act_bwd_f32. */
+int cstr_linear_act_fwd_f32(const float *x, int64_t x_group_stride, int64_t ldx, const float *w, const float *bias, int act, float *y,
+                            int64_t groups, int64_t m, int64_t n, int64_t k, cstr_stream_t stream);
+
 /* Last hidden layer + scalar head of a Q network: create_mlp(..., output_dim = 1) (core/common/torch_layers.py:110-183;
  * ContinuousCritic.forward, core/common/policies.py:960-987) ends in y = act(z + b1), q = y . w2 + b2. The head is a
  * matrix-vector product, done in the epilogue of the previous GEMM: z [groups][m][k] is replaced by y IN PLACE and

@@ -15,6 +15,7 @@ a hand-written HIP kernel, and gradients are written STRAIGHT into the flat aren
 The nn.Modules keep owning the parameters (state_dict / API); `FastMLP` only reads their tensors. Arithmetic per
 element is the reference's (core/common/torch_layers.py:110-183, core/common/distributions.py:161-260).
 """
+import os
 from typing import List, Optional, Tuple
 
 import torch as th
@@ -24,12 +25,31 @@ from core.common import hip_ops
 
 ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2
 
+# Linear + bias + activation forward in ONE launch (cstr_linear_act_fwd_f32, f32 matrix cores) where it beats the rocBLAS GEMM
+# + epilogue pair: measured on MI355X (tools/linear_probe.py) for every K at batch-sized M and for narrow inputs (K <= 32) at
+# any M; the 4096-row x 256 x 256 layers of the collect-time actor stay on rocBLAS. CSTR_FUSED_LINEAR=0 turns it off.
+USE_FUSED_LINEAR = os.environ.get("CSTR_FUSED_LINEAR", "1") != "0"
+
+
+def _fused_linear_ok(x: th.Tensor) -> bool:
+    if not USE_FUSED_LINEAR or x.stride(-1) != 1:
+        return False
+    rows = x.shape[-2] * (x.shape[0] if x.dim() == 3 else 1)
+    return x.shape[-1] <= 32 or rows <= 1024
+
+
+def _linear_fwd(x: th.Tensor, weight: th.Tensor, bias: th.Tensor, act: int) -> th.Tensor:
+    """act(x @ W^T + b), plain or stacked ([G, M, K] x [G, N, K]): one fused launch or GEMM + epilogue"""
+    if _fused_linear_ok(x):
+        return hip_ops.linear_act_fwd(x, weight, bias, act)
+    y = th.bmm(x, weight.transpose(1, 2)) if x.dim() == 3 else th.mm(x, weight.t())
+    return hip_ops.bias_act_fwd_(y, bias, act)
+
 
 class _LinearFn(th.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, act: int, train_params: bool):
-        y = th.mm(x, weight.t())
-        hip_ops.bias_act_fwd_(y, bias, act)
+        y = _linear_fwd(x, weight, bias, act)
         ctx.act, ctx.train_params = act, train_params
         ctx.save_for_backward(x, weight, y)
         ctx.wgrad, ctx.bgrad = (weight.grad, bias.grad) if train_params else (None, None)
@@ -56,8 +76,7 @@ class _LinearFn(th.autograd.Function):
 def linear(x: th.Tensor, weight: th.Tensor, bias: th.Tensor, act: int, train_params: bool) -> th.Tensor:
     """y = act(x @ W^T + b). With grad mode off this is just the two launches."""
     if not th.is_grad_enabled() or not (x.requires_grad or (train_params and weight.requires_grad)):
-        y = th.mm(x, weight.t())
-        return hip_ops.bias_act_fwd_(y, bias, act)
+        return _linear_fwd(x, weight, bias, act)
     if train_params and (weight.grad is None or bias.grad is None):
         raise RuntimeError("fused linear: parameter gradients must be views of a ParamArena gradient buffer")
     return _LinearFn.apply(x, weight, bias, act, train_params)
@@ -150,8 +169,7 @@ class _StackedLinearFn(th.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, wgrad, bgrad, act: int, train_params: bool, *owners):
-        y = th.bmm(x, weight.transpose(1, 2))
-        hip_ops.bias_act_fwd_(y, bias, act)
+        y = _linear_fwd(x, weight, bias, act)
         ctx.act, ctx.train_params = act, train_params
         ctx.save_for_backward(x, weight, y)
         ctx.wgrad, ctx.bgrad = wgrad, bgrad
@@ -180,8 +198,7 @@ def stacked_linear(x, weight, bias, wgrad, bgrad, act: int, train_params: bool, 
     """`owners`: the nn.Parameters whose storage `weight` / `bias` alias; passing them makes the output require grad when
     only the parameters do (first layer on replay data)."""
     if not th.is_grad_enabled() or not (x.requires_grad or train_params):
-        y = th.bmm(x, weight.transpose(1, 2))
-        return hip_ops.bias_act_fwd_(y, bias, act)
+        return _linear_fwd(x, weight, bias, act)
     return _StackedLinearFn.apply(x, weight, bias, wgrad, bgrad, act, train_params, *(owners if train_params else ()))
 
 

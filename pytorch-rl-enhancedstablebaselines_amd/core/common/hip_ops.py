@@ -326,6 +326,31 @@ def gaussian_head_bwd(g_action, g_logp, action, params, eps, g_params, g_bias):
           "cstr_gaussian_head_bwd_f32")
 
 
+def linear_act_fwd(x, weight, bias, act: int, out=None):
+    """y = act(x @ W^T + b) in one launch (f32 matrix cores). x [M, K] or [G, M, K] with unit inner stride (rows / groups may
+    be strided, a stride-0 group dimension shares the input), weight [N, K] / [G, N, K], bias [N] / [G, N] contiguous."""
+    if x.dim() == 2:
+        g, (m, k), gs, ldx = 1, x.shape, 0, x.stride(0)
+        n = weight.shape[0]
+        shape = (m, n)
+    else:
+        g, m, k = x.shape
+        gs, ldx = x.stride(0), x.stride(1)
+        n = weight.shape[1]
+        shape = (g, m, n)
+    if not (x.is_cuda and x.dtype == th.float32 and x.stride(-1) == 1 and ldx >= k):
+        raise ValueError("x: needs a float32 device tensor with unit inner stride")
+    if m == 1:
+        ldx = max(ldx, k)
+    _f32c(weight, "weight"), _f32c(bias, "bias")
+    if weight.numel() != g * n * k or bias.numel() != g * n:
+        raise ValueError(f"weight / bias do not match x {tuple(x.shape)}: {tuple(weight.shape)}, {tuple(bias.shape)}")
+    y = th.empty(shape, dtype=th.float32, device=x.device) if out is None else _chk(out, "out", shape, th.float32)
+    check(nv.lib().cstr_linear_act_fwd_f32(ptr(x), C.c_int64(gs), C.c_int64(ldx), ptr(weight), ptr(bias), C.c_int(act), ptr(y),
+                                           C.c_int64(g), C.c_int64(m), C.c_int64(n), C.c_int64(k), stream_ptr()), "cstr_linear_act_fwd_f32")
+    return y
+
+
 def target_smooth(action, noise, rng_ctl, sigma: float, clip: float, out):
     """out = clamp(action + clamp(noise, -clip, clip), -1, 1); noise given ([B, A], already scaled) or drawn (rng_ctl)."""
     b, a = action.shape

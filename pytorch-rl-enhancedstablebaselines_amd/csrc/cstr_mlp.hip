@@ -114,6 +114,88 @@ __device__ __forceinline__ float block_sum_256(float v, float *sm)
     return r;
 }
 
+// ---- small-batch Linear + bias + activation forward on the f32 matrix cores ----------------------------------------
+// y[m][n] = act(sum_k x[m][k] * W[n][k] + b[n]) for the learners' shapes (M = 256..4096 rows, N, K <= a few hundred):
+// a rocBLAS GEMM followed by the bias/activation epilogue is two ~3 us launches for ~30 MFLOP; this is one. One wave owns
+// a 16 x 16 output tile and runs v_mfma_f32_16x16x4_f32 (exact f32 fma chains, the guide's "FP32-input MFMA") over K with
+// two independent accumulators. Operands go straight from L2 to registers: lane (r = lane & 15, h = lane >> 4) loads
+// x[m0 + r][16c + 4h .. +3] and W[n0 + r][16c + 4h .. +3] as one 16-byte vector per 16-wide K chunk and feeds element e to
+// MFMA step e -- the k order inside a chunk is permuted identically for both operands, which a sum over k does not see.
+// No LDS: at these sizes the tile re-reads hit L2 and the launch is latency-, not bandwidth-bound.
+// Grouped (stacked twin critics): x [G][M][K] (group stride may be 0: shared input), W [G][N][K], b [G][N], y [G][M][N].
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+template <bool VEC>
+__device__ __forceinline__ float4 load_k4(const float *__restrict__ row, const int k, const int K, const bool valid)
+{
+    float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (!valid || k >= K) return v;
+    if (VEC) return *reinterpret_cast<const float4 *>(row + k);  // K % 4 == 0 and 16-byte aligned rows
+    v.x = row[k];
+    if (k + 1 < K) v.y = row[k + 1];
+    if (k + 2 < K) v.z = row[k + 2];
+    if (k + 3 < K) v.w = row[k + 3];
+    return v;
+}
+
+// WAVES > 1: split-K -- wave s takes the 16-wide K chunks s, s + WAVES, ... (all of its loads in flight at once: one L2
+// round trip for K = 256 with four waves) and the partial tiles meet in LDS.
+template <int ACT, bool VEC, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void linear_act_fwd_kernel(const float *__restrict__ x, const int64_t x_group_stride,
+                                                                    const int ldx, const float *__restrict__ w,
+                                                                    const float *__restrict__ bias, float *__restrict__ y,
+                                                                    const int M, const int N, const int K)
+{
+    __shared__ f32x4 part[WAVES > 1 ? WAVES - 1 : 1][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, h = lane >> 4;
+    const int n0 = blockIdx.x * 16, m0 = blockIdx.y * 16;
+    const int64_t g = blockIdx.z;
+    const float *xr = x + g * x_group_stride + (int64_t)(m0 + r) * ldx;
+    const float *wr = w + (g * N + n0 + r) * (int64_t)K;
+    const bool row_ok = m0 + r < M, col_ok = n0 + r < N;
+    f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
+    constexpr int UNROLL = 4;  // 8 vector loads in flight per lane
+    for (int c0 = 16 * wave; c0 < K; c0 += 16 * WAVES * UNROLL) {
+        float4 a[UNROLL], b[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const int k = c0 + 16 * WAVES * u + 4 * h;
+            a[u] = load_k4<VEC>(xr, k, K, row_ok);
+            b[u] = load_k4<VEC>(wr, k, K, col_ok);
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].x, b[u].x, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].y, b[u].y, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].z, b[u].z, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].w, b[u].w, acc1, 0, 0, 0);
+        }
+    }
+    f32x4 acc = acc0 + acc1;
+    if (WAVES > 1) {
+        if (wave > 0) part[wave - 1][lane] = acc;
+        __syncthreads();
+        if (wave > 0) return;
+#pragma unroll
+        for (int v = 0; v < WAVES - 1; ++v) acc += part[v][lane];
+    }
+    // C/D map of the 16x16 MFMA: column = lane & 15, row = 4 * (lane >> 4) + register
+    const int col = n0 + r;
+    if (col < N) {
+        const float bv = bias[g * N + col];
+        float *yo = y + (g * M + m0 + 4 * h) * (int64_t)N + col;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (m0 + 4 * h + e < M) {
+                float v = acc[e] + bv;
+                if (ACT == ACT_RELU) v = fmaxf(v, 0.0f);
+                if (ACT == ACT_TANH) v = tanhf(v);
+                yo[(int64_t)e * N] = v;
+            }
+        }
+    }
+}
+
 // ---- last hidden layer + scalar head of a Q network ------------------------------------------------------------
 // create_mlp(..., output_dim = 1) ends in  y = act(z + b1);  q = y . w2 + b2  (core/common/torch_layers.py:110-183,
 // ContinuousCritic: core/common/policies.py:960-987). The head is a matrix-VECTOR product (n = 1), which rocBLAS runs
@@ -669,5 +751,25 @@ extern "C" int cstr_target_smooth_f32(const float *action, const float *noise, u
     const int64_t g = (batch + 63) / 64;
     target_smooth_kernel<<<(unsigned)(g < 4096 ? g : 4096), 64, 0, (hipStream_t)stream>>>(action, noise, rng_ctl, sigma, clip, out,
                                                                                          out_stride, batch, act_dim);
+    return (int)hipGetLastError();
+}
+
+extern "C" int cstr_linear_act_fwd_f32(const float *x, int64_t x_group_stride, int64_t ldx, const float *w, const float *bias, int act,
+                                       float *y, int64_t groups, int64_t m, int64_t n, int64_t k, cstr_stream_t stream)
+{
+    if (!x || !w || !bias || !y || groups <= 0 || m <= 0 || n <= 0 || k <= 0 || ldx < k || x_group_stride < 0) return CSTR_E_BADARG;
+    if (act < 0 || act > 2 || m > 0x7fffff || n > 0x7fffff || k > 0x7fffff || groups > 65535 || (m + 15) / 16 > 65535) return CSTR_E_UNSUPPORTED;
+    const dim3 grid((unsigned)((n + 15) / 16), (unsigned)((m + 15) / 16), (unsigned)groups);
+    const bool vec = (k & 3) == 0 && (ldx & 3) == 0 && (x_group_stride & 3) == 0 && aligned16(x) && aligned16(w);
+    hipStream_t s = (hipStream_t)stream;
+    // one wave per tile when K fits one chunk batch of a single wave's first round trip or the grid is already large;
+    // four-way split-K otherwise (K = 256 on 256 tiles: each wave's loads are one round trip)
+    const bool split = k > 32 && (int64_t)grid.x * grid.y * grid.z <= 2048;
+#define LIN(A, V, W) linear_act_fwd_kernel<A, V, W><<<grid, 64 * W, 0, s>>>(x, x_group_stride, (int)ldx, w, bias, y, (int)m, (int)n, (int)k)
+#define LIN_ACT(V, W) do { if (act == 0) LIN(0, V, W); else if (act == 1) LIN(1, V, W); else LIN(2, V, W); } while (0)
+    if (vec) { if (split) LIN_ACT(true, 4); else LIN_ACT(true, 1); }
+    else { if (split) LIN_ACT(false, 4); else LIN_ACT(false, 1); }
+#undef LIN_ACT
+#undef LIN
     return (int)hipGetLastError();
 }

@@ -89,7 +89,8 @@ def test_fused_linear_matches_module(ops, M, K, N, act):
     fn = {0: lambda t: t, 1: th.relu, 2: th.tanh}[act]
     y_ref = fn(ref(x2))
     y = fused.linear(x, lin.weight, lin.bias, act, True)
-    assert rel_err(y.detach().cpu().numpy(), y_ref.detach().cpu().numpy(), 1e-2) < 1e-5
+    # two fp32 summation orders (rocBLAS tiles vs the k-ordered MFMA chain of the fused kernel): compare at the output scale
+    assert rel_err(y.detach().cpu().numpy(), y_ref.detach().cpu().numpy(), max(1e-2, float(y_ref.detach().abs().mean()))) < 1e-5
     gy = th.randn(M, N, device="cuda")
     arena.grad.fill_(123.0)  # stale values must be overwritten, not accumulated
     y.backward(gy)
@@ -325,3 +326,37 @@ def test_target_smoothing_kernel(ops):
     assert float(out.abs().max()) == 0.0
     with pytest.raises(ValueError):
         hip_ops.target_smooth(a, noise, ctl, 0.2, 0.5, x[:, D:])
+
+
+@pytest.mark.parametrize("G,M,N,K,act", [(0, 256, 256, 256, 1), (0, 256, 256, 4, 1), (0, 4096, 256, 256, 1), (2, 256, 256, 6, 1),
+                                        (2, 256, 256, 256, 1), (0, 100, 400, 10, 1), (0, 37, 300, 400, 2), (2, 33, 30, 50, 0),
+                                        (0, 1, 16, 7, 2), (0, 256, 4, 256, 0)])
+def test_fused_linear_forward_on_f32_matrix_cores(ops, G, M, N, K, act):
+    """cstr_linear_act_fwd_f32 (v_mfma_f32_16x16x4_f32 tiles) against an fp64 reference: create_mlp's Linear + ReLU / Tanh
+    (torch_layers.py:110-183), plain and grouped, strided / shared inputs, ragged M, N, K."""
+    from core.common import hip_ops
+
+    gen = th.Generator(device="cuda").manual_seed(M * 7 + N * 3 + K)
+    gg = max(G, 1)
+    w = th.randn(gg, N, K, device="cuda", generator=gen) / K ** 0.5
+    b = th.randn(gg, N, device="cuda", generator=gen)
+    wide = th.randn(gg, M, K + 3, device="cuda", generator=gen)
+    for variant in ("contiguous", "row-strided", "shared"):
+        if variant == "contiguous":
+            x = wide[:, :, :K].contiguous()
+        elif variant == "row-strided":
+            x = wide[:, :, 1:K + 1]  # rows K + 3 floats apart, base not 16-byte aligned
+        else:
+            x = wide[0, :, :K].contiguous().unsqueeze(0).expand(gg, -1, -1)  # stride-0 group dimension
+        ref = th.einsum("gmk,gnk->gmn", x.double(), w.double()) + b.double()[:, None, :]
+        ref = th.relu(ref) if act == 1 else (th.tanh(ref) if act == 2 else ref)
+        if G == 0:
+            y = hip_ops.linear_act_fwd(x[0], w[0], b[0], act)
+            ref = ref[0]
+        else:
+            y = hip_ops.linear_act_fwd(x, w, b, act)
+        scale = max(1.0, float(ref.abs().max()))
+        assert tuple(y.shape) == tuple(ref.shape)
+        assert rel_err(y.cpu().numpy(), ref.cpu().numpy(), scale) < 2e-6, variant
+    with pytest.raises(ValueError):
+        hip_ops.linear_act_fwd(wide[0].t(), w[0], b[0], act)

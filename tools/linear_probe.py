@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""GPU probe: Linear + bias + activation forward as (rocBLAS GEMM from the tuned table + epilogue launch) vs the one-launch
+f32-MFMA kernel cstr_linear_act_fwd_f32, both timed as graph-replayed launches (the way the training loop issues them)."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "pytorch-rl-enhancedstablebaselines_amd")):
+    sys.path.insert(0, p)
+import torch as th  # noqa: E402
+
+from core.common import blas, hip_ops  # noqa: E402
+from tools.gemm_probe import t_us  # noqa: E402
+
+SHAPES = [(0, 256, 256, 4), (0, 256, 256, 256), (0, 4096, 256, 4), (0, 4096, 256, 256), (2, 256, 256, 6), (2, 256, 256, 256),
+          (0, 256, 400, 4), (0, 256, 300, 400), (2, 256, 400, 6), (2, 256, 300, 400), (0, 4096, 400, 4), (0, 4096, 300, 400)]
+
+if __name__ == "__main__":
+    blas.configure()
+    for (g, m, n, k) in SHAPES:
+        gg = max(g, 1)
+        x = th.randn(gg, m, k, device="cuda")
+        w, b = th.randn(gg, n, k, device="cuda"), th.randn(gg, n, device="cuda")
+        if g == 0:
+            x, w, b = x[0], w[0], b[0]
+            two = t_us(lambda: hip_ops.bias_act_fwd_(th.mm(x, w.t()), b, 1))
+        else:
+            two = t_us(lambda: hip_ops.bias_act_fwd_(th.bmm(x, w.transpose(1, 2)), b, 1))
+        one = t_us(lambda: hip_ops.linear_act_fwd(x, w, b, 1))
+        print(f"G={g} M={m} N={n} K={k}: GEMM + epilogue {two:6.2f} us   fused MFMA kernel {one:6.2f} us", flush=True)
