@@ -224,6 +224,14 @@ int cstr_bias_act_bwd_f32(const float *gy, const float *y, int act, float *gz, f
 int cstr_linear_act_fwd_f32(const float *x, int64_t x_group_stride, int64_t ldx, const float *w, const float *bias, int act, float *y,
                             int64_t groups, int64_t m, int64_t n, int64_t k, cstr_stream_t stream);
 
+/* Backward of a Linear w.r.t. its input, fused with the activation gradient of the layer BELOW it (autograd's mm backward +
+ * threshold/tanh backward of core/common/torch_layers.py:110-183's Linear -> ReLU -> Linear):
+ *   dz[g][m][k] = (sum_n gz[g][m][n] * w[g][n][k]) * act'(y[g][m][k])
+ * gz: gradient w.r.t. this layer's pre-activation [groups][m][n]; w [groups][n][k]; y [groups][m][k]: the lower layer's
+ * OUTPUT (this layer's input), NULL with act == NONE; all contiguous. */
+int cstr_linear_bwd_input_f32(const float *gz, const float *w, const float *y, int act, float *dz, int64_t groups, int64_t m,
+                              int64_t n, int64_t k, cstr_stream_t stream);
+
 /* Last hidden layer + scalar head of a Q network: create_mlp(..., output_dim = 1) (core/common/torch_layers.py:110-183;
  * ContinuousCritic.forward, core/common/policies.py:960-987) ends in y = act(z + b1), q = y . w2 + b2. The head is a
  * matrix-vector product, done in the epilogue of the previous GEMM: z [groups][m][k] is replaced by y IN PLACE and

@@ -46,11 +46,49 @@ def _linear_fwd(x: th.Tensor, weight: th.Tensor, bias: th.Tensor, act: int) -> t
     return hip_ops.bias_act_fwd_(y, bias, act)
 
 
+# Inside a chain of fused layers the gradient that travels DOWN between two Linears is dz (w.r.t. the lower layer's
+# pre-activation), not dy: the upper layer's input-gradient kernel applies the lower layer's activation gradient while the
+# tile is still in registers (cstr_linear_bwd_input_f32) and adds the lower bias gradient's column sums, so the lower
+# layer's own backward has no element-wise launch left. `below` = (activation, bias-gradient view | None) of the fused
+# layer whose OUTPUT this layer's input is; `grad_is_dz` marks a layer whose consumer does that for it. Both are set by
+# the chain builders below (FastMLP, FastTwinCritic, FastSacActor) -- the tensors in between are private to the chain.
+def _input_grad(gz: th.Tensor, weight: th.Tensor, x: th.Tensor, below) -> th.Tensor:
+    """d(loss)/d(input) of a Linear given gz = d(loss)/d(pre-activation); with `below`, d(loss)/d(lower pre-activation)."""
+    if below is None or not USE_FUSED_LINEAR:
+        dx = th.bmm(gz, weight) if gz.dim() == 3 else th.mm(gz, weight)
+        if below is not None:  # unfused arithmetic of the same contract
+            act, bgrad = below
+            out = th.empty_like(dx)
+            hip_ops.bias_act_bwd(dx, x, act, out, bgrad)
+            return out
+        return dx
+    act, bgrad = below
+    dz = hip_ops.linear_bwd_input(gz, weight, x, act)
+    if bgrad is not None:
+        hip_ops.bias_act_bwd(dz, None, ACT_NONE, dz, bgrad)  # the lower layer's bias gradient: column sums of dz
+    return dz
+
+
+def _own_grad(ctx, gy: th.Tensor, y: th.Tensor) -> th.Tensor:
+    """gz of this layer from what arrived: already dz when the consumer is a fused layer, otherwise dy -> dz here."""
+    gy = gy.contiguous()
+    if ctx.grad_is_dz:
+        return gy
+    gbias = ctx.bgrad if ctx.train_params else None
+    if ctx.act != ACT_NONE:
+        gz = th.empty_like(gy)
+        hip_ops.bias_act_bwd(gy, y, ctx.act, gz, gbias)
+        return gz
+    if gbias is not None:
+        hip_ops.bias_act_bwd(gy, None, ACT_NONE, gy, gbias)
+    return gy
+
+
 class _LinearFn(th.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, act: int, train_params: bool):
+    def forward(ctx, x, weight, bias, act: int, train_params: bool, below, grad_is_dz: bool):
         y = _linear_fwd(x, weight, bias, act)
-        ctx.act, ctx.train_params = act, train_params
+        ctx.act, ctx.train_params, ctx.below, ctx.grad_is_dz = act, train_params, below, grad_is_dz
         ctx.save_for_backward(x, weight, y)
         ctx.wgrad, ctx.bgrad = (weight.grad, bias.grad) if train_params else (None, None)
         return y
@@ -58,28 +96,21 @@ class _LinearFn(th.autograd.Function):
     @staticmethod
     def backward(ctx, gy):
         x, weight, y = ctx.saved_tensors
-        gy = gy.contiguous()
-        gbias = ctx.bgrad if ctx.train_params else None
-        if ctx.act != ACT_NONE:
-            gz = th.empty_like(gy)
-            hip_ops.bias_act_bwd(gy, y, ctx.act, gz, gbias)
-        else:
-            gz = gy
-            if gbias is not None:
-                hip_ops.bias_act_bwd(gy, None, ACT_NONE, gy, gbias)
+        gz = _own_grad(ctx, gy, y)
         if ctx.train_params:
             th.mm(gz.t(), x, out=ctx.wgrad)  # dW lands in the flat gradient arena
-        dx = th.mm(gz, weight) if ctx.needs_input_grad[0] else None
-        return dx, None, None, None, None
+        dx = _input_grad(gz, weight, x, ctx.below) if ctx.needs_input_grad[0] else None
+        return dx, None, None, None, None, None, None
 
 
-def linear(x: th.Tensor, weight: th.Tensor, bias: th.Tensor, act: int, train_params: bool) -> th.Tensor:
-    """y = act(x @ W^T + b). With grad mode off this is just the two launches."""
+def linear(x: th.Tensor, weight: th.Tensor, bias: th.Tensor, act: int, train_params: bool, below=None,
+           grad_is_dz: bool = False) -> th.Tensor:
+    """y = act(x @ W^T + b). With grad mode off this is just the forward launch(es)."""
     if not th.is_grad_enabled() or not (x.requires_grad or (train_params and weight.requires_grad)):
         return _linear_fwd(x, weight, bias, act)
     if train_params and (weight.grad is None or bias.grad is None):
         raise RuntimeError("fused linear: parameter gradients must be views of a ParamArena gradient buffer")
-    return _LinearFn.apply(x, weight, bias, act, train_params)
+    return _LinearFn.apply(x, weight, bias, act, train_params, below if x.requires_grad else None, grad_is_dz)
 
 
 class FastMLP:
@@ -111,17 +142,27 @@ class FastMLP:
         except NotImplementedError:
             return False
 
-    def __call__(self, x: th.Tensor, train_params: bool = True) -> th.Tensor:
+    def tail_below(self, train_params: bool):
+        """what a fused consumer of this MLP's output needs to run the last layer's activation / bias gradient itself"""
+        lin, act = self.layers[-1]
+        return (act, lin.bias.grad if train_params else None)
+
+    def __call__(self, x: th.Tensor, train_params: bool = True, out_grad_is_dz: bool = False) -> th.Tensor:
+        """`out_grad_is_dz`: the consumer is a fused layer built with `below=self.tail_below(...)` (see _input_grad)."""
         layers = self.layers
         scalar_head = len(layers) >= 2 and layers[-1][0].out_features == 1 and layers[-1][1] == ACT_NONE
-        for lin, act in (layers[:-2] if scalar_head else layers):
-            x = linear(x, lin.weight, lin.bias, act, train_params)
+        plain = layers[:-2] if scalar_head else layers
+        below = None
+        for i, (lin, act) in enumerate(plain):
+            inner = scalar_head or i < len(plain) - 1 or out_grad_is_dz
+            x = linear(x, lin.weight, lin.bias, act, train_params, below, grad_is_dz=inner)
+            below = (act, lin.bias.grad if train_params else None)
         if scalar_head:
             (l1, act), (l2, _) = layers[-2:]
             grads = (l1.weight.grad, l1.bias.grad, l2.weight.grad, l2.bias.grad) if train_params else None
             if train_params and th.is_grad_enabled() and any(g is None for g in grads):
                 raise RuntimeError("fused linear: parameter gradients must be views of a ParamArena gradient buffer")
-            x = hidden_head(x, l1.weight, l1.bias, l2.weight, l2.bias, grads, act, train_params, (l1.weight, l2.weight))
+            x = hidden_head(x, l1.weight, l1.bias, l2.weight, l2.bias, grads, act, train_params, (l1.weight, l2.weight), below)
         return x
 
 
@@ -168,9 +209,9 @@ class _StackedLinearFn(th.autograd.Function):
     W [G, N, K], b [G, N] are stacked VIEWS of the parameter arena, wgrad / bgrad the same views of the gradient arena."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, wgrad, bgrad, act: int, train_params: bool, *owners):
+    def forward(ctx, x, weight, bias, wgrad, bgrad, act: int, train_params: bool, below, grad_is_dz: bool, *owners):
         y = _linear_fwd(x, weight, bias, act)
-        ctx.act, ctx.train_params = act, train_params
+        ctx.act, ctx.train_params, ctx.below, ctx.grad_is_dz = act, train_params, below, grad_is_dz
         ctx.save_for_backward(x, weight, y)
         ctx.wgrad, ctx.bgrad = wgrad, bgrad
         ctx.n_owners = len(owners)
@@ -179,27 +220,20 @@ class _StackedLinearFn(th.autograd.Function):
     @staticmethod
     def backward(ctx, gy):
         x, weight, y = ctx.saved_tensors
-        gy = gy.contiguous()
-        gbias = ctx.bgrad if ctx.train_params else None
-        if ctx.act != ACT_NONE:
-            gz = th.empty_like(gy)
-            hip_ops.bias_act_bwd(gy, y, ctx.act, gz, gbias)
-        else:
-            gz = gy
-            if gbias is not None:
-                hip_ops.bias_act_bwd(gy, None, ACT_NONE, gy, gbias)
+        gz = _own_grad(ctx, gy, y)
         if ctx.train_params:
             th.bmm(gz.transpose(1, 2), x, out=ctx.wgrad)
-        dx = th.bmm(gz, weight) if ctx.needs_input_grad[0] else None
-        return (dx, None, None, None, None, None, None) + (None,) * ctx.n_owners
+        dx = _input_grad(gz, weight, x, ctx.below) if ctx.needs_input_grad[0] else None
+        return (dx,) + (None,) * (8 + ctx.n_owners)
 
 
-def stacked_linear(x, weight, bias, wgrad, bgrad, act: int, train_params: bool, owners=()):
+def stacked_linear(x, weight, bias, wgrad, bgrad, act: int, train_params: bool, owners=(), below=None, grad_is_dz: bool = False):
     """`owners`: the nn.Parameters whose storage `weight` / `bias` alias; passing them makes the output require grad when
     only the parameters do (first layer on replay data)."""
     if not th.is_grad_enabled() or not (x.requires_grad or train_params):
         return _linear_fwd(x, weight, bias, act)
-    return _StackedLinearFn.apply(x, weight, bias, wgrad, bgrad, act, train_params, *(owners if train_params else ()))
+    return _StackedLinearFn.apply(x, weight, bias, wgrad, bgrad, act, train_params, below if x.requires_grad else None, grad_is_dz,
+                                  *(owners if train_params else ()))
 
 
 class _HiddenHeadFn(th.autograd.Function):
@@ -207,12 +241,13 @@ class _HiddenHeadFn(th.autograd.Function):
     w1 [.., N, K], b1 [.., N], w2 [.., 1, N], b2 [.., 1] and their gradient views (None when frozen)."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, grads, act: int, train_params: bool, *owners):
+    def forward(ctx, x, w1, b1, w2, b2, grads, act: int, train_params: bool, below, *owners):
         batched = x.dim() == 3
         z = th.bmm(x, w1.transpose(1, 2)) if batched else th.mm(x, w1.t())
         q = th.empty(*z.shape[:-1], 1, dtype=z.dtype, device=z.device)
         hip_ops.hidden_head_fwd_(z, b1, act, w2, b2, q)  # z now holds y = act(z + b1)
         ctx.act, ctx.train_params, ctx.batched, ctx.grads, ctx.n_owners = act, train_params, batched, grads, len(owners)
+        ctx.below = below
         ctx.save_for_backward(x, w1, z, w2)
         return q
 
@@ -222,22 +257,18 @@ class _HiddenHeadFn(th.autograd.Function):
         gw1, gb1, gw2, gb2 = ctx.grads if ctx.train_params else (None, None, None, None)
         dz = th.empty_like(y)
         hip_ops.hidden_head_bwd(gq.contiguous(), y, ctx.act, w2, dz, gb1, gw2, gb2)
-        if ctx.batched:
-            if ctx.train_params:
-                th.bmm(dz.transpose(1, 2), x, out=gw1)
-            dx = th.bmm(dz, w1) if ctx.needs_input_grad[0] else None
-        else:
-            if ctx.train_params:
-                th.mm(dz.t(), x, out=gw1)
-            dx = th.mm(dz, w1) if ctx.needs_input_grad[0] else None
-        return (dx,) + (None,) * (7 + ctx.n_owners)
+        if ctx.train_params:
+            th.bmm(dz.transpose(1, 2), x, out=gw1) if ctx.batched else th.mm(dz.t(), x, out=gw1)
+        dx = _input_grad(dz, w1, x, ctx.below) if ctx.needs_input_grad[0] else None
+        return (dx,) + (None,) * (8 + ctx.n_owners)
 
 
-def hidden_head(x, w1, b1, w2, b2, grads, act: int, train_params: bool, owners=()):
+def hidden_head(x, w1, b1, w2, b2, grads, act: int, train_params: bool, owners=(), below=None):
     """The last two layers of a Q network in one GEMM + one launch. `grads` = (w1.grad, b1.grad, w2.grad, b2.grad) views of
     the gradient arena (or None when the parameters are frozen)."""
     if th.is_grad_enabled() and (x.requires_grad or train_params):
-        return _HiddenHeadFn.apply(x, w1, b1, w2, b2, grads, act, train_params, *(owners if train_params else ()))
+        return _HiddenHeadFn.apply(x, w1, b1, w2, b2, grads, act, train_params, below if x.requires_grad else None,
+                                   *(owners if train_params else ()))
     z = th.bmm(x, w1.transpose(1, 2)) if x.dim() == 3 else th.mm(x, w1.t())
     q = th.empty(*z.shape[:-1], 1, dtype=z.dtype, device=z.device)
     return hip_ops.hidden_head_fwd_(z, b1, act, w2, b2, q)
@@ -290,12 +321,14 @@ class FastSacActor:
             if xbuf is not None:
                 return th.cat((xbuf[:, :xbuf.shape[1] - self.act_dim], action), dim=1), logp
             return action, logp
-        h = self.latent(obs, train_params)
+        h = self.latent(obs, train_params, out_grad_is_dz=True)  # this head runs the latent net's last activation gradient
         if self.rng_ctl is None:
             self.rng_ctl = hip_ops.new_rng_ctl(th.initial_seed(), obs.device)
         grad = th.is_grad_enabled() and (h.requires_grad or train_params)
         tp = train_params and grad
-        args = (h, self._hw, self._hb, self._hwg if tp else None, self._hbg if tp else None, eps, self.rng_ctl, xbuf, tp, want_logp)
+        below = self.latent.tail_below(train_params) if h.requires_grad else None
+        args = (h, self._hw, self._hb, self._hwg if tp else None, self._hbg if tp else None, eps, self.rng_ctl, xbuf, tp, want_logp,
+                below)
         if grad:
             out = _GaussianHeadFn.apply(*args, *((self.mu.weight, self.log_std.weight) if tp else ()))
         else:
@@ -328,7 +361,7 @@ class _GaussianHeadFn(th.autograd.Function):
     `eps` is given); backward = ONE launch (d params + bias gradient) + the head's two GEMMs."""
 
     @staticmethod
-    def forward(ctx, h, w, b, wg, bg, eps, rng_ctl, xbuf, train_params: bool, want_logp: bool, *owners):
+    def forward(ctx, h, w, b, wg, bg, eps, rng_ctl, xbuf, train_params: bool, want_logp: bool, below, *owners):
         params = th.mm(h, w.t())
         n, a = params.shape[0], params.shape[1] // 2
         # xbuf: a critic input [B, D + A] whose LAST A columns receive the action (no torch.cat); the whole buffer is the
@@ -340,7 +373,7 @@ class _GaussianHeadFn(th.autograd.Function):
         else:
             rng_ctl = None
         hip_ops.gaussian_head_fwd_(params, b, eps, rng_ctl, action, logp)
-        ctx.train_params, ctx.wg, ctx.bg, ctx.n_owners = train_params, wg, bg, len(owners)
+        ctx.train_params, ctx.wg, ctx.bg, ctx.n_owners, ctx.below = train_params, wg, bg, len(owners), below
         ctx.save_for_backward(h, w, params, eps)
         ctx.action, ctx.a = action.detach(), a
         ctx.set_materialize_grads(False)
@@ -363,8 +396,8 @@ class _GaussianHeadFn(th.autograd.Function):
                                   ctx.bg if ctx.train_params else None)
         if ctx.train_params:
             th.mm(g_params.t(), h, out=ctx.wg)
-        dx = th.mm(g_params, w) if ctx.needs_input_grad[0] else None
-        return (dx,) + (None,) * (9 + ctx.n_owners)
+        dx = _input_grad(g_params, w, h, ctx.below) if ctx.needs_input_grad[0] else None
+        return (dx,) + (None,) * (10 + ctx.n_owners)
 
 
 class QOut(tuple):
@@ -409,13 +442,17 @@ class FastTwinCritic:
         if train_params and g != stack[0][0].shape[0]:
             raise RuntimeError("stacked critic: parameter gradients need all Q networks in the pass")
         cut = lambda t: None if t is None else t[:g]  # noqa: E731
-        for li, (w, wg, b, bg) in enumerate(stack[:-2] if scalar_head else stack):
-            h = stacked_linear(h, w[:g], b[:g], cut(wg), cut(bg), self.acts[li], train_params, self.owners[li][:g])
+        plain = stack[:-2] if scalar_head else stack
+        below = None
+        for li, (w, wg, b, bg) in enumerate(plain):
+            inner = scalar_head or li < len(plain) - 1  # its consumer is a fused layer that takes over the activation gradient
+            h = stacked_linear(h, w[:g], b[:g], cut(wg), cut(bg), self.acts[li], train_params, self.owners[li][:g], below, inner)
+            below = (self.acts[li], cut(bg) if train_params else None)
         if scalar_head:
             (w1, wg1, b1, bg1), (w2, wg2, b2, bg2) = stack[-2:]
             grads = (cut(wg1), cut(bg1), cut(wg2), cut(bg2)) if train_params else None
             h = hidden_head(h, w1[:g], b1[:g], w2[:g], b2[:g], grads, self.acts[-2], train_params,
-                            self.owners[-2][:g] + self.owners[-1][:g])
+                            self.owners[-2][:g] + self.owners[-1][:g], below)
         out = QOut(h[i] for i in range(g))
         out.stacked = h
         return out

@@ -351,6 +351,23 @@ def linear_act_fwd(x, weight, bias, act: int, out=None):
     return y
 
 
+def linear_bwd_input(gz, weight, y, act: int):
+    """dz = (gz @ W) * act'(y): a Linear's input gradient fused with the activation gradient of the layer below (whose output
+    y is this layer's input). gz [M, N] / [G, M, N], weight [N, K] / [G, N, K] contiguous."""
+    g, m, n = _gmn(gz)
+    k = weight.shape[-1]
+    _f32c(gz, "gz"), _f32c(weight, "weight")
+    if weight.numel() != g * n * k:
+        raise ValueError(f"weight {tuple(weight.shape)} does not match gz {tuple(gz.shape)}")
+    shape = (m, k) if gz.dim() == 2 else (g, m, k)
+    if act != 0:
+        _chk(y, "y", shape, th.float32)
+    dz = th.empty(shape, dtype=th.float32, device=gz.device)
+    check(nv.lib().cstr_linear_bwd_input_f32(ptr(gz), ptr(weight), ptr(y if act != 0 else None), C.c_int(act), ptr(dz), C.c_int64(g),
+                                             C.c_int64(m), C.c_int64(n), C.c_int64(k), stream_ptr()), "cstr_linear_bwd_input_f32")
+    return dz
+
+
 def target_smooth(action, noise, rng_ctl, sigma: float, clip: float, out):
     """out = clamp(action + clamp(noise, -clip, clip), -1, 1); noise given ([B, A], already scaled) or drawn (rng_ctl)."""
     b, a = action.shape

@@ -360,3 +360,24 @@ def test_fused_linear_forward_on_f32_matrix_cores(ops, G, M, N, K, act):
         assert rel_err(y.cpu().numpy(), ref.cpu().numpy(), scale) < 2e-6, variant
     with pytest.raises(ValueError):
         hip_ops.linear_act_fwd(wide[0].t(), w[0], b[0], act)
+
+
+@pytest.mark.parametrize("G,M,N,K,act", [(0, 256, 256, 256, 1), (2, 256, 256, 256, 1), (0, 256, 4, 256, 1), (2, 256, 256, 6, 0),
+                                        (0, 100, 300, 400, 1), (0, 37, 50, 30, 2), (2, 5, 7, 9, 1), (0, 512, 256, 256, 1)])
+def test_fused_linear_input_gradient_kernel(ops, G, M, N, K, act):
+    """cstr_linear_bwd_input_f32: dz = (gz @ W) * act'(y) -- against fp64."""
+    from core.common import hip_ops
+
+    gen = th.Generator(device="cuda").manual_seed(M + 3 * N + 7 * K)
+    gg = max(G, 1)
+    gz = th.randn(gg, M, N, device="cuda", generator=gen)
+    w = th.randn(gg, N, K, device="cuda", generator=gen) / N ** 0.5
+    pre = th.randn(gg, M, K, device="cuda", generator=gen)
+    y = th.relu(pre) if act == 1 else (th.tanh(pre) if act == 2 else pre)
+    dx = th.einsum("gmn,gnk->gmk", gz.double(), w.double())
+    ref = dx * ((y > 0).double() if act == 1 else ((1 - y.double() ** 2) if act == 2 else 1.0))
+    if G == 0:
+        dz, ref = hip_ops.linear_bwd_input(gz[0], w[0], y[0], act), ref[0]
+    else:
+        dz = hip_ops.linear_bwd_input(gz, w, y, act)
+    assert rel_err(dz.cpu().numpy(), ref.cpu().numpy(), max(1.0, float(ref.abs().max()))) < 2e-6

@@ -28,3 +28,23 @@ if __name__ == "__main__":
             two = t_us(lambda: hip_ops.bias_act_fwd_(th.bmm(x, w.transpose(1, 2)), b, 1))
         one = t_us(lambda: hip_ops.linear_act_fwd(x, w, b, 1))
         print(f"G={g} M={m} N={n} K={k}: GEMM + epilogue {two:6.2f} us   fused MFMA kernel {one:6.2f} us", flush=True)
+    print("input gradient + activation / bias gradient of the layer below:")
+    for (g, m, n, k) in [(0, 256, 256, 256), (2, 256, 256, 256), (0, 256, 4, 256), (0, 256, 300, 400), (2, 256, 300, 400), (0, 256, 2, 300)]:
+        gg = max(g, 1)
+        gz, w = th.randn(gg, m, n, device="cuda"), th.randn(gg, n, k, device="cuda")
+        y, gb = th.relu(th.randn(gg, m, k, device="cuda")), th.empty(gg, k, device="cuda")
+        if g == 0:
+            gz, w, y, gb = gz[0], w[0], y[0], gb[0]
+
+        def two(bias_grad):
+            dx = th.bmm(gz, w) if g else th.mm(gz, w)
+            out = th.empty_like(dx)
+            hip_ops.bias_act_bwd(dx, y, 1, out, gb if bias_grad else None)
+
+        def fused_plus_colsum():
+            dz = hip_ops.linear_bwd_input(gz, w, y, 1)
+            hip_ops.bias_act_bwd(dz, None, 0, dz, gb)
+
+        print(f"G={g} M={m} N={n} K={k}: GEMM + bias_act_bwd {t_us(lambda: two(True)):6.2f} us | fused + column sums "
+              f"{t_us(fused_plus_colsum):6.2f} us || without bias gradient: {t_us(lambda: two(False)):6.2f} us | fused "
+              f"{t_us(lambda: hip_ops.linear_bwd_input(gz, w, y, 1)):6.2f} us", flush=True)
