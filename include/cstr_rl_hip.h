@@ -232,6 +232,13 @@ int cstr_linear_act_fwd_f32(const float *x, int64_t x_group_stride, int64_t ldx,
 int cstr_linear_bwd_input_f32(const float *gz, const float *w, const float *y, int act, float *dz, int64_t groups, int64_t m,
                               int64_t n, int64_t k, cstr_stream_t stream);
 
+/* Weight and bias gradient of a Linear in one launch (autograd's mm backward for the weight + the bias sum over the batch):
+ *   dw[g][n][k] = sum_m dz[g][m][n] * x[g][m][k],   db[g][n] = sum_m dz[g][m][n]   (db may be NULL)
+ * dz [groups][m][n] contiguous (gradient w.r.t. the pre-activation); x rows ldx floats apart, groups x_group_stride apart
+ * (0 = shared input); dw [groups][n][k] and db [groups][n] contiguous -- views of the gradient arena. */
+int cstr_linear_bwd_weight_f32(const float *dz, const float *x, int64_t x_group_stride, int64_t ldx, float *dw, float *db,
+                               int64_t groups, int64_t m, int64_t n, int64_t k, cstr_stream_t stream);
+
 /* Last hidden layer + scalar head of a Q network: create_mlp(..., output_dim = 1) (core/common/torch_layers.py:110-183;
  * ContinuousCritic.forward, core/common/policies.py:960-987) ends in y = act(z + b1), q = y . w2 + b2. The head is a
  * matrix-vector product, done in the epilogue of the previous GEMM: z [groups][m][k] is replaced by y IN PLACE and

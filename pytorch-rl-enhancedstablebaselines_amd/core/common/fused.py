@@ -48,40 +48,41 @@ def _linear_fwd(x: th.Tensor, weight: th.Tensor, bias: th.Tensor, act: int) -> t
 
 # Inside a chain of fused layers the gradient that travels DOWN between two Linears is dz (w.r.t. the lower layer's
 # pre-activation), not dy: the upper layer's input-gradient kernel applies the lower layer's activation gradient while the
-# tile is still in registers (cstr_linear_bwd_input_f32) and adds the lower bias gradient's column sums, so the lower
-# layer's own backward has no element-wise launch left. `below` = (activation, bias-gradient view | None) of the fused
-# layer whose OUTPUT this layer's input is; `grad_is_dz` marks a layer whose consumer does that for it. Both are set by
-# the chain builders below (FastMLP, FastTwinCritic, FastSacActor) -- the tensors in between are private to the chain.
+# tile is still in registers (cstr_linear_bwd_input_f32), so the lower layer's backward is ONE more launch: dW and db
+# together (cstr_linear_bwd_weight_f32). `below` = (activation, None) of the fused layer whose OUTPUT this layer's input is;
+# `grad_is_dz` marks a layer whose consumer does that for it. Both are set by the chain builders below (FastMLP,
+# FastTwinCritic, FastSacActor) -- the tensors in between are private to the chain.
 def _input_grad(gz: th.Tensor, weight: th.Tensor, x: th.Tensor, below) -> th.Tensor:
     """d(loss)/d(input) of a Linear given gz = d(loss)/d(pre-activation); with `below`, d(loss)/d(lower pre-activation)."""
     if below is None or not USE_FUSED_LINEAR:
         dx = th.bmm(gz, weight) if gz.dim() == 3 else th.mm(gz, weight)
-        if below is not None:  # unfused arithmetic of the same contract
-            act, bgrad = below
+        if below is not None and below[0] != ACT_NONE:  # unfused arithmetic of the same contract
             out = th.empty_like(dx)
-            hip_ops.bias_act_bwd(dx, x, act, out, bgrad)
+            hip_ops.bias_act_bwd(dx, x, below[0], out, None)
             return out
         return dx
-    act, bgrad = below
-    dz = hip_ops.linear_bwd_input(gz, weight, x, act)
-    if bgrad is not None:
-        hip_ops.bias_act_bwd(dz, None, ACT_NONE, dz, bgrad)  # the lower layer's bias gradient: column sums of dz
-    return dz
+    return hip_ops.linear_bwd_input(gz, weight, x, below[0])
 
 
 def _own_grad(ctx, gy: th.Tensor, y: th.Tensor) -> th.Tensor:
     """gz of this layer from what arrived: already dz when the consumer is a fused layer, otherwise dy -> dz here."""
     gy = gy.contiguous()
-    if ctx.grad_is_dz:
+    if ctx.grad_is_dz or ctx.act == ACT_NONE:
         return gy
-    gbias = ctx.bgrad if ctx.train_params else None
-    if ctx.act != ACT_NONE:
-        gz = th.empty_like(gy)
-        hip_ops.bias_act_bwd(gy, y, ctx.act, gz, gbias)
-        return gz
-    if gbias is not None:
-        hip_ops.bias_act_bwd(gy, None, ACT_NONE, gy, gbias)
-    return gy
+    gz = th.empty_like(gy)
+    hip_ops.bias_act_bwd(gy, y, ctx.act, gz, None)
+    return gz
+
+
+def _param_grads(ctx, gz: th.Tensor, x: th.Tensor) -> None:
+    """dW = gz^T x and db = column sums of gz, written into the gradient arena views."""
+    if not ctx.train_params:
+        return
+    if USE_FUSED_LINEAR:
+        hip_ops.linear_bwd_weight(gz, x, ctx.wgrad, ctx.bgrad)  # one launch for both
+        return
+    th.bmm(gz.transpose(1, 2), x, out=ctx.wgrad) if gz.dim() == 3 else th.mm(gz.t(), x, out=ctx.wgrad)
+    hip_ops.bias_act_bwd(gz, None, ACT_NONE, gz, ctx.bgrad)
 
 
 class _LinearFn(th.autograd.Function):
@@ -97,8 +98,7 @@ class _LinearFn(th.autograd.Function):
     def backward(ctx, gy):
         x, weight, y = ctx.saved_tensors
         gz = _own_grad(ctx, gy, y)
-        if ctx.train_params:
-            th.mm(gz.t(), x, out=ctx.wgrad)  # dW lands in the flat gradient arena
+        _param_grads(ctx, gz, x)  # dW / db land in the flat gradient arena
         dx = _input_grad(gz, weight, x, ctx.below) if ctx.needs_input_grad[0] else None
         return dx, None, None, None, None, None, None
 
@@ -144,8 +144,7 @@ class FastMLP:
 
     def tail_below(self, train_params: bool):
         """what a fused consumer of this MLP's output needs to run the last layer's activation / bias gradient itself"""
-        lin, act = self.layers[-1]
-        return (act, lin.bias.grad if train_params else None)
+        return (self.layers[-1][1], None)
 
     def __call__(self, x: th.Tensor, train_params: bool = True, out_grad_is_dz: bool = False) -> th.Tensor:
         """`out_grad_is_dz`: the consumer is a fused layer built with `below=self.tail_below(...)` (see _input_grad)."""
@@ -156,7 +155,7 @@ class FastMLP:
         for i, (lin, act) in enumerate(plain):
             inner = scalar_head or i < len(plain) - 1 or out_grad_is_dz
             x = linear(x, lin.weight, lin.bias, act, train_params, below, grad_is_dz=inner)
-            below = (act, lin.bias.grad if train_params else None)
+            below = (act, None)
         if scalar_head:
             (l1, act), (l2, _) = layers[-2:]
             grads = (l1.weight.grad, l1.bias.grad, l2.weight.grad, l2.bias.grad) if train_params else None
@@ -221,8 +220,7 @@ class _StackedLinearFn(th.autograd.Function):
     def backward(ctx, gy):
         x, weight, y = ctx.saved_tensors
         gz = _own_grad(ctx, gy, y)
-        if ctx.train_params:
-            th.bmm(gz.transpose(1, 2), x, out=ctx.wgrad)
+        _param_grads(ctx, gz, x)
         dx = _input_grad(gz, weight, x, ctx.below) if ctx.needs_input_grad[0] else None
         return (dx,) + (None,) * (8 + ctx.n_owners)
 
@@ -447,7 +445,7 @@ class FastTwinCritic:
         for li, (w, wg, b, bg) in enumerate(plain):
             inner = scalar_head or li < len(plain) - 1  # its consumer is a fused layer that takes over the activation gradient
             h = stacked_linear(h, w[:g], b[:g], cut(wg), cut(bg), self.acts[li], train_params, self.owners[li][:g], below, inner)
-            below = (self.acts[li], cut(bg) if train_params else None)
+            below = (self.acts[li], None)
         if scalar_head:
             (w1, wg1, b1, bg1), (w2, wg2, b2, bg2) = stack[-2:]
             grads = (cut(wg1), cut(bg1), cut(wg2), cut(bg2)) if train_params else None

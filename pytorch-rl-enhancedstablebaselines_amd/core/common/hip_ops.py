@@ -368,6 +368,29 @@ def linear_bwd_input(gz, weight, y, act: int):
     return dz
 
 
+def linear_bwd_weight(dz, x, dw, db=None):
+    """dw = dz^T @ x and (optionally) db = column sums of dz in one launch. dz [M, N] / [G, M, N] contiguous; x [M, K] /
+    [G, M, K] with unit inner stride (rows / groups may be strided, stride-0 groups share the input); dw, db: contiguous
+    views of the gradient arena."""
+    g, m, n = _gmn(dz)
+    k = x.shape[-1]
+    _f32c(dz, "dz"), _f32c(dw, "dw")
+    if x.dim() == 2:
+        gs, ldx = 0, x.stride(0)
+    else:
+        gs, ldx = x.stride(0), x.stride(1)
+    if not (x.is_cuda and x.dtype == th.float32 and x.stride(-1) == 1 and x.shape[-2] == m):
+        raise ValueError("x: needs a float32 device tensor with unit inner stride and as many rows as dz")
+    if m == 1:
+        ldx = max(ldx, k)
+    if dw.numel() != g * n * k:
+        raise ValueError(f"dw has {dw.numel()} elements, expected {g * n * k}")
+    if db is not None and _f32c(db, "db").numel() != g * n:
+        raise ValueError(f"db has {db.numel()} elements, expected {g * n}")
+    check(nv.lib().cstr_linear_bwd_weight_f32(ptr(dz), ptr(x), C.c_int64(gs), C.c_int64(ldx), ptr(dw), ptr(db), C.c_int64(g),
+                                              C.c_int64(m), C.c_int64(n), C.c_int64(k), stream_ptr()), "cstr_linear_bwd_weight_f32")
+
+
 def target_smooth(action, noise, rng_ctl, sigma: float, clip: float, out):
     """out = clamp(action + clamp(noise, -clip, clip), -1, 1); noise given ([B, A], already scaled) or drawn (rng_ctl)."""
     b, a = action.shape

@@ -269,6 +269,79 @@ __global__ __launch_bounds__(64 * WAVES) void linear_bwd_input_kernel(const floa
     }
 }
 
+// Weight + bias gradient of a Linear in one launch:
+//   dW[n][k] = sum_m dz[m][n] * x[m][k],   db[n] = sum_m dz[m][n]
+// (the rocBLAS dW GEMM + the column-sum launch). The reduction runs over the BATCH: one workgroup per 16 x 16 tile of dW,
+// WAVES waves split the rows m; A = dz^T and B = x are both read as 64-byte row segments (lane r takes column n0 + r /
+// k0 + r of row 16c + 4h + e). The workgroups of the first k strip also add up the dz values they load anyway: db needs no
+// extra pass and, being reduced inside one workgroup in a fixed order, stays deterministic.
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void linear_bwd_weight_kernel(const float *__restrict__ dz, const float *__restrict__ x,
+                                                                       const int64_t x_group_stride, const int ldx,
+                                                                       float *__restrict__ dw, float *__restrict__ db, const int M,
+                                                                       const int N, const int K)
+{
+    __shared__ f32x4 part[WAVES > 1 ? WAVES - 1 : 1][64];
+    __shared__ float colpart[WAVES][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, h = lane >> 4;
+    const int k0 = blockIdx.x * 16, n0 = blockIdx.y * 16;
+    const int64_t g = blockIdx.z;
+    dz += g * (int64_t)M * N;
+    x += g * x_group_stride;
+    const bool n_ok = n0 + r < N, k_ok = k0 + r < K;
+    const bool want_db = db != nullptr && blockIdx.x == 0;
+    f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
+    float colsum = 0.0f;
+    constexpr int UNROLL = 4;
+    for (int c0 = 16 * wave; c0 < M; c0 += 16 * WAVES * UNROLL) {
+        float4 a[UNROLL], b[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const int m = c0 + 16 * WAVES * u + 4 * h;
+            const float *dr = dz + (int64_t)m * N + n0 + r;
+            const float *xr = x + (int64_t)m * ldx + k0 + r;
+            a[u].x = (n_ok && m < M) ? dr[0] : 0.0f;
+            a[u].y = (n_ok && m + 1 < M) ? dr[N] : 0.0f;
+            a[u].z = (n_ok && m + 2 < M) ? dr[2 * (int64_t)N] : 0.0f;
+            a[u].w = (n_ok && m + 3 < M) ? dr[3 * (int64_t)N] : 0.0f;
+            b[u].x = (k_ok && m < M) ? xr[0] : 0.0f;
+            b[u].y = (k_ok && m + 1 < M) ? xr[ldx] : 0.0f;
+            b[u].z = (k_ok && m + 2 < M) ? xr[2 * (int64_t)ldx] : 0.0f;
+            b[u].w = (k_ok && m + 3 < M) ? xr[3 * (int64_t)ldx] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].x, b[u].x, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].y, b[u].y, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].z, b[u].z, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].w, b[u].w, acc1, 0, 0, 0);
+            colsum += (a[u].x + a[u].y) + (a[u].z + a[u].w);
+        }
+    }
+    if (want_db) colpart[wave][lane] = colsum;
+    f32x4 acc = acc0 + acc1;
+    if (WAVES > 1) {
+        if (wave > 0) part[wave - 1][lane] = acc;
+        __syncthreads();
+        if (wave > 0) return;
+#pragma unroll
+        for (int v = 0; v < WAVES - 1; ++v) acc += part[v][lane];
+    }
+    // tile of dW: column (k) = lane & 15, row (n) = 4 * (lane >> 4) + register
+    if (k_ok) {
+        float *out = dw + (g * N + n0 + 4 * h) * (int64_t)K + k0 + r;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (n0 + 4 * h + e < N) out[(int64_t)e * K] = acc[e];
+    }
+    if (want_db && lane < 16 && n_ok) {
+        float sum = 0.0f;
+#pragma unroll
+        for (int v = 0; v < WAVES; ++v) sum += (colpart[v][lane] + colpart[v][lane + 16]) + (colpart[v][lane + 32] + colpart[v][lane + 48]);
+        db[g * N + n0 + lane] = sum;
+    }
+}
+
 // ---- last hidden layer + scalar head of a Q network ------------------------------------------------------------
 // create_mlp(..., output_dim = 1) ends in  y = act(z + b1);  q = y . w2 + b2  (core/common/torch_layers.py:110-183,
 // ContinuousCritic: core/common/policies.py:960-987). The head is a matrix-VECTOR product (n = 1), which rocBLAS runs
@@ -861,5 +934,17 @@ extern "C" int cstr_linear_bwd_input_f32(const float *gz, const float *w, const 
     else { if (vec) LBI_ACT(true, 1); else LBI_ACT(false, 1); }
 #undef LBI_ACT
 #undef LBI
+    return (int)hipGetLastError();
+}
+
+extern "C" int cstr_linear_bwd_weight_f32(const float *dz, const float *x, int64_t x_group_stride, int64_t ldx, float *dw, float *db,
+                                          int64_t groups, int64_t m, int64_t n, int64_t k, cstr_stream_t stream)
+{
+    if (!dz || !x || !dw || groups <= 0 || m <= 0 || n <= 0 || k <= 0 || ldx < k || x_group_stride < 0) return CSTR_E_BADARG;
+    if (m > 0x7fffff || n > 0x7fffff || k > 0x7fffff || groups > 65535 || (n + 15) / 16 > 65535) return CSTR_E_UNSUPPORTED;
+    const dim3 grid((unsigned)((k + 15) / 16), (unsigned)((n + 15) / 16), (unsigned)groups);
+    hipStream_t s = (hipStream_t)stream;
+    if (m > 32) linear_bwd_weight_kernel<4><<<grid, 256, 0, s>>>(dz, x, x_group_stride, (int)ldx, dw, db, (int)m, (int)n, (int)k);
+    else linear_bwd_weight_kernel<1><<<grid, 64, 0, s>>>(dz, x, x_group_stride, (int)ldx, dw, db, (int)m, (int)n, (int)k);
     return (int)hipGetLastError();
 }

@@ -381,3 +381,35 @@ def test_fused_linear_input_gradient_kernel(ops, G, M, N, K, act):
     else:
         dz = hip_ops.linear_bwd_input(gz, w, y, act)
     assert rel_err(dz.cpu().numpy(), ref.cpu().numpy(), max(1.0, float(ref.abs().max()))) < 2e-6
+
+
+@pytest.mark.parametrize("G,M,N,K", [(0, 256, 256, 256), (2, 256, 256, 6), (0, 256, 256, 4), (2, 256, 256, 256), (0, 100, 300, 400),
+                                     (0, 37, 50, 30), (2, 5, 7, 9), (0, 256, 4, 256), (0, 512, 400, 10)])
+def test_fused_linear_weight_gradient_kernel(ops, G, M, N, K):
+    """cstr_linear_bwd_weight_f32: dW = dz^T x and db = column sums of dz in one launch -- against fp64; strided / shared x."""
+    from core.common import hip_ops
+
+    gen = th.Generator(device="cuda").manual_seed(M + 5 * N + 11 * K)
+    gg = max(G, 1)
+    dz = th.randn(gg, M, N, device="cuda", generator=gen)
+    wide = th.randn(gg, M, K + 3, device="cuda", generator=gen)
+    for variant in ("contiguous", "row-strided", "shared"):
+        if variant == "contiguous":
+            x = wide[:, :, :K].contiguous()
+        elif variant == "row-strided":
+            x = wide[:, :, 1:K + 1]
+        else:
+            x = wide[0, :, :K].contiguous().unsqueeze(0).expand(gg, -1, -1)
+        ref_w = th.einsum("gmn,gmk->gnk", dz.double(), x.double())
+        ref_b = dz.double().sum(1)
+        dw, db = th.full((gg, N, K), 9.0, device="cuda"), th.full((gg, N), 9.0, device="cuda")
+        if G == 0:
+            hip_ops.linear_bwd_weight(dz[0], x[0], dw[0], db[0])
+        else:
+            hip_ops.linear_bwd_weight(dz, x, dw, db)
+        scale = float(M) ** 0.5
+        assert rel_err(dw.cpu().numpy(), ref_w.cpu().numpy(), scale) < 2e-6, variant
+        assert rel_err(db.cpu().numpy(), ref_b.cpu().numpy(), scale) < 2e-6, variant
+        dw2 = th.empty_like(dw)
+        hip_ops.linear_bwd_weight(dz if G else dz[0], x if G else x[0], dw2 if G else dw2[0], None)
+        assert th.equal(dw2 if G else dw2[0], dw if G else dw[0])

@@ -48,3 +48,18 @@ if __name__ == "__main__":
         print(f"G={g} M={m} N={n} K={k}: GEMM + bias_act_bwd {t_us(lambda: two(True)):6.2f} us | fused + column sums "
               f"{t_us(fused_plus_colsum):6.2f} us || without bias gradient: {t_us(lambda: two(False)):6.2f} us | fused "
               f"{t_us(lambda: hip_ops.linear_bwd_input(gz, w, y, 1)):6.2f} us", flush=True)
+    print("weight + bias gradient:")
+    for (g, m, n, k) in [(0, 256, 256, 256), (0, 256, 256, 4), (2, 256, 256, 6), (2, 256, 256, 256), (0, 256, 300, 400), (0, 256, 400, 4)]:
+        gg = max(g, 1)
+        dzz, xx = th.randn(gg, m, n, device="cuda"), th.randn(gg, m, k, device="cuda")
+        dw, db = th.empty(gg, n, k, device="cuda"), th.empty(gg, n, device="cuda")
+        if g == 0:
+            dzz, xx, dw, db = dzz[0], xx[0], dw[0], db[0]
+
+        def two():
+            th.bmm(dzz.transpose(1, 2), xx, out=dw) if g else th.mm(dzz.t(), xx, out=dw)
+            hip_ops.bias_act_bwd(dzz, None, 0, dzz, db)
+
+        print(f"G={g} M={m} N={n} K={k}: GEMM + column sums {t_us(two):6.2f} us   fused MFMA kernel "
+              f"{t_us(lambda: hip_ops.linear_bwd_weight(dzz, xx, dw, db)):6.2f} us   (GEMM alone "
+              f"{t_us(lambda: th.bmm(dzz.transpose(1, 2), xx, out=dw) if g else th.mm(dzz.t(), xx, out=dw)):6.2f} us)", flush=True)
