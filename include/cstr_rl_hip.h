@@ -275,6 +275,13 @@ int cstr_squashed_gaussian_bwd_f32(const float *g_action, const float *g_logp, c
 int cstr_gaussian_head_fwd_f32(float *params, const float *bias, float *eps, uint64_t *rng_ctl, float *action,
                                int64_t action_stride, float *logp, int64_t batch, int act_dim, cstr_stream_t stream);
 
+/* The same head INCLUDING its Linear: params[b][j] = hidden[b] . w[j] + bias[j] (2A <= 8 dot products per row -- a matrix-
+ * vector shaped product, one wave per row) followed by the sampling above. hidden rows ldh floats apart (k and ldh multiples
+ * of 4, 16-byte aligned); w [2A][k], bias [2A]; params [B][2A] is an OUTPUT here (kept for the backward). */
+int cstr_gaussian_head_gemm_fwd_f32(const float *hidden, int64_t ldh, const float *w, const float *bias, float *params, float *eps,
+                                    uint64_t *rng_ctl, float *action, int64_t action_stride, float *logp, int64_t batch, int act_dim,
+                                    int64_t k, cstr_stream_t stream);
+
 /* Backward: g_params [B][2A] = d/d(mean | log_std_raw) from g_action (row stride ga_stride, or NULL) and g_logp ([B] or
  * NULL); g_bias [2A] = column sums over the batch (or NULL). */
 int cstr_gaussian_head_bwd_f32(const float *g_action, int64_t ga_stride, const float *g_logp, const float *action,

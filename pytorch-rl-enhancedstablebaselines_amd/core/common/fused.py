@@ -360,8 +360,10 @@ class _GaussianHeadFn(th.autograd.Function):
 
     @staticmethod
     def forward(ctx, h, w, b, wg, bg, eps, rng_ctl, xbuf, train_params: bool, want_logp: bool, below, *owners):
-        params = th.mm(h, w.t())
-        n, a = params.shape[0], params.shape[1] // 2
+        gemm_inside = (USE_FUSED_LINEAR and h.shape[1] % 4 == 0 and h.stride(1) == 1 and h.stride(0) % 4 == 0
+                       and h.data_ptr() % 16 == 0 and w.is_contiguous())
+        n, a = h.shape[0], w.shape[0] // 2
+        params = th.empty(n, 2 * a, dtype=h.dtype, device=h.device) if gemm_inside else th.mm(h, w.t())
         # xbuf: a critic input [B, D + A] whose LAST A columns receive the action (no torch.cat); the whole buffer is the
         # output then, so the critic's input gradient comes back as one tensor and its action columns are read in place
         action = xbuf[:, xbuf.shape[1] - a:] if xbuf is not None else th.empty(n, a, dtype=params.dtype, device=params.device)
@@ -370,7 +372,10 @@ class _GaussianHeadFn(th.autograd.Function):
             eps = th.empty(n, a, dtype=params.dtype, device=params.device)
         else:
             rng_ctl = None
-        hip_ops.gaussian_head_fwd_(params, b, eps, rng_ctl, action, logp)
+        if gemm_inside:  # the 2A-output head Linear is 2A dot products per row: done inside the sampling kernel
+            hip_ops.gaussian_head_gemm_fwd(h, w, b, params, eps, rng_ctl, action, logp)
+        else:
+            hip_ops.gaussian_head_fwd_(params, b, eps, rng_ctl, action, logp)
         ctx.train_params, ctx.wg, ctx.bg, ctx.n_owners, ctx.below = train_params, wg, bg, len(owners), below
         ctx.save_for_backward(h, w, params, eps)
         ctx.action, ctx.a = action.detach(), a

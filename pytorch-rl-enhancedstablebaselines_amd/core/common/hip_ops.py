@@ -314,6 +314,22 @@ def gaussian_head_fwd_(params, bias, eps, rng_ctl, action, logp):
                                               C.c_int64(b), C.c_int(a), stream_ptr()), "cstr_gaussian_head_fwd_f32")
 
 
+def gaussian_head_gemm_fwd(hidden, weight, bias, params, eps, rng_ctl, action, logp):
+    """gaussian_head_fwd_ with the head's Linear inside: params [B, 2A] = hidden @ weight^T + bias is an OUTPUT."""
+    b, k = hidden.shape
+    a2 = weight.shape[0]
+    a = a2 // 2
+    if not (hidden.is_cuda and hidden.dtype == th.float32 and hidden.stride(1) == 1):
+        raise ValueError("hidden: needs a float32 device matrix with unit column stride")
+    _chk(weight, "weight", (a2, k), th.float32), _chk(bias, "bias", (a2,), th.float32)
+    _chk(params, "params", (b, a2), th.float32), _chk(eps, "eps", (b, a), th.float32)
+    _opt(rng_ctl, "rng_ctl", (nv.RNG_CTL_WORDS,), th.int64), _opt(logp, "logp", (b,), th.float32)
+    stride = _rows(action, "action", b, a)
+    check(nv.lib().cstr_gaussian_head_gemm_fwd_f32(ptr(hidden), C.c_int64(hidden.stride(0)), ptr(weight), ptr(bias), ptr(params), ptr(eps),
+                                                   ptr(rng_ctl), ptr(action), C.c_int64(stride), ptr(logp), C.c_int64(b), C.c_int(a),
+                                                   C.c_int64(k), stream_ptr()), "cstr_gaussian_head_gemm_fwd_f32")
+
+
 def gaussian_head_bwd(g_action, g_logp, action, params, eps, g_params, g_bias):
     b, a2 = params.shape
     a = a2 // 2

@@ -596,6 +596,81 @@ __global__ __launch_bounds__(64) void target_smooth_kernel(const float *__restri
         rng_ctl[1] = base + (uint64_t)batch;
 }
 
+// The same head INCLUDING its GEMM: the merged (mu | log_std) Linear has 2A <= 8 outputs, i.e. it is 2A dot products per
+// row, not a matrix-matrix product. One wave per row: 16-byte loads of the latent row and of the 2A weight rows, xor-shuffle
+// reductions, then the sampling arithmetic of gaussian_head_fwd_kernel on the reduced values (computed redundantly by every
+// lane, stored by lane 0). params [B][2A] is written for the backward.
+__global__ __launch_bounds__(1024) void gaussian_head_gemm_fwd_kernel(const float *__restrict__ hid, const int ldh,
+                                                                     const float *__restrict__ w, const float *__restrict__ bias,
+                                                                     float *__restrict__ params, float *__restrict__ eps,
+                                                                     uint64_t *__restrict__ rng_ctl, float *__restrict__ action,
+                                                                     const int64_t action_stride, float *__restrict__ logp,
+                                                                     const int64_t batch, const int act_dim, const int K)
+{
+    const float half_log_2pi = 0.91893853320467274178f;
+    const uint64_t seed = rng_ctl ? rng_ctl[0] : 0ull, base = rng_ctl ? rng_ctl[1] : 0ull;
+    const int lane = threadIdx.x & 63;
+    const int64_t b = blockIdx.x * (int64_t)(blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (b < batch) {  // (no early return: every wave reaches the ticket barrier below)
+        const float *hr = hid + b * ldh;
+        float p[2 * CSTR_MAX_HEAD_ACT];
+#pragma unroll
+        for (int j = 0; j < 2 * CSTR_MAX_HEAD_ACT; ++j) p[j] = 0.0f;
+        for (int c = lane * 4; c < K; c += 256) {
+            const float4 hv = *reinterpret_cast<const float4 *>(hr + c);
+#pragma unroll
+            for (int j = 0; j < 2 * CSTR_MAX_HEAD_ACT; ++j) {
+                if (j >= 2 * act_dim) break;
+                const float4 wv = *reinterpret_cast<const float4 *>(w + (int64_t)j * K + c);
+                p[j] += (hv.x * wv.x + hv.y * wv.y) + (hv.z * wv.z + hv.w * wv.w);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 2 * CSTR_MAX_HEAD_ACT; ++j) {
+            if (j >= 2 * act_dim) break;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) p[j] += __shfl_xor(p[j], o, 64);
+            p[j] += bias[j];
+        }
+        float lp = 0.0f, corr = 0.0f;
+        for (int j0 = 0; j0 < act_dim; j0 += 2) {
+            float e[2] = {0.0f, 0.0f};
+            if (rng_ctl) {
+                const uint64_t ctr = base + (uint64_t)b;
+                uint32_t r[4];
+                philox4x32_10((uint32_t)ctr, (uint32_t)(ctr >> 32), (uint32_t)(j0 >> 1), 0u, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+                box_muller(r[0], r[1], e[0], e[1]);
+            }
+            for (int jj = 0; jj < 2 && j0 + jj < act_dim; ++jj) {
+                const int j = j0 + jj;
+                if (!rng_ctl) e[jj] = eps[b * act_dim + j];
+                float mu = 0.0f, raw = 0.0f;
+#pragma unroll
+                for (int q = 0; q < 2 * CSTR_MAX_HEAD_ACT; ++q) {  // selects with static register indices
+                    if (q == j) mu = p[q];
+                    if (q == act_dim + j) raw = p[q];
+                }
+                const float ls = fminf(fmaxf(raw, LOG_STD_MIN), LOG_STD_MAX);
+                const float sd = expf(ls);
+                const float u = mu + sd * e[jj];
+                const float a = tanhf(u);
+                const float d = u - mu, var = sd * sd;
+                lp += -(d * d) / (2.0f * var) - logf(sd) - half_log_2pi;
+                corr += logf(1.0f - a * a + 1e-6f);
+                if (lane == 0) {
+                    if (rng_ctl) eps[b * act_dim + j] = e[jj];
+                    params[b * 2 * act_dim + j] = mu;
+                    params[b * 2 * act_dim + act_dim + j] = raw;
+                    action[b * action_stride + j] = a;
+                }
+            }
+        }
+        if (logp && lane == 0) logp[b] = lp - corr;
+    }
+    if (rng_ctl && last_block_ticket(reinterpret_cast<unsigned long long *>(rng_ctl + 2)) && threadIdx.x == 0)
+        rng_ctl[1] = base + (uint64_t)batch;
+}
+
 // Backward (same algebra as squashed_gaussian_bwd_kernel) + the merged head's bias gradient (column sums over the batch).
 // One workgroup: the batch is a few hundred rows.
 __global__ __launch_bounds__(256) void gaussian_head_bwd_kernel(const float *__restrict__ g_action, const int64_t ga_stride,
@@ -946,5 +1021,20 @@ extern "C" int cstr_linear_bwd_weight_f32(const float *dz, const float *x, int64
     hipStream_t s = (hipStream_t)stream;
     if (m > 32) linear_bwd_weight_kernel<4><<<grid, 256, 0, s>>>(dz, x, x_group_stride, (int)ldx, dw, db, (int)m, (int)n, (int)k);
     else linear_bwd_weight_kernel<1><<<grid, 64, 0, s>>>(dz, x, x_group_stride, (int)ldx, dw, db, (int)m, (int)n, (int)k);
+    return (int)hipGetLastError();
+}
+
+extern "C" int cstr_gaussian_head_gemm_fwd_f32(const float *hidden, int64_t ldh, const float *w, const float *bias, float *params,
+                                               float *eps, uint64_t *rng_ctl, float *action, int64_t action_stride, float *logp,
+                                               int64_t batch, int act_dim, int64_t k, cstr_stream_t stream)
+{
+    if (!hidden || !w || !bias || !params || !eps || !action || batch <= 0 || act_dim <= 0 || k <= 0 || ldh < k || action_stride < act_dim)
+        return CSTR_E_BADARG;
+    if (act_dim > CSTR_MAX_HEAD_ACT || (k & 3) || (ldh & 3) || !aligned16(hidden) || !aligned16(w) || k > 0x7fffff) return CSTR_E_UNSUPPORTED;
+    // 16 rows (waves) per workgroup: few workgroups = few tickets on the RNG control word (they serialise on one address)
+    const int64_t g = (batch + 15) / 16;
+    if (g > 0x7fffffff) return CSTR_E_UNSUPPORTED;
+    gaussian_head_gemm_fwd_kernel<<<(unsigned)g, batch >= 16 ? 1024 : 64 * (int)batch, 0, (hipStream_t)stream>>>(hidden, (int)ldh, w, bias, params, eps, rng_ctl, action,
+                                                                                action_stride, logp, batch, act_dim, (int)k);
     return (int)hipGetLastError();
 }

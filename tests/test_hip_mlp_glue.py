@@ -413,3 +413,30 @@ def test_fused_linear_weight_gradient_kernel(ops, G, M, N, K):
         dw2 = th.empty_like(dw)
         hip_ops.linear_bwd_weight(dz if G else dz[0], x if G else x[0], dw2 if G else dw2[0], None)
         assert th.equal(dw2 if G else dw2[0], dw if G else dw[0])
+
+
+@pytest.mark.parametrize("B,A,K", [(256, 2, 256), (4096, 2, 256), (33, 4, 300), (1, 1, 64)])
+def test_gaussian_head_with_its_linear_inside(ops, B, A, K):
+    """cstr_gaussian_head_gemm_fwd_f32 == head GEMM + cstr_gaussian_head_fwd_f32 (dot-product order aside)."""
+    from core.common import hip_ops
+
+    g = th.Generator(device="cuda").manual_seed(B + K)
+    wide = th.randn(B, K + 4, device="cuda", generator=g)
+    h = wide[:, :K]  # row-strided, 16-byte aligned rows
+    w, bias = th.randn(2 * A, K, device="cuda", generator=g) / K ** 0.5, th.randn(2 * A, device="cuda", generator=g) * 0.1
+    eps = th.randn(B, A, device="cuda", generator=g)
+    ref_p = th.mm(h, w.t())
+    ref_a, ref_lp = th.empty(B, A, device="cuda"), th.empty(B, device="cuda")
+    hip_ops.gaussian_head_fwd_(ref_p, bias, eps, None, ref_a, ref_lp)
+    p, x, lp = th.empty(B, 2 * A, device="cuda"), th.full((B, 3 + A), 5.0, device="cuda"), th.empty(B, device="cuda")
+    hip_ops.gaussian_head_gemm_fwd(h, w, bias, p, eps, None, x[:, 3:], lp)
+    assert rel_err(p.cpu().numpy(), ref_p.cpu().numpy(), 1.0) < 2e-6
+    assert rel_err(x[:, 3:].cpu().numpy(), ref_a.cpu().numpy(), 1.0) < 5e-6 and float(x[:, :3].min()) == 5.0
+    assert rel_err(lp.cpu().numpy(), ref_lp.cpu().numpy(), 1.0) < 1e-4  # log(1 - a^2 + 1e-6) amplifies near saturation
+    # in-kernel noise: same stream as the GEMM-less kernel for the same (seed, offset)
+    c1, c2 = hip_ops.new_rng_ctl(77, "cuda"), hip_ops.new_rng_ctl(77, "cuda")
+    e1, e2, a1, a2 = (th.empty(B, A, device="cuda") for _ in range(4))
+    hip_ops.gaussian_head_gemm_fwd(h, w, bias, p, e1, c1, a1, None)
+    hip_ops.gaussian_head_fwd_(th.mm(h, w.t()), bias, e2, c2, a2, None)
+    assert th.equal(e1, e2) and th.equal(c1, c2) and int(c1[1]) == B
+    assert rel_err(a1.cpu().numpy(), a2.cpu().numpy(), 1.0) < 5e-6
