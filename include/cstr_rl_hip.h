@@ -202,6 +202,15 @@ int cstr_adam_f32(float *param, const float *grad, float *exp_avg, float *exp_av
                   const double *lr, double beta1, double beta2, double eps, float grad_scale, int64_t n,
                   cstr_stream_t stream);
 
+/* Several Adam steps in ONE launch (SAC: the entropy coefficient -- one parameter -- next to the critic, core/sac/sac.py:240-243
+ * and :266-268): each segment is a cstr_adam_f32 call's argument list. */
+#define CSTR_MAX_ADAM_SEGS 4
+typedef struct {
+    float *param; const float *grad; float *exp_avg; float *exp_avg_sq; int64_t *adam_ctl; const double *lr;
+    double beta1, beta2, eps; float grad_scale; int64_t n;
+} cstr_adam_seg_t;
+int cstr_adam_multi_f32(const cstr_adam_seg_t *segs, int n_segs, cstr_stream_t stream);
+
 /* ---- learner glue around the PyTorch-ROCm GEMMs (csrc/cstr_mlp.hip) --------------------------------------------- */
 
 #define CSTR_ACT_NONE 0
@@ -228,9 +237,10 @@ int cstr_linear_act_fwd_f32(const float *x, int64_t x_group_stride, int64_t ldx,
  * threshold/tanh backward of core/common/torch_layers.py:110-183's Linear -> ReLU -> Linear):
  *   dz[g][m][k] = (sum_n gz[g][m][n] * w[g][n][k]) * act'(y[g][m][k])
  * gz: gradient w.r.t. this layer's pre-activation [groups][m][n]; w [groups][n][k]; y [groups][m][k]: the lower layer's
- * OUTPUT (this layer's input), NULL with act == NONE; all contiguous. */
-int cstr_linear_bwd_input_f32(const float *gz, const float *w, const float *y, int act, float *dz, int64_t groups, int64_t m,
-                              int64_t n, int64_t k, cstr_stream_t stream);
+ * OUTPUT (this layer's input), NULL with act == NONE; all contiguous. sum_groups != 0: the groups share ONE input
+ * (stacked critics): dz [m][k] = sum_g gz[g] @ w[g] (and y [m][k]) -- the batched product and the sum over groups at once. */
+int cstr_linear_bwd_input_f32(const float *gz, const float *w, const float *y, int act, float *dz, int64_t groups, int sum_groups,
+                              int64_t m, int64_t n, int64_t k, cstr_stream_t stream);
 
 /* Weight and bias gradient of a Linear in one launch (autograd's mm backward for the weight + the bias sum over the batch):
  *   dw[g][n][k] = sum_m dz[g][m][n] * x[g][m][k],   db[g][n] = sum_m dz[g][m][n]   (db may be NULL)

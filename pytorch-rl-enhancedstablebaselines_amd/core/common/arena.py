@@ -167,6 +167,16 @@ class FlatAdam:
             hip_ops.adam(self.arena.flat, self.arena.grad, self.exp_avg, self.exp_avg_sq, self.ctl, self.lr_dev,
                          g["betas"][0], g["betas"][1], g["eps"], self.grad_scale)
 
+    def _segment(self) -> tuple:
+        g = self.param_groups[0]
+        return (self.arena.flat, self.arena.grad, self.exp_avg, self.exp_avg_sq, self.ctl, self.lr_dev, g["betas"][0], g["betas"][1],
+                g["eps"], self.grad_scale)
+
+    def step_with(self, *others: "FlatAdam") -> None:
+        """This optimiser's step and the others' in ONE launch (same arithmetic as separate step() calls)."""
+        with th.cuda.device(self.arena.device):
+            hip_ops.adam_multi([self._segment()] + [o._segment() for o in others])
+
     @property
     def step_count(self) -> int:
         return int(self.ctl[0])

@@ -209,6 +209,9 @@ class _StackedLinearFn(th.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, wgrad, bgrad, act: int, train_params: bool, below, grad_is_dz: bool, *owners):
+        ctx.shared = x.dim() == 2  # ONE input for all groups (the critics' first layer): kept 2-D so its gradient comes back
+        if ctx.shared:             # as the [M, K] sum over groups from a single launch, not as an expand + reduce
+            x = x.unsqueeze(0).expand(weight.shape[0], -1, -1)
         y = _linear_fwd(x, weight, bias, act)
         ctx.act, ctx.train_params, ctx.below, ctx.grad_is_dz = act, train_params, below, grad_is_dz
         ctx.save_for_backward(x, weight, y)
@@ -221,7 +224,14 @@ class _StackedLinearFn(th.autograd.Function):
         x, weight, y = ctx.saved_tensors
         gz = _own_grad(ctx, gy, y)
         _param_grads(ctx, gz, x)
-        dx = _input_grad(gz, weight, x, ctx.below) if ctx.needs_input_grad[0] else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            if ctx.shared and USE_FUSED_LINEAR:
+                dx = hip_ops.linear_bwd_input(gz, weight, None, ACT_NONE, sum_groups=True)
+            else:
+                dx = _input_grad(gz, weight, x, ctx.below)
+                if ctx.shared:
+                    dx = dx.sum(0)
         return (dx,) + (None,) * (8 + ctx.n_owners)
 
 
@@ -229,7 +239,7 @@ def stacked_linear(x, weight, bias, wgrad, bgrad, act: int, train_params: bool, 
     """`owners`: the nn.Parameters whose storage `weight` / `bias` alias; passing them makes the output require grad when
     only the parameters do (first layer on replay data)."""
     if not th.is_grad_enabled() or not (x.requires_grad or train_params):
-        return _linear_fwd(x, weight, bias, act)
+        return _linear_fwd(x if x.dim() == 3 else x.unsqueeze(0).expand(weight.shape[0], -1, -1), weight, bias, act)
     return _StackedLinearFn.apply(x, weight, bias, wgrad, bgrad, act, train_params, below if x.requires_grad else None, grad_is_dz,
                                   *(owners if train_params else ()))
 
@@ -439,7 +449,7 @@ class FastTwinCritic:
             nets = self.nets[:1] if only_first else self.nets
             return QOut(net(x, train_params) for net in nets)
         g = 1 if only_first else len(self.nets)
-        h = x.unsqueeze(0).expand(g, -1, -1)
+        h = x  # 2-D: shared by the g groups of the first stacked layer
         stack = self.stack
         scalar_head = len(stack) >= 2 and stack[-1][0].shape[1] == 1 and self.acts[-1] == ACT_NONE
         if train_params and g != stack[0][0].shape[0]:
@@ -452,6 +462,8 @@ class FastTwinCritic:
             h = stacked_linear(h, w[:g], b[:g], cut(wg), cut(bg), self.acts[li], train_params, self.owners[li][:g], below, inner)
             below = (self.acts[li], None)
         if scalar_head:
+            if h.dim() == 2:  # no plain layer in front: the head pair itself reads the shared input
+                h = h.unsqueeze(0).expand(g, -1, -1)
             (w1, wg1, b1, bg1), (w2, wg2, b2, bg2) = stack[-2:]
             grads = (cut(wg1), cut(bg1), cut(wg2), cut(bg2)) if train_params else None
             h = hidden_head(h, w1[:g], b1[:g], w2[:g], b2[:g], grads, self.acts[-2], train_params,

@@ -251,6 +251,20 @@ def adam(param, grad, exp_avg, exp_avg_sq, adam_ctl, lr_dev, beta1=0.9, beta2=0.
                                  C.c_int64(n), stream_ptr()), "cstr_adam_f32")
 
 
+def adam_multi(segments):
+    """Several `adam` calls in one launch; `segments` = iterable of adam()'s positional argument tuples (<= 4)."""
+    segs = list(segments)
+    arr = (nv.AdamSeg * len(segs))()
+    for i, (param, grad, exp_avg, exp_avg_sq, adam_ctl, lr_dev, beta1, beta2, eps, grad_scale) in enumerate(segs):
+        n = param.numel()
+        for t, nm in ((param, "param"), (grad, "grad"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq")):
+            _chk(t, nm, (n,), th.float32)
+        _chk(adam_ctl, "adam_ctl", (nv.ADAM_CTL_WORDS,), th.int64), _chk(lr_dev, "lr", (1,), th.float64)
+        arr[i] = nv.AdamSeg(param.data_ptr(), grad.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(), adam_ctl.data_ptr(),
+                            lr_dev.data_ptr(), beta1, beta2, eps, grad_scale, n)
+    check(nv.lib().cstr_adam_multi_f32(arr, C.c_int(len(segs)), stream_ptr()), "cstr_adam_multi_f32")
+
+
 # ---- learner glue around the GEMMs (csrc/cstr_mlp.hip) ------------------------------------------------------------
 ACT = {"none": 0, "relu": 1, "tanh": 2}
 
@@ -367,20 +381,22 @@ def linear_act_fwd(x, weight, bias, act: int, out=None):
     return y
 
 
-def linear_bwd_input(gz, weight, y, act: int):
+def linear_bwd_input(gz, weight, y, act: int, sum_groups: bool = False):
     """dz = (gz @ W) * act'(y): a Linear's input gradient fused with the activation gradient of the layer below (whose output
-    y is this layer's input). gz [M, N] / [G, M, N], weight [N, K] / [G, N, K] contiguous."""
+    y is this layer's input). gz [M, N] / [G, M, N], weight [N, K] / [G, N, K] contiguous. sum_groups: the G groups share one
+    input, the result is the [M, K] sum over groups."""
     g, m, n = _gmn(gz)
     k = weight.shape[-1]
     _f32c(gz, "gz"), _f32c(weight, "weight")
     if weight.numel() != g * n * k:
         raise ValueError(f"weight {tuple(weight.shape)} does not match gz {tuple(gz.shape)}")
-    shape = (m, k) if gz.dim() == 2 else (g, m, k)
+    shape = (m, k) if (gz.dim() == 2 or sum_groups) else (g, m, k)
     if act != 0:
         _chk(y, "y", shape, th.float32)
     dz = th.empty(shape, dtype=th.float32, device=gz.device)
     check(nv.lib().cstr_linear_bwd_input_f32(ptr(gz), ptr(weight), ptr(y if act != 0 else None), C.c_int(act), ptr(dz), C.c_int64(g),
-                                             C.c_int64(m), C.c_int64(n), C.c_int64(k), stream_ptr()), "cstr_linear_bwd_input_f32")
+                                             C.c_int(int(sum_groups)), C.c_int64(m), C.c_int64(n), C.c_int64(k), stream_ptr()),
+          "cstr_linear_bwd_input_f32")
     return dz
 
 

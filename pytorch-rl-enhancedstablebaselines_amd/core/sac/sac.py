@@ -207,8 +207,10 @@ class SAC(OffPolicyAlgorithm):
         fused.backward_q(qs, gq)  # :266-268
         self._allreduce_grads(pol.critic_arena)
         if self.ent_coef_optimizer is not None and self._ent_rides_critic:
-            self.ent_coef_optimizer.step()  # :240-243, gradient averaged by the critic's collective
-        self.critic.optimizer.step()
+            # :240-243 (gradient averaged by the critic's collective) and :266-268 in one launch
+            self.critic.optimizer.step_with(self.ent_coef_optimizer)
+        else:
+            self.critic.optimizer.step()
 
         # :273-275 (critic weights frozen)
         qs_pi = (self._fast_critic.forward_input(x_pi, train_params=False) if pb is not None

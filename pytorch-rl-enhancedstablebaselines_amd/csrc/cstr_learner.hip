@@ -58,9 +58,10 @@ __device__ __forceinline__ void adam1(float &p, float g, float &m, float &v, con
     p = p + (a.step_size_neg * m) / denom;
 }
 
-__global__ void adam_kernel(float *__restrict__ param, const float *__restrict__ grad, float *__restrict__ exp_avg,
-                            float *__restrict__ exp_avg_sq, int64_t *__restrict__ adam_ctl, const double *__restrict__ lr,
-                            const double beta1, const double beta2, const double eps, const float gscale, const int64_t n)
+__device__ __forceinline__ void adam_body(float *__restrict__ param, const float *__restrict__ grad, float *__restrict__ exp_avg,
+                                          float *__restrict__ exp_avg_sq, int64_t *__restrict__ adam_ctl,
+                                          const double *__restrict__ lr, const double beta1, const double beta2, const double eps,
+                                          const float gscale, const int64_t n)
 {
     __shared__ AdamScalars sa;
     if (threadIdx.x == 0) {
@@ -102,6 +103,23 @@ __global__ void adam_kernel(float *__restrict__ param, const float *__restrict__
     }
 }
 
+__global__ void adam_kernel(float *__restrict__ param, const float *__restrict__ grad, float *__restrict__ exp_avg,
+                            float *__restrict__ exp_avg_sq, int64_t *__restrict__ adam_ctl, const double *__restrict__ lr,
+                            const double beta1, const double beta2, const double eps, const float gscale, const int64_t n)
+{
+    adam_body(param, grad, exp_avg, exp_avg_sq, adam_ctl, lr, beta1, beta2, eps, gscale, n);
+}
+
+// Several optimisers' steps in ONE launch (e.g. SAC's entropy coefficient -- a single parameter -- next to the critic):
+// blockIdx.y selects the segment, every segment keeps its own control words, learning rate and hyper-parameters.
+struct AdamSegs { cstr_adam_seg_t s[CSTR_MAX_ADAM_SEGS]; };
+
+__global__ void adam_multi_kernel(const AdamSegs segs)
+{
+    const cstr_adam_seg_t &s = segs.s[blockIdx.y];
+    adam_body(s.param, s.grad, s.exp_avg, s.exp_avg_sq, s.adam_ctl, s.lr, s.beta1, s.beta2, s.eps, s.grad_scale, s.n);
+}
+
 }  // namespace
 
 extern "C" int cstr_td_target_min_f32(const float *q1, const float *q2, const float *logp, const float *rew, const float *done,
@@ -133,5 +151,24 @@ extern "C" int cstr_adam_f32(float *param, const float *grad, float *exp_avg, fl
     flat_launch_shape((n + 3) / 4, block, grid);
     adam_kernel<<<grid, block, 0, (hipStream_t)stream>>>(param, grad, exp_avg, exp_avg_sq, adam_ctl, lr, beta1, beta2, eps,
                                                          grad_scale, n);
+    return (int)hipGetLastError();
+}
+
+extern "C" int cstr_adam_multi_f32(const cstr_adam_seg_t *segs, int n_segs, cstr_stream_t stream)
+{
+    if (!segs || n_segs <= 0) return CSTR_E_BADARG;
+    if (n_segs > CSTR_MAX_ADAM_SEGS) return CSTR_E_UNSUPPORTED;
+    AdamSegs a;
+    int grid = 1;
+    for (int i = 0; i < n_segs; ++i) {
+        const cstr_adam_seg_t &s = segs[i];
+        if (!s.param || !s.grad || !s.exp_avg || !s.exp_avg_sq || !s.adam_ctl || !s.lr || s.n <= 0) return CSTR_E_BADARG;
+        if (!aligned16(s.param) || !aligned16(s.grad) || !aligned16(s.exp_avg) || !aligned16(s.exp_avg_sq)) return CSTR_E_BADARG;
+        int block, g;
+        flat_launch_shape((s.n + 3) / 4, block, g);
+        grid = g > grid ? g : grid;
+        a.s[i] = s;
+    }
+    adam_multi_kernel<<<dim3((unsigned)grid, (unsigned)n_segs), 256, 0, (hipStream_t)stream>>>(a);
     return (int)hipGetLastError();
 }

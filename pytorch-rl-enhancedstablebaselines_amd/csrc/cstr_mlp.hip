@@ -210,38 +210,44 @@ __global__ __launch_bounds__(64 * WAVES) void linear_act_fwd_kernel(const float 
 template <int ACT, bool VEC, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void linear_bwd_input_kernel(const float *__restrict__ gz, const float *__restrict__ w,
                                                                       const float *__restrict__ y, float *__restrict__ dz,
-                                                                      const int M, const int N, const int K)
+                                                                      const int M, const int N, const int K, const int n_sum)
 {
+    // n_sum > 0: the n_sum groups share ONE input (stacked critics on the same rows): dz[m][k] = sum_g gz[g][m] . W[g][:, k]
+    // -- the reduction simply continues over the groups, which replaces the batched GEMM + the sum over groups.
     __shared__ f32x4 part[WAVES > 1 ? WAVES - 1 : 1][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, h = lane >> 4;
     const int k0 = blockIdx.x * 16, m0 = blockIdx.y * 16, col = k0 + r;
-    const int64_t g = blockIdx.z;
-    gz += g * (int64_t)M * N;
-    w += g * (int64_t)N * K;
-    y += g * (int64_t)M * K;
-    dz += g * (int64_t)M * K;
+    const int64_t g0 = n_sum > 0 ? 0 : blockIdx.z;
+    const int n_groups = n_sum > 0 ? n_sum : 1;
+    if (n_sum <= 0) {
+        y += g0 * (int64_t)M * K;
+        dz += g0 * (int64_t)M * K;
+    }
     const bool col_ok = col < K, row_ok = m0 + r < M;
-    const float *gr = gz + (int64_t)(m0 + r) * N;
     f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
     constexpr int UNROLL = 4;
-    for (int c0 = 16 * wave; c0 < N; c0 += 16 * WAVES * UNROLL) {
-        float4 a[UNROLL], b[UNROLL];
+    for (int gi = 0; gi < n_groups; ++gi) {
+        const float *gzg = gz + (g0 + gi) * (int64_t)M * N, *wg = w + (g0 + gi) * (int64_t)N * K;
+        const float *gr = gzg + (int64_t)(m0 + r) * N;
+        for (int c0 = 16 * wave; c0 < N; c0 += 16 * WAVES * UNROLL) {
+            float4 a[UNROLL], b[UNROLL];
 #pragma unroll
-        for (int u = 0; u < UNROLL; ++u) {
-            const int n = c0 + 16 * WAVES * u + 4 * h;
-            a[u] = load_k4<VEC>(gr, n, N, row_ok);
-            const float *wn = w + (int64_t)n * K + col;
-            b[u].x = (col_ok && n < N) ? wn[0] : 0.0f;
-            b[u].y = (col_ok && n + 1 < N) ? wn[K] : 0.0f;
-            b[u].z = (col_ok && n + 2 < N) ? wn[2 * (int64_t)K] : 0.0f;
-            b[u].w = (col_ok && n + 3 < N) ? wn[3 * (int64_t)K] : 0.0f;
-        }
+            for (int u = 0; u < UNROLL; ++u) {
+                const int n = c0 + 16 * WAVES * u + 4 * h;
+                a[u] = load_k4<VEC>(gr, n, N, row_ok);
+                const float *wn = wg + (int64_t)n * K + col;
+                b[u].x = (col_ok && n < N) ? wn[0] : 0.0f;
+                b[u].y = (col_ok && n + 1 < N) ? wn[K] : 0.0f;
+                b[u].z = (col_ok && n + 2 < N) ? wn[2 * (int64_t)K] : 0.0f;
+                b[u].w = (col_ok && n + 3 < N) ? wn[3 * (int64_t)K] : 0.0f;
+            }
 #pragma unroll
-        for (int u = 0; u < UNROLL; ++u) {
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].x, b[u].x, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].y, b[u].y, acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].z, b[u].z, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].w, b[u].w, acc1, 0, 0, 0);
+            for (int u = 0; u < UNROLL; ++u) {
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].x, b[u].x, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].y, b[u].y, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].z, b[u].z, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].w, b[u].w, acc1, 0, 0, 0);
+            }
         }
     }
     f32x4 acc = acc0 + acc1;
@@ -996,14 +1002,15 @@ extern "C" int cstr_linear_act_fwd_f32(const float *x, int64_t x_group_stride, i
 }
 
 extern "C" int cstr_linear_bwd_input_f32(const float *gz, const float *w, const float *y, int act, float *dz, int64_t groups,
-                                         int64_t m, int64_t n, int64_t k, cstr_stream_t stream)
+                                         int sum_groups, int64_t m, int64_t n, int64_t k, cstr_stream_t stream)
 {
     if (!gz || !w || !dz || groups <= 0 || m <= 0 || n <= 0 || k <= 0 || (act != 0 && !y)) return CSTR_E_BADARG;
     if (act < 0 || act > 2 || m > 0x7fffff || n > 0x7fffff || k > 0x7fffff || groups > 65535 || (m + 15) / 16 > 65535) return CSTR_E_UNSUPPORTED;
-    const dim3 grid((unsigned)((k + 15) / 16), (unsigned)((m + 15) / 16), (unsigned)groups);
+    const dim3 grid((unsigned)((k + 15) / 16), (unsigned)((m + 15) / 16), (unsigned)(sum_groups ? 1 : groups));
+    const int n_sum = sum_groups ? (int)groups : 0;
     const bool vec = (n & 3) == 0 && aligned16(gz);
     hipStream_t s = (hipStream_t)stream;
-#define LBI(A, V, W) linear_bwd_input_kernel<A, V, W><<<grid, 64 * W, 0, s>>>(gz, w, y, dz, (int)m, (int)n, (int)k)
+#define LBI(A, V, W) linear_bwd_input_kernel<A, V, W><<<grid, 64 * W, 0, s>>>(gz, w, y, dz, (int)m, (int)n, (int)k, n_sum)
 #define LBI_ACT(V, W) do { if (act == 0) LBI(0, V, W); else if (act == 1) LBI(1, V, W); else LBI(2, V, W); } while (0)
     if (n > 32) { if (vec) LBI_ACT(true, 4); else LBI_ACT(false, 4); }
     else { if (vec) LBI_ACT(true, 1); else LBI_ACT(false, 1); }

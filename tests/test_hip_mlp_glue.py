@@ -381,6 +381,10 @@ def test_fused_linear_input_gradient_kernel(ops, G, M, N, K, act):
     else:
         dz = hip_ops.linear_bwd_input(gz, w, y, act)
     assert rel_err(dz.cpu().numpy(), ref.cpu().numpy(), max(1.0, float(ref.abs().max()))) < 2e-6
+    if G:  # groups sharing one input: the sum over groups in the same launch
+        tot = hip_ops.linear_bwd_input(gz, w, y[0], act, sum_groups=True)
+        ref_sum = dx.sum(0) * ((y[0] > 0).double() if act == 1 else ((1 - y[0].double() ** 2) if act == 2 else 1.0))
+        assert tuple(tot.shape) == (M, K) and rel_err(tot.cpu().numpy(), ref_sum.cpu().numpy(), max(1.0, float(ref_sum.abs().max()))) < 3e-6
 
 
 @pytest.mark.parametrize("G,M,N,K", [(0, 256, 256, 256), (2, 256, 256, 6), (0, 256, 256, 4), (2, 256, 256, 256), (0, 100, 300, 400),
