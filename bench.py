@@ -249,16 +249,23 @@ def cpu_baseline(n_envs, batch, seconds):
                 env_only_value=round(env_only, 1), ms_per_iteration=round(1e3 * dt / n, 3))
 
 
-def north_star_variant(n_envs: int, device: str, graph: bool) -> dict:
-    """BASELINE.json's north_star wording (8-dim state, batched RK4) differs from the reference (4-dim obs, forward Euler;
-    SURVEY D1/D2). The headline value is measured on the reference-true shape; this is the same loop on the north_star shape:
-    obs = [normalised | raw] (8 columns), RK4 integrator. Rank 0, one GPU, short run."""
+def north_star_variant(n_envs: int, device: str, graph: bool, obs_dim: int = 8, integrator: str = "rk4", mlp_on_rocblas: bool = False) -> dict:
+    """BASELINE.json's north_star wording differs from the reference / from what is built in two places; the headline value is
+    measured on the reference-true, fastest configuration and these are the same loop on the north_star-literal ones:
+      * 8-dim state + batched RK4 (the reference: 4-dim obs, forward Euler; SURVEY D1/D2): obs = [normalised | raw], rk4;
+      * "MLP forward/backward on PyTorch-ROCm": every GEMM left to rocBLAS (CSTR_FUSED_LINEAR=0) instead of the hand-written
+        f32-MFMA Linear kernels (DESIGN D8).
+    Rank 0, one GPU, short run."""
+    from core.common import fused
     from core.common.callbacks import NoopCallback
     from core.common.vec_env import CSTRVecEnv
     from core.sac import SAC
 
     warm, steps = 30, 150
-    env = CSTRVecEnv(n_envs, obs_dim=8, integrator="rk4", device=device)
+    fused_before = fused.USE_FUSED_LINEAR
+    if mlp_on_rocblas:
+        fused.USE_FUSED_LINEAR = False
+    env = CSTRVecEnv(n_envs, obs_dim=obs_dim, integrator=integrator, device=device)
     model = SAC("MlpPolicy", env, seed=0, device=device)
     _, cb = model._setup_learn((warm + steps) * n_envs, NoopCallback(), True, "bench", False)
     model.enable_graph_capture(graph)
@@ -270,7 +277,9 @@ def north_star_variant(n_envs: int, device: str, graph: bool) -> dict:
         model._learn_iteration(cb, None)
     th.cuda.synchronize()
     dt = time.perf_counter() - t0
-    return dict(workload=f"SAC class defaults, {n_envs} envs, obs 8 ([normalised | raw]) / act 2, rk4, batch 256", steps=steps,
+    fused.USE_FUSED_LINEAR = fused_before
+    what = f"obs {obs_dim} / act 2, {integrator}" + (", every MLP GEMM on PyTorch-ROCm (rocBLAS)" if mlp_on_rocblas else "")
+    return dict(workload=f"SAC class defaults, {n_envs} envs, {what}, batch 256", steps=steps,
                 value=round(steps * n_envs / dt, 1), unit="env-steps/s", ms_per_step=round(1e3 * dt / steps, 4))
 
 
@@ -358,7 +367,9 @@ def main():
             line["kernels"] = other_kernels(model, B)
         if world == 1 and not args.no_variant and args.algo == "sac" and (args.obs_dim, args.integrator) == (4, "euler"):
             del model, env
-            line["north_star_variant"] = north_star_variant(N, f"cuda:{local_rank}", use_graph)
+            dev = f"cuda:{local_rank}"
+            line["north_star_variant"] = north_star_variant(N, dev, use_graph)
+            line["mlp_on_pytorch_rocm_variant"] = north_star_variant(N, dev, use_graph, 4, "euler", mlp_on_rocblas=True)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(N, B, args.cpu_seconds)
             line["speedup_vs_cpu_port"] = round(value / line["cpu_baseline"]["value"], 2)

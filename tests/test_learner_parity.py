@@ -65,11 +65,17 @@ def _make_env(n=4):
     return CSTRVecEnv(n)
 
 
-@pytest.mark.parametrize("fused_path", [True, False])
+@pytest.mark.parametrize("fused_path", [True, "rocblas", False])
 @pytest.mark.parametrize("tag", ["small", "default"])
-def test_sac_train_teacher_forced(golden, tag, fused_path):
-    from core.common import legacy_rng
+def test_sac_train_teacher_forced(golden, tag, fused_path, monkeypatch):
+    """fused_path: True = the default (hand-written MFMA Linear kernels + HIP glue); "rocblas" = the same fused glue with every
+    GEMM left to PyTorch-ROCm / rocBLAS (CSTR_FUSED_LINEAR=0); False = stock-ATen evaluation of the same statements."""
+    from core.common import fused, legacy_rng
     from core.sac import SAC
+
+    if fused_path == "rocblas":
+        monkeypatch.setattr(fused, "USE_FUSED_LINEAR", False)
+        fused_path = True
 
     g = golden(f"sac_train_kat_{tag}.npz")
     gamma, tau, target_entropy, lr, B, n_steps = g["hyper"]
@@ -110,10 +116,14 @@ def test_sac_train_teacher_forced(golden, tag, fused_path):
     assert model.actor.optimizer.step_count == n_steps and model.critic.optimizer.step_count == n_steps
 
 
-@pytest.mark.parametrize("fused_path", [True, False])
-def test_td3_train_teacher_forced(golden, fused_path):
-    from core.common import legacy_rng
+@pytest.mark.parametrize("fused_path", [True, "rocblas", False])
+def test_td3_train_teacher_forced(golden, fused_path, monkeypatch):
+    from core.common import fused, legacy_rng
     from core.td3 import TD3
+
+    if fused_path == "rocblas":  # the fused glue with every GEMM left to PyTorch-ROCm / rocBLAS (CSTR_FUSED_LINEAR=0)
+        monkeypatch.setattr(fused, "USE_FUSED_LINEAR", False)
+        fused_path = True
 
     g = golden("td3_train_kat.npz")
     gamma, tau, tpn, tnc, delay, lr, B, n_steps = g["hyper"]
