@@ -306,10 +306,10 @@ int cstr_target_smooth_f32(const float *action, const float *noise, uint64_t *rn
                            int64_t out_stride, int64_t batch, int act_dim, cstr_stream_t stream);
 
 /* SAC entropy coefficient (core/sac/sac.py:230-243): ent_coef_out = exp(log_alpha); grad_out = d/dlog_alpha of
- * -mean(log_alpha * (logp + target_entropy)) = -mean(logp + target_entropy). loss_sum / ent_coef_sum (device scalars,
- * may be NULL) accumulate the values train() logs (:232, :236) without a host sync. */
+ * -mean(log_alpha * (logp + target_entropy)) = -mean(logp + target_entropy). loss_out (stored) and loss_sum /
+ * ent_coef_sum (accumulated) are device scalars, each may be NULL: the values train() logs (:232, :236), no host sync. */
 int cstr_sac_alpha_f32(const float *log_alpha, const float *logp, float target_entropy, float *grad_out, float *ent_coef_out,
-                       float *loss_sum, float *ent_coef_sum, int64_t batch, cstr_stream_t stream);
+                       float *loss_out, float *loss_sum, float *ent_coef_sum, int64_t batch, cstr_stream_t stream);
 
 /* Twin-critic loss as a backward root: loss = scale * (mse(q1, t) + mse(q2, t)) (scale 0.5: core/sac/sac.py:261;
  * scale 1: core/td3/td3.py:182, core/maddpg/maddpg.py:157); gq_k = d loss / d q_k. */

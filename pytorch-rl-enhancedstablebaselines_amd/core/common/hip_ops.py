@@ -504,13 +504,13 @@ def _vec(t, name, n):
     return t
 
 
-def sac_alpha(log_alpha, logp, target_entropy: float, grad_out, ent_coef_out, loss_sum=None, ent_coef_sum=None):
+def sac_alpha(log_alpha, logp, target_entropy: float, grad_out, ent_coef_out, loss_sum=None, ent_coef_sum=None, loss_out=None):
     b = logp.numel()
     _vec(logp, "logp", b)
     for t, nm in ((log_alpha, "log_alpha"), (grad_out, "grad_out"), (ent_coef_out, "ent_coef_out")):
         _vec(t, nm, 1)
     check(nv.lib().cstr_sac_alpha_f32(ptr(log_alpha), ptr(logp), C.c_float(target_entropy), ptr(grad_out), ptr(ent_coef_out),
-                                      ptr(loss_sum), ptr(ent_coef_sum), C.c_int64(b), stream_ptr()), "cstr_sac_alpha_f32")
+                                      ptr(loss_out), ptr(loss_sum), ptr(ent_coef_sum), C.c_int64(b), stream_ptr()), "cstr_sac_alpha_f32")
 
 
 def twin_q_loss(q1, q2, target, scale: float, gq1, gq2, loss_out=None, loss_sum=None):

@@ -138,7 +138,10 @@ class SAC(OffPolicyAlgorithm):
         self._update_learning_rate(optimizers)  # :208
 
     def _train_device_only(self, gradient_steps: int, batch_size: int) -> None:
-        self._loss_sum_buf.zero_()
+        # one gradient step per train() call (the default): the loss kernels STORE the logged values, no zero-fill launch
+        self._single_step = gradient_steps == 1 and self.fused_learner and self.ent_coef_optimizer is not None
+        if not self._single_step:
+            self._loss_sum_buf.zero_()
         for gradient_step in range(gradient_steps):
             self._gradient_step(batch_size, gradient_step)
 
@@ -161,6 +164,9 @@ class SAC(OffPolicyAlgorithm):
         """The same statements as `_gradient_step_aten` (sac.py:215-287), evaluated on the fused path: losses are
         backward roots whose kernels emit d(loss)/d(inputs) directly; parameter gradients land in the arenas."""
         s, pol = self._loss_sums, self.policy
+        single = getattr(self, "_single_step", False)
+        acc = (lambda k: None) if single else (lambda k: s[k])  # accumulate into the sums ...
+        sto = (lambda k, other: s[k]) if single else (lambda k, other: other)  # ... or store straight into them
         pb = None
         if self._use_packed_batch():
             pb = self.replay_buffer.sample_packed_into(self._packed_batch(batch_size))  # :215 + the critics' cat([obs, act])
@@ -183,11 +189,12 @@ class SAC(OffPolicyAlgorithm):
             # ent_coef = exp(log_ent_coef) BEFORE the update (:230); the updated value is first used by the next gradient
             # step, so the optimiser step itself may wait for the critic's all-reduce (one collective instead of two)
             hip_ops.sac_alpha(self.log_ent_coef.detach(), log_prob.detach(), self.target_entropy, self._ent_arena.grad[0:1],
-                              self._ent_coef_buf, s["ent_coef_loss"], s["ent_coef"])
+                              s["ent_coef"] if single else self._ent_coef_buf, acc("ent_coef_loss"), acc("ent_coef"),
+                              loss_out=s["ent_coef_loss"] if single else None)
             if not self._ent_rides_critic:
                 self._allreduce_grads(self._ent_arena)
                 self.ent_coef_optimizer.step()
-            ent_coef = self._ent_coef_buf
+            ent_coef = s["ent_coef"] if single else self._ent_coef_buf
         else:
             ent_coef = self.ent_coef_tensor.reshape(1)
             s["ent_coef"] += ent_coef
@@ -203,7 +210,7 @@ class SAC(OffPolicyAlgorithm):
 
         qs = self._fast_critic.forward_input(pb.x_data) if pb is not None else self._fast_critic(rd.observations, rd.actions)  # :258
         q1, q2 = qs
-        hip_ops.twin_q_loss(q1, q2, self._target_q, 0.5, gq1, gq2, self._loss_now["critic"], s["critic"])  # :261
+        hip_ops.twin_q_loss(q1, q2, self._target_q, 0.5, gq1, gq2, sto("critic", self._loss_now["critic"]), acc("critic"))  # :261
         fused.backward_q(qs, gq)  # :266-268
         self._allreduce_grads(pol.critic_arena)
         if self.ent_coef_optimizer is not None and self._ent_rides_critic:
@@ -216,7 +223,7 @@ class SAC(OffPolicyAlgorithm):
         qs_pi = (self._fast_critic.forward_input(x_pi, train_params=False) if pb is not None
                  else self._fast_critic(rd.observations, actions_pi, train_params=False))
         q1_pi, q2_pi = qs_pi
-        hip_ops.sac_actor_loss(log_prob, q1_pi, q2_pi, ent_coef, g_lp, gq1, gq2, self._loss_now["actor"], s["actor"])
+        hip_ops.sac_actor_loss(log_prob, q1_pi, q2_pi, ent_coef, g_lp, gq1, gq2, sto("actor", self._loss_now["actor"]), acc("actor"))
         if qs_pi.stacked is not None:  # :279-281
             th.autograd.backward([log_prob, qs_pi.stacked], [g_lp, gq])
         else:
@@ -229,7 +236,8 @@ class SAC(OffPolicyAlgorithm):
 
         if self.debug_capture:
             self.last_train_tensors = dict(target_q=self._target_q.clone(), current_q=[q1.detach().clone(), q2.detach().clone()],
-                                           critic_loss=self._loss_now["critic"].clone(), actor_loss=self._loss_now["actor"].clone(),
+                                           critic_loss=sto("critic", self._loss_now["critic"]).clone(),
+                                           actor_loss=sto("actor", self._loss_now["actor"]).clone(),
                                            ent_coef=ent_coef.detach().clone(), log_prob=log_prob.detach().clone())
 
     def _gradient_step_aten(self, batch_size: int, gradient_step: int) -> None:

@@ -722,8 +722,8 @@ __global__ __launch_bounds__(256) void gaussian_head_bwd_kernel(const float *__r
 // d loss / d log_alpha = -mean(logp + H). Writes the gradient straight into the alpha arena's gradient word.
 __global__ __launch_bounds__(256) void sac_alpha_kernel(const float *__restrict__ log_alpha, const float *__restrict__ logp,
                                                         const float target_entropy, float *__restrict__ grad_out,
-                                                        float *__restrict__ ent_coef_out, float *__restrict__ loss_sum,
-                                                        float *__restrict__ ent_coef_sum, const int batch)
+                                                        float *__restrict__ ent_coef_out, float *__restrict__ loss_out,
+                                                        float *__restrict__ loss_sum, float *__restrict__ ent_coef_sum, const int batch)
 {
     __shared__ float sm[4];
     float acc = 0.0f;
@@ -733,6 +733,7 @@ __global__ __launch_bounds__(256) void sac_alpha_kernel(const float *__restrict_
         const float la = log_alpha[0], ec = expf(la);
         grad_out[0] = -mean;
         ent_coef_out[0] = ec;
+        if (loss_out) loss_out[0] = -(la * mean);
         if (loss_sum) loss_sum[0] += -(la * mean);
         if (ent_coef_sum) ent_coef_sum[0] += ec;
     }
@@ -880,11 +881,12 @@ extern "C" int cstr_squashed_gaussian_bwd_f32(const float *g_action, const float
 }
 
 extern "C" int cstr_sac_alpha_f32(const float *log_alpha, const float *logp, float target_entropy, float *grad_out,
-                                  float *ent_coef_out, float *loss_sum, float *ent_coef_sum, int64_t batch, cstr_stream_t stream)
+                                  float *ent_coef_out, float *loss_out, float *loss_sum, float *ent_coef_sum, int64_t batch,
+                                  cstr_stream_t stream)
 {
     if (!log_alpha || !logp || !grad_out || !ent_coef_out || batch <= 0) return CSTR_E_BADARG;
     if (batch > CSTR_MAX_SAMPLE_BATCH) return CSTR_E_UNSUPPORTED;
-    sac_alpha_kernel<<<1, 256, 0, (hipStream_t)stream>>>(log_alpha, logp, target_entropy, grad_out, ent_coef_out, loss_sum,
+    sac_alpha_kernel<<<1, 256, 0, (hipStream_t)stream>>>(log_alpha, logp, target_entropy, grad_out, ent_coef_out, loss_out, loss_sum,
                                                          ent_coef_sum, (int)batch);
     return (int)hipGetLastError();
 }
