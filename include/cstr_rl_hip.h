@@ -202,12 +202,15 @@ int cstr_adam_f32(float *param, const float *grad, float *exp_avg, float *exp_av
                   const double *lr, double beta1, double beta2, double eps, float grad_scale, int64_t n,
                   cstr_stream_t stream);
 
-/* Several Adam steps in ONE launch (SAC: the entropy coefficient -- one parameter -- next to the critic, core/sac/sac.py:240-243
- * and :266-268): each segment is a cstr_adam_f32 call's argument list. */
+/* Several flat-arena updates in ONE launch (SAC: the entropy coefficient -- one parameter -- next to the critic,
+ * core/sac/sac.py:240-243 and :266-268; the actor's step next to the critic's soft target update, :281 and :284-287). A
+ * segment is a cstr_adam_f32 call's argument list, or -- polyak_source != NULL -- a cstr_polyak_f32 call with param = the
+ * TARGET arena (the other Adam fields are ignored). Segments must not depend on each other. */
 #define CSTR_MAX_ADAM_SEGS 4
 typedef struct {
     float *param; const float *grad; float *exp_avg; float *exp_avg_sq; int64_t *adam_ctl; const double *lr;
     double beta1, beta2, eps; float grad_scale; int64_t n;
+    const float *polyak_source; double tau;
 } cstr_adam_seg_t;
 int cstr_adam_multi_f32(const cstr_adam_seg_t *segs, int n_segs, cstr_stream_t stream);
 

@@ -47,7 +47,7 @@ class AdamSeg(C.Structure):
     """cstr_adam_seg_t"""
     _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
                 ("adam_ctl", C.c_void_p), ("lr", C.c_void_p), ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double),
-                ("grad_scale", C.c_float), ("n", C.c_int64)]
+                ("grad_scale", C.c_float), ("n", C.c_int64), ("polyak_source", C.c_void_p), ("tau", C.c_double)]
 
 
 class VecNormCfg(C.Structure):

@@ -172,10 +172,17 @@ class FlatAdam:
         return (self.arena.flat, self.arena.grad, self.exp_avg, self.exp_avg_sq, self.ctl, self.lr_dev, g["betas"][0], g["betas"][1],
                 g["eps"], self.grad_scale)
 
-    def step_with(self, *others: "FlatAdam") -> None:
-        """This optimiser's step and the others' in ONE launch (same arithmetic as separate step() calls)."""
+    def step_with(self, *others: "FlatAdam", polyak=None) -> None:
+        """This optimiser's step, the others' and -- polyak=(source arena, target arena, tau) -- a soft target update of
+        arenas none of them touches, in ONE launch (same arithmetic as the separate calls)."""
+        segs = [self._segment()] + [o._segment() for o in others]
+        if polyak is not None:
+            source, target, tau = polyak
+            if not target.same_layout(source):
+                raise ValueError("Iterables have different lengths")  # zip_strict's error (utils.py:447)
+            segs.append(("polyak", source.flat, target.flat, tau))
         with th.cuda.device(self.arena.device):
-            hip_ops.adam_multi([self._segment()] + [o._segment() for o in others])
+            hip_ops.adam_multi(segs)
 
     @property
     def step_count(self) -> int:

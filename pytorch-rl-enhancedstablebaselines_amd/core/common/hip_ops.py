@@ -252,16 +252,24 @@ def adam(param, grad, exp_avg, exp_avg_sq, adam_ctl, lr_dev, beta1=0.9, beta2=0.
 
 
 def adam_multi(segments):
-    """Several `adam` calls in one launch; `segments` = iterable of adam()'s positional argument tuples (<= 4)."""
+    """Several flat-arena updates in one launch; `segments` = iterable of adam()'s positional argument tuples, or
+    ("polyak", source, target, tau) for a soft target update (<= 4 segments, mutually independent)."""
     segs = list(segments)
     arr = (nv.AdamSeg * len(segs))()
-    for i, (param, grad, exp_avg, exp_avg_sq, adam_ctl, lr_dev, beta1, beta2, eps, grad_scale) in enumerate(segs):
+    for i, seg in enumerate(segs):
+        if seg[0] == "polyak":
+            _, source, target, tau = seg
+            n = source.numel()
+            _chk(source, "source", (n,), th.float32), _chk(target, "target", (n,), th.float32)
+            arr[i] = nv.AdamSeg(target.data_ptr(), None, None, None, None, None, 0.0, 0.0, 0.0, 1.0, n, source.data_ptr(), float(tau))
+            continue
+        param, grad, exp_avg, exp_avg_sq, adam_ctl, lr_dev, beta1, beta2, eps, grad_scale = seg
         n = param.numel()
         for t, nm in ((param, "param"), (grad, "grad"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq")):
             _chk(t, nm, (n,), th.float32)
         _chk(adam_ctl, "adam_ctl", (nv.ADAM_CTL_WORDS,), th.int64), _chk(lr_dev, "lr", (1,), th.float64)
         arr[i] = nv.AdamSeg(param.data_ptr(), grad.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(), adam_ctl.data_ptr(),
-                            lr_dev.data_ptr(), beta1, beta2, eps, grad_scale, n)
+                            lr_dev.data_ptr(), beta1, beta2, eps, grad_scale, n, None, 0.0)
     check(nv.lib().cstr_adam_multi_f32(arr, C.c_int(len(segs)), stream_ptr()), "cstr_adam_multi_f32")
 
 

@@ -229,10 +229,10 @@ class SAC(OffPolicyAlgorithm):
         else:
             th.autograd.backward([log_prob, q1_pi, q2_pi], [g_lp, gq1, gq2])
         self._allreduce_grads(pol.actor_arena)
-        self.actor.optimizer.step()
-
-        if gradient_step % self.target_update_interval == 0:  # :284-287
-            pol.critic_target_arena.polyak_from(pol.critic_arena, self.tau)
+        if gradient_step % self.target_update_interval == 0:  # :281 and :284-287 (disjoint arenas) in one launch
+            self.actor.optimizer.step_with(polyak=(pol.critic_arena, pol.critic_target_arena, self.tau))
+        else:
+            self.actor.optimizer.step()
 
         if self.debug_capture:
             self.last_train_tensors = dict(target_q=self._target_q.clone(), current_q=[q1.detach().clone(), q2.detach().clone()],

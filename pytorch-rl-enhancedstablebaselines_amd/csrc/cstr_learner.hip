@@ -114,9 +114,30 @@ __global__ void adam_kernel(float *__restrict__ param, const float *__restrict__
 // blockIdx.y selects the segment, every segment keeps its own control words, learning rate and hyper-parameters.
 struct AdamSegs { cstr_adam_seg_t s[CSTR_MAX_ADAM_SEGS]; };
 
+__device__ __forceinline__ void polyak_body(const float *__restrict__ param, float *__restrict__ target, const float tau,
+                                            const float om, const int64_t n)
+{
+    const int64_t nv = n >> 2;
+    const float4 *p4 = reinterpret_cast<const float4 *>(param);
+    float4 *t4 = reinterpret_cast<float4 *>(target);
+    const int64_t tid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x, stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = tid; i < nv; i += stride) {
+        const float4 p = p4[i];
+        float4 t = t4[i];
+        t.x = polyak1(p.x, t.x, tau, om); t.y = polyak1(p.y, t.y, tau, om);
+        t.z = polyak1(p.z, t.z, tau, om); t.w = polyak1(p.w, t.w, tau, om);
+        t4[i] = t;
+    }
+    for (int64_t i = (nv << 2) + tid; i < n; i += stride) target[i] = polyak1(param[i], target[i], tau, om);
+}
+
 __global__ void adam_multi_kernel(const AdamSegs segs)
 {
     const cstr_adam_seg_t &s = segs.s[blockIdx.y];
+    if (s.polyak_source) {  // a soft target update riding in the same launch: param = target arena
+        polyak_body(s.polyak_source, s.param, (float)s.tau, (float)(1.0 - s.tau), s.n);
+        return;
+    }
     adam_body(s.param, s.grad, s.exp_avg, s.exp_avg_sq, s.adam_ctl, s.lr, s.beta1, s.beta2, s.eps, s.grad_scale, s.n);
 }
 
@@ -162,8 +183,12 @@ extern "C" int cstr_adam_multi_f32(const cstr_adam_seg_t *segs, int n_segs, cstr
     int grid = 1;
     for (int i = 0; i < n_segs; ++i) {
         const cstr_adam_seg_t &s = segs[i];
-        if (!s.param || !s.grad || !s.exp_avg || !s.exp_avg_sq || !s.adam_ctl || !s.lr || s.n <= 0) return CSTR_E_BADARG;
-        if (!aligned16(s.param) || !aligned16(s.grad) || !aligned16(s.exp_avg) || !aligned16(s.exp_avg_sq)) return CSTR_E_BADARG;
+        if (s.polyak_source) {
+            if (!s.param || s.n <= 0 || !aligned16(s.param) || !aligned16(s.polyak_source) || s.param == s.polyak_source) return CSTR_E_BADARG;
+        } else {
+            if (!s.param || !s.grad || !s.exp_avg || !s.exp_avg_sq || !s.adam_ctl || !s.lr || s.n <= 0) return CSTR_E_BADARG;
+            if (!aligned16(s.param) || !aligned16(s.grad) || !aligned16(s.exp_avg) || !aligned16(s.exp_avg_sq)) return CSTR_E_BADARG;
+        }
         int block, g;
         flat_launch_shape((s.n + 3) / 4, block, g);
         grid = g > grid ? g : grid;

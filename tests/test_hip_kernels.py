@@ -608,3 +608,34 @@ def test_twin_layout_reset_draw(ops):
     b = orc.reset_draw(st)
     np.testing.assert_array_equal(out.cpu().numpy(), np.concatenate([a, b], 1))
     np.testing.assert_array_equal(dst.cpu().numpy().view(np.uint64).reshape(-1), st.view(np.uint64).reshape(-1))
+
+
+def test_multi_update_launch_equals_separate_calls(ops):
+    """cstr_adam_multi_f32: two Adam segments with different hyper-parameters and a polyak segment in ONE launch produce
+    exactly what the separate cstr_adam_f32 / cstr_polyak_f32 calls produce (same device functions)."""
+    g = th.Generator(device="cuda").manual_seed(4)
+
+    def arena(n):
+        return [th.randn(n, device="cuda", generator=g) for _ in range(2)] + [th.zeros(n, device="cuda"), th.zeros(n, device="cuda")]
+
+    def fresh():
+        th.manual_seed(0)
+        a, b = arena(135744), arena(64)
+        src, tgt = th.randn(70000, device="cuda", generator=th.Generator(device="cuda").manual_seed(9)), th.randn(70000, device="cuda", generator=th.Generator(device="cuda").manual_seed(10))
+        ca, cb = ops.new_adam_ctl("cuda", 0, 0.9, 0.999), ops.new_adam_ctl("cuda", 0, 0.8, 0.99)
+        return a, b, src, tgt, ca, cb
+
+    g = th.Generator(device="cuda").manual_seed(4)
+    a1, b1, s1, t1, ca1, cb1 = fresh()
+    g = th.Generator(device="cuda").manual_seed(4)
+    a2, b2, s2, t2, ca2, cb2 = fresh()
+    lra, lrb = th.tensor([3e-4], dtype=th.float64, device="cuda"), th.tensor([1e-2], dtype=th.float64, device="cuda")
+    for _ in range(3):
+        ops.adam(a1[0], a1[1], a1[2], a1[3], ca1, lra, 0.9, 0.999, 1e-8, 1.0)
+        ops.adam(b1[0], b1[1], b1[2], b1[3], cb1, lrb, 0.8, 0.99, 1e-6, 0.5)
+        ops.polyak(s1, t1, 0.005)
+        ops.adam_multi([(a2[0], a2[1], a2[2], a2[3], ca2, lra, 0.9, 0.999, 1e-8, 1.0),
+                        (b2[0], b2[1], b2[2], b2[3], cb2, lrb, 0.8, 0.99, 1e-6, 0.5), ("polyak", s2, t2, 0.005)])
+    for x, y in zip(a1 + b1 + [t1, ca1, cb1], a2 + b2 + [t2, ca2, cb2]):
+        assert th.equal(x, y)
+    assert int(ca2[0]) == 3 and int(cb2[0]) == 3
