@@ -1040,10 +1040,12 @@ extern "C" int cstr_gaussian_head_gemm_fwd_f32(const float *hidden, int64_t ldh,
     if (!hidden || !w || !bias || !params || !eps || !action || batch <= 0 || act_dim <= 0 || k <= 0 || ldh < k || action_stride < act_dim)
         return CSTR_E_BADARG;
     if (act_dim > CSTR_MAX_HEAD_ACT || (k & 3) || (ldh & 3) || !aligned16(hidden) || !aligned16(w) || k > 0x7fffff) return CSTR_E_UNSUPPORTED;
-    // 16 rows (waves) per workgroup: few workgroups = few tickets on the RNG control word (they serialise on one address)
-    const int64_t g = (batch + 15) / 16;
+    // rows (waves) per workgroup: 4 at batch size (spread over many CUs), 16 for large batches (fewer tickets on the RNG
+    // control word: they serialise on one address)
+    const int rows_per_wg = batch <= 1024 ? 4 : 16;
+    const int64_t g = (batch + rows_per_wg - 1) / rows_per_wg;
     if (g > 0x7fffffff) return CSTR_E_UNSUPPORTED;
-    gaussian_head_gemm_fwd_kernel<<<(unsigned)g, batch >= 16 ? 1024 : 64 * (int)batch, 0, (hipStream_t)stream>>>(hidden, (int)ldh, w, bias, params, eps, rng_ctl, action,
+    gaussian_head_gemm_fwd_kernel<<<(unsigned)g, 64 * rows_per_wg, 0, (hipStream_t)stream>>>(hidden, (int)ldh, w, bias, params, eps, rng_ctl, action,
                                                                                 action_stride, logp, batch, act_dim, (int)k);
     return (int)hipGetLastError();
 }

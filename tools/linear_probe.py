@@ -63,3 +63,11 @@ if __name__ == "__main__":
         print(f"G={g} M={m} N={n} K={k}: GEMM + column sums {t_us(two):6.2f} us   fused MFMA kernel "
               f"{t_us(lambda: hip_ops.linear_bwd_weight(dzz, xx, dw, db)):6.2f} us   (GEMM alone "
               f"{t_us(lambda: th.bmm(dzz.transpose(1, 2), xx, out=dw) if g else th.mm(dzz.t(), xx, out=dw)):6.2f} us)", flush=True)
+    print("SAC actor head (Linear 256 -> 4, sampling):")
+    for b in (256, 4096):
+        h, w, bias = th.randn(b, 256, device="cuda"), th.randn(4, 256, device="cuda") / 16, th.zeros(4, device="cuda")
+        p, e, a, lp = th.empty(b, 4, device="cuda"), th.empty(b, 2, device="cuda"), th.empty(b, 2, device="cuda"), th.empty(b, device="cuda")
+        ctl = hip_ops.new_rng_ctl(1, "cuda")
+        two = t_us(lambda: hip_ops.gaussian_head_fwd_(th.mm(h, w.t()), bias, e, ctl, a, lp))
+        one = t_us(lambda: hip_ops.gaussian_head_gemm_fwd(h, w, bias, p, e, ctl, a, lp))
+        print(f"B={b}: GEMM + head kernel {two:6.2f} us   head kernel with the Linear inside {one:6.2f} us", flush=True)
