@@ -33,10 +33,16 @@ static inline void env_launch_shape(int64_t n, int &block, int &grid)
 // Flat element-wise kernels over float4: same rule.
 static inline void flat_launch_shape(int64_t n_vec, int &block, int &grid)
 {
-    block = 256;
-    int64_t g = (n_vec + 255) / 256;
+    // tuning knobs for A/B microbenchmarks (bench.py "kernels" section); unset in production
+    static const int ov_block = getenv("CSTR_FLAT_BLOCK") ? atoi(getenv("CSTR_FLAT_BLOCK")) : 0;
+    static const int ov_cap = getenv("CSTR_FLAT_GRID_CAP") ? atoi(getenv("CSTR_FLAT_GRID_CAP")) : 0;
+    // A/B on MI355X (bench.py "kernels", r01_notes.md): 512-thread workgroups, <= 4096 of them: Adam at the learners' 136 k
+    // parameters 4.5 -> 3.9 us, streaming fractions unchanged (0.63 Adam / 0.87 polyak of 8 TB/s for every shape tried)
+    block = ov_block ? ov_block : 512;
+    const int64_t cap = ov_cap ? ov_cap : 4096;
+    int64_t g = (n_vec + block - 1) / block;
     if (g < 1) g = 1;
-    grid = (int)(g < 2048 ? g : 2048);
+    grid = (int)(g < cap ? g : cap);
 }
 
 #ifdef __HIPCC__

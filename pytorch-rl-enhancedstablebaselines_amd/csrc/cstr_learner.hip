@@ -83,12 +83,22 @@ __device__ __forceinline__ void adam_body(float *__restrict__ param, const float
     const int64_t tid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x, stride = (int64_t)gridDim.x * blockDim.x;
     float4 *p4 = reinterpret_cast<float4 *>(param), *m4 = reinterpret_cast<float4 *>(exp_avg), *v4 = reinterpret_cast<float4 *>(exp_avg_sq);
     const float4 *g4 = reinterpret_cast<const float4 *>(grad);
+    // arenas far beyond the caches (a microbenchmark regime, not the learners'): stream the updated state past L2
+    const bool stream_out = n >= (int64_t)(16 << 20);
     for (int64_t i = tid; i < nv; i += stride) {
         float4 p = p4[i], m = m4[i], v = v4[i];
         const float4 g = g4[i];
         adam1(p.x, g.x, m.x, v.x, a); adam1(p.y, g.y, m.y, v.y, a);
         adam1(p.z, g.z, m.z, v.z, a); adam1(p.w, g.w, m.w, v.w, a);
-        p4[i] = p; m4[i] = m; v4[i] = v;
+        if (stream_out) {
+            typedef float v4f __attribute__((ext_vector_type(4)));
+            const v4f pv = {p.x, p.y, p.z, p.w}, mv = {m.x, m.y, m.z, m.w}, vv = {v.x, v.y, v.z, v.w};
+            __builtin_nontemporal_store(pv, reinterpret_cast<v4f *>(p4 + i));
+            __builtin_nontemporal_store(mv, reinterpret_cast<v4f *>(m4 + i));
+            __builtin_nontemporal_store(vv, reinterpret_cast<v4f *>(v4 + i));
+        } else {
+            p4[i] = p; m4[i] = m; v4[i] = v;
+        }
     }
     for (int64_t i = (nv << 2) + tid; i < n; i += stride) {
         float p = param[i], m = exp_avg[i], v = exp_avg_sq[i];
