@@ -39,8 +39,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s meas
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=300)
-    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--steps", type=int, default=2000)  # >= 2000 vec-steps after 200 warm-up (0.4 s of GPU time)
+    ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--algo", default="sac", choices=["sac", "td3", "maddpg"])
     ap.add_argument("--n-envs", type=int, default=4096)
     ap.add_argument("--obs-dim", type=int, default=4, choices=[4, 8])
