@@ -193,8 +193,8 @@ class TD3(OffPolicyAlgorithm):
             hip_ops.neg_mean_loss(qs_pi[0], gq1, self._loss_now["actor"], s["actor"])
             fused.backward_q(qs_pi, gq)
             self._allreduce_grads(pol.actor_arena)
-            self.actor.optimizer.step()
-            pol.critic_target_arena.polyak_from(pol.critic_arena, self.tau)
+            # the actor's step and the critics' soft update touch disjoint arenas: one launch (:199 and :204)
+            self.actor.optimizer.step_with(polyak=(pol.critic_arena, pol.critic_target_arena, self.tau))
             pol.actor_target_arena.polyak_from(pol.actor_arena, self.tau)
             actor_done = True
         if self.debug_capture:

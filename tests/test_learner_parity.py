@@ -591,3 +591,40 @@ def test_unrolled_hipgraph_equals_single_iteration_graphs(algo):
         np.testing.assert_array_equal(a[k], b[k])
     for k in ("actor", "critic", "ring"):
         np.testing.assert_allclose(a[k], b[k], rtol=2e-3, atol=2e-4, err_msg=k)
+
+
+def test_full_size_run_index_stream_ring_and_episode_invariants():
+    """BASELINE config 2 at full size (SAC class defaults, 4096 envs, ring 244 x 4096, batch 256), 500 iterations from a
+    hipGraph: size-independent properties -- the sampler's legacy MT19937 stream ends exactly where numpy's would after the
+    same randint calls (ring wraps twice, `upper` saturates at 244), ring control words, step counters and episode statistics
+    (every env truncates once at step 400 and is reset by the fused kernel)."""
+    from core.common import legacy_rng
+    from core.common.vec_env import CSTRVecEnv
+    from core.sac import SAC
+
+    N, B, seed, iters = 4096, 256, 11, 500
+    env = CSTRVecEnv(N)
+    model = SAC("MlpPolicy", env, seed=seed)
+    model.enable_graph_capture()
+    model.learn(N * iters)
+    rb = model.replay_buffer
+    R = rb.buffer_size
+    assert R == 244 and model.num_timesteps == N * iters and model._n_updates == iters  # learning_starts 100 < 4096
+    rs = np.random.RandomState(seed + N - 1)
+    for k in range(1, iters + 1):
+        rs.randint(0, min(k, R), size=B)
+        rs.randint(0, N, size=B)
+    st, w = rs.get_state(), legacy_rng.global_stream(model.device).cpu().numpy().view(np.uint32)
+    np.testing.assert_array_equal(w[:624], st[1])
+    assert int(w[624]) == st[2]
+    ctl = rb.ring.ctl.cpu().numpy()
+    assert (ctl[0], ctl[1], ctl[3]) == (iters % R, 1, iters) and rb.pos == iters % R and rb.full
+    assert int(env.step_count.min()) == int(env.step_count.max()) == iters - 400
+    n_ep, ret_sum, len_sum, _ = model._ep_stats.cpu().tolist()
+    assert n_ep == N and len_sum == 400 * N and ret_sum < 0
+    d, t = rb.dones.cpu().numpy(), rb.timeouts.cpu().numpy()
+    row = (400 - 1) % R  # the truncating transition of every env sits in one ring row
+    assert d.sum() == N and t.sum() == N and d[row].all() and t[row].all()
+    for p in model.policy.parameters():
+        assert th.isfinite(p).all()
+    assert model.critic.optimizer.step_count == iters and model.actor.optimizer.step_count == iters
