@@ -167,6 +167,10 @@ int cstr_vecnorm_apply_f32(const cstr_vecnorm_cfg_t *cfg, const double *vn_state
  * Box-Muller, second deviate first, odd tail cached in mt_state). loc / scale: HOST double[period], period <= 8. */
 int cstr_mt19937_normal_f32(uint32_t *mt_state, const double *loc, const double *scale, int32_t period, float *out,
                             int64_t count, cstr_stream_t stream);
+/* The same draws kept in double precision: np.random.normal(size=...) as OrnsteinUhlenbeckActionNoise.__call__ uses it
+ * (core/common/noise.py:85-89) before its own float64 arithmetic. */
+int cstr_mt19937_normal_f64(uint32_t *mt_state, const double *loc, const double *scale, int32_t period, double *out,
+                            int64_t count, cstr_stream_t stream);
 
 /* ReplayBuffer.sample (core/common/buffers.py:106-115, :285-325): upper = rows if full else pos;
  * batch_inds = np.random.randint(0, upper, batch); env_indices = np.random.randint(0, n_envs, batch)

@@ -129,10 +129,12 @@ def mt19937_normal(mt_state, loc, scale, out):
         raise ValueError(f"loc / scale must have the same length in [1, {nv.MAX_NOISE_PERIOD}]")
     if any(not v >= 0.0 for v in scale):
         raise ValueError("scale < 0")  # numpy's message
-    _chk(out, "out", (out.shape[0], period), th.float32)
-    check(nv.lib().cstr_mt19937_normal_f32(ptr(mt_state), (C.c_double * period)(*loc), (C.c_double * period)(*scale),
-                                           C.c_int32(period), ptr(out), C.c_int64(out.numel()), stream_ptr()),
-          "cstr_mt19937_normal_f32")
+    if out.dtype not in (th.float32, th.float64):
+        raise ValueError(f"out: dtype {out.dtype}, expected float32 or float64")
+    _chk(out, "out", (out.shape[0], period), out.dtype)
+    fn = nv.lib().cstr_mt19937_normal_f32 if out.dtype == th.float32 else nv.lib().cstr_mt19937_normal_f64
+    check(fn(ptr(mt_state), (C.c_double * period)(*loc), (C.c_double * period)(*scale), C.c_int32(period), ptr(out),
+             C.c_int64(out.numel()), stream_ptr()), "cstr_mt19937_normal")
 
 
 def replay_sample(ring: DeviceRing, mt_state, batch: int, out_obs, out_act, out_next_obs, out_done, out_rew,

@@ -4,7 +4,8 @@ The reference draws Gaussian noise with `np.random.normal` on the process-global
 stream ReplayBuffer.sample draws its indices from. On the device env's fast path `NormalActionNoise` is therefore
 replaced by `LegacyStreamNormalActionNoise`, which draws all n_envs x action_dim deviates in ONE kernel from the HBM
 image of that stream (cstr_mt19937_normal_f32): the noise values and the replay index stream that follows stay
-bit-faithful to a seeded reference run. `DeviceNormalActionNoise` is the faster, statistically
+bit-faithful to a seeded reference run; `OrnsteinUhlenbeckActionNoise` likewise becomes
+`LegacyStreamOUActionNoise` (float64 draws from the same stream). `DeviceNormalActionNoise` is the faster, statistically
 equivalent alternative (torch's device generator, not bit-faithful). The plain host classes keep the reference's
 NumPy code for generic (non-device) envs; their host draws do NOT advance the device stream."""
 import copy
@@ -91,6 +92,56 @@ class LegacyStreamNormalActionNoise(ActionNoise):
 
     def __repr__(self) -> str:
         return f"LegacyStreamNormalActionNoise(mu={self._mu.tolist()}, sigma={self._sigma.tolist()}, n_envs={self.n_envs})"
+
+
+class LegacyStreamOUActionNoise(ActionNoise):
+    """`VectorizedActionNoise(OrnsteinUhlenbeckActionNoise(...), n_envs)()` (reference: noise.py:48-106, :141-142) on the GPU:
+    the n_envs x action_dim standard normals come from the legacy MT19937 stream `stream_fn()` returns (the replay
+    sampler's) in numpy's draw order and in float64, the recursion runs in float64 with the reference's operation order,
+    the result is cast to float32 like `.astype(self._dtype)`. `reset_done(done)` = `reset(indices)` for finished envs."""
+
+    def __init__(self, mean, sigma, theta: float, dt: float, initial_noise, n_envs: int, device, stream_fn):
+        import torch as th
+
+        self._mu_np = np.asarray(mean, np.float64).reshape(-1)
+        a = self._mu_np.size
+        self._sigma_np = np.broadcast_to(np.asarray(sigma, np.float64).reshape(-1), (a,)).copy()
+        self._theta, self._dt = float(theta), float(dt)
+        self.n_envs, self.device, self._stream_fn = int(n_envs), th.device(device), stream_fn
+        dev = self.device
+        self._mu = th.as_tensor(self._mu_np, device=dev).reshape(1, a)
+        self._s = th.as_tensor(self._sigma_np * np.sqrt(self._dt), device=dev).reshape(1, a)  # sigma * np.sqrt(dt) (:87)
+        init = np.zeros(a) if initial_noise is None else np.asarray(initial_noise, np.float64).reshape(-1)
+        self._init = th.as_tensor(init, device=dev).reshape(1, a).expand(self.n_envs, a).contiguous()
+        self.noise_prev = self._init.clone()
+        self._z = th.empty(self.n_envs, a, dtype=th.float64, device=dev)
+        self._zero, self._one = [0.0] * a, [1.0] * a
+
+    def __call__(self):
+        from core.common import hip_ops
+
+        hip_ops.mt19937_normal(self._stream_fn(), self._zero, self._one, self._z)  # np.random.normal(size=mu.shape), per env
+        p = self.noise_prev
+        noise = p + self._theta * (self._mu - p) * self._dt + self._s * self._z  # the reference's operation order (:84-88)
+        self.noise_prev.copy_(noise)
+        return noise.float()  # .astype(np.float32)
+
+    def reset(self, indices: Optional[Iterable[int]] = None) -> None:
+        if indices is None:
+            self.noise_prev.copy_(self._init)
+        else:
+            idx = list(indices)
+            if idx:
+                self.noise_prev[idx] = self._init[idx]
+
+    def reset_done(self, done) -> None:
+        """reset(indices) for the envs whose episode just ended (off_policy_algorithm.py:596-599), without a host sync"""
+        import torch as th
+
+        self.noise_prev.copy_(th.where(done.reshape(-1, 1) > 0, self._init, self.noise_prev))
+
+    def __repr__(self) -> str:
+        return f"LegacyStreamOUActionNoise(mu={self._mu_np.tolist()}, sigma={self._sigma_np.tolist()}, n_envs={self.n_envs})"
 
 
 class DeviceNormalActionNoise(ActionNoise):

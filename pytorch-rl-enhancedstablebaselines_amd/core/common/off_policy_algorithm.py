@@ -127,8 +127,8 @@ class OffPolicyAlgorithm(BaseAlgorithm):
 
     # ---- learn ----------------------------------------------------------------------------------------------------
     def _setup_learn(self, total_timesteps, callback=None, reset_num_timesteps=True, tb_log_name="run", progress_bar=False):
-        from core.common.noise import (DeviceNormalActionNoise, LegacyStreamNormalActionNoise, NormalActionNoise,
-                                       VectorizedActionNoise)
+        from core.common.noise import (DeviceNormalActionNoise, LegacyStreamNormalActionNoise, LegacyStreamOUActionNoise,
+                                       NormalActionNoise, OrnsteinUhlenbeckActionNoise, VectorizedActionNoise)
 
         self.replay_buffer.normalizer = self._vec_normalize_env  # sample(..., env=self._vec_normalize_env), sac.py:215
         base = self.action_noise
@@ -139,8 +139,12 @@ class OffPolicyAlgorithm(BaseAlgorithm):
             # kernel on the HBM image of the same legacy stream the replay sampler uses: bit-faithful interleaving
             self.action_noise = LegacyStreamNormalActionNoise(base._mu, base._sigma, self.env.num_envs, self.device,
                                                               lambda: self.replay_buffer.sampler_stream)
+        elif isinstance(base, OrnsteinUhlenbeckActionNoise) and self._fast_path() and np.size(base._mu) <= 8:
+            # noise.py:84-89 per env on the same stream, float64 state in HBM
+            self.action_noise = LegacyStreamOUActionNoise(base._mu, base._sigma, base._theta, base._dt, base.initial_noise,
+                                                          self.env.num_envs, self.device, lambda: self.replay_buffer.sampler_stream)
         elif self.action_noise is not None and self.env.num_envs > 1 and not hasattr(self.action_noise, "noises") \
-                and not isinstance(self.action_noise, (DeviceNormalActionNoise, LegacyStreamNormalActionNoise)):
+                and not isinstance(self.action_noise, (DeviceNormalActionNoise, LegacyStreamNormalActionNoise, LegacyStreamOUActionNoise)):
             self.action_noise = VectorizedActionNoise(self.action_noise, self.env.num_envs)
         return super()._setup_learn(total_timesteps, callback, reset_num_timesteps, tb_log_name, progress_bar)
 
@@ -193,10 +197,11 @@ class OffPolicyAlgorithm(BaseAlgorithm):
         self.graph_unroll = max(1, int(unroll if unroll is not None else os.environ.get("CSTR_GRAPH_UNROLL", "1")))
 
     def _graph_eligible(self, callback: BaseCallback) -> bool:
-        from core.common.noise import DeviceNormalActionNoise, LegacyStreamNormalActionNoise
+        from core.common.noise import DeviceNormalActionNoise, LegacyStreamNormalActionNoise, LegacyStreamOUActionNoise
 
         return (self._fast_path() and getattr(callback, "is_noop", False)
-                and (self.action_noise is None or isinstance(self.action_noise, (DeviceNormalActionNoise, LegacyStreamNormalActionNoise)))
+                and (self.action_noise is None
+                     or isinstance(self.action_noise, (DeviceNormalActionNoise, LegacyStreamNormalActionNoise, LegacyStreamOUActionNoise)))
                 and self.train_freq == TrainFreq(1, TrainFrequencyUnit.STEP)
                 and self.gradient_steps >= 1 and self.num_timesteps >= self.learning_starts
                 and self.num_timesteps + self.n_envs > self.learning_starts and not getattr(self, "debug_capture", False))
@@ -209,6 +214,8 @@ class OffPolicyAlgorithm(BaseAlgorithm):
         hip_ops.collect_step(env.coef, env.integrator, rb.ring, env.obs, env.step_count, pol, self._action_mode(False),
                              self.action_space.low, self.action_space.high, noise=noise, pcg_state=env.pcg_state, static_init=env.static_init, reward_out=env._rew, done_out=env._done,
                              ep_return=self._ep_return, ep_stats=self._ep_stats)
+        if hasattr(self.action_noise, "reset_done"):
+            self.action_noise.reset_done(env._done)  # action_noise.reset(indices of finished envs), :596-599
         if vn is not None:
             vn.after_device_step()
         self.policy.set_training_mode(True)
@@ -465,6 +472,8 @@ class OffPolicyAlgorithm(BaseAlgorithm):
             hip_ops.collect_step(env.coef, env.integrator, rb.ring, env.obs, env.step_count, pol, squashed,
                                  self.action_space.low, self.action_space.high, noise=noise, pcg_state=env.pcg_state, static_init=env.static_init,
                                  reward_out=env._rew, done_out=env._done, ep_return=self._ep_return, ep_stats=self._ep_stats)
+            if hasattr(action_noise, "reset_done"):
+                action_noise.reset_done(env._done)  # action_noise.reset(indices of finished envs), :596-599
             if vn is not None:
                 vn.after_device_step()  # VecNormalize.step_wait on the raw outputs (vec_normalize.py:174-204)
         rb.note_fused_add()

@@ -198,8 +198,9 @@ struct NormalShared {
     double gauss;
 };
 
+template <typename T>  // float: NormalActionNoise's .astype(float32); double: the raw deviates (Ornstein-Uhlenbeck noise)
 __global__ __launch_bounds__(TPB) void mt_normal_kernel(uint32_t *__restrict__ mt_state, const NormalParams prm,
-                                                        float *__restrict__ out, const int64_t count)
+                                                        T *__restrict__ out, const int64_t count)
 {
     __shared__ NormalShared sh;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, P = prm.period;
@@ -214,7 +215,7 @@ __global__ __launch_bounds__(TPB) void mt_normal_kernel(uint32_t *__restrict__ m
     int64_t j = 0;
     if (has0 && count > 0) {  // the cached deviate of the previous call comes first
         if (t == 0) {
-            out[0] = (float)(prm.loc[0] + prm.scale[0] * sh.gauss);
+            out[0] = (T)(prm.loc[0] + prm.scale[0] * sh.gauss);
             sh.has_gauss = 0;
             sh.gauss = 0.0;
         }
@@ -266,8 +267,8 @@ __global__ __launch_bounds__(TPB) void mt_normal_kernel(uint32_t *__restrict__ m
             const double f = sqrt(-2.0 * log(r2) / r2);
             const int64_t e0 = j + 2 * (int64_t)rank;
             const int p0 = (int)(e0 % P), p1 = (int)((e0 + 1) % P);
-            out[e0] = (float)(prm.loc[p0] + prm.scale[p0] * (f * x2));
-            if (e0 + 1 < count) out[e0 + 1] = (float)(prm.loc[p1] + prm.scale[p1] * (f * x1));
+            out[e0] = (T)(prm.loc[p0] + prm.scale[p0] * (f * x2));
+            if (e0 + 1 < count) out[e0 + 1] = (T)(prm.loc[p1] + prm.scale[p1] * (f * x1));
             else { sh.has_gauss = 1; sh.gauss = f * x1; }  // odd tail: keep the first deviate for the next call
             if (rank == pairs - 1) sh.consumed = t + 1;
         }
@@ -313,8 +314,9 @@ extern "C" int cstr_mt19937_seed(uint32_t *mt_state, uint32_t seed, cstr_stream_
     return (int)hipGetLastError();
 }
 
-extern "C" int cstr_mt19937_normal_f32(uint32_t *mt_state, const double *loc, const double *scale, int32_t period, float *out,
-                                       int64_t count, cstr_stream_t stream)
+template <typename T>
+static int mt_normal_launch(uint32_t *mt_state, const double *loc, const double *scale, int32_t period, T *out, int64_t count,
+                            cstr_stream_t stream)
 {
     if (!mt_state || !loc || !scale || !out || count < 0) return CSTR_E_BADARG;
     if (period < 1 || period > CSTR_MAX_NOISE_PERIOD) return CSTR_E_UNSUPPORTED;
@@ -326,8 +328,20 @@ extern "C" int cstr_mt19937_normal_f32(uint32_t *mt_state, const double *loc, co
         if (i < period && !(scale[i] >= 0.0)) return CSTR_E_BADARG;  // numpy: "scale < 0"
     }
     prm.period = period;
-    mt_normal_kernel<<<1, TPB, 0, (hipStream_t)stream>>>(mt_state, prm, out, count);
+    mt_normal_kernel<T><<<1, TPB, 0, (hipStream_t)stream>>>(mt_state, prm, out, count);
     return (int)hipGetLastError();
+}
+
+extern "C" int cstr_mt19937_normal_f32(uint32_t *mt_state, const double *loc, const double *scale, int32_t period, float *out,
+                                       int64_t count, cstr_stream_t stream)
+{
+    return mt_normal_launch<float>(mt_state, loc, scale, period, out, count, stream);
+}
+
+extern "C" int cstr_mt19937_normal_f64(uint32_t *mt_state, const double *loc, const double *scale, int32_t period, double *out,
+                                       int64_t count, cstr_stream_t stream)
+{
+    return mt_normal_launch<double>(mt_state, loc, scale, period, out, count, stream);
 }
 
 extern "C" int cstr_replay_sample_mt19937_f32(const cstr_ring_t *ring, const int64_t *ring_ctl, uint32_t *mt_state,

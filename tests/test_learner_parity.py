@@ -628,3 +628,51 @@ def test_full_size_run_index_stream_ring_and_episode_invariants():
     for p in model.policy.parameters():
         assert th.isfinite(p).all()
     assert model.critic.optimizer.step_count == iters and model.actor.optimizer.step_count == iters
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_ou_action_noise_on_the_legacy_stream_matches_numpy(graph):
+    """OrnsteinUhlenbeckActionNoise (reference: noise.py:48-106) through VectorizedActionNoise semantics: per vec-step n_envs x
+    np.random.normal(size=A) float64 draws from the global stream the sampler shares, the float64 recursion in the reference's
+    operation order, per-env reset at episode end. The stored actions of the warm-up rows and the final stream / noise state
+    must equal a NumPy replay."""
+    from core.common import legacy_rng
+    from core.common.noise import LegacyStreamOUActionNoise, OrnsteinUhlenbeckActionNoise
+    from core.common.vec_env import CSTRVecEnv
+    from core.td3 import TD3
+
+    N, B, seed, iters, R, warm = 16, 8, 3, 12, 40, 5
+    mu, sigma, theta, dt = np.array([0.1, -0.2]), np.array([0.3, 0.2]), 0.15, 1e-2
+    env = CSTRVecEnv(N)
+    model = TD3("MlpPolicy", env, seed=seed, batch_size=B, buffer_size=N * R, learning_starts=N * warm,
+                action_noise=OrnsteinUhlenbeckActionNoise(mu, sigma, theta=theta, dt=dt), policy_kwargs=dict(net_arch=[16, 16]))
+    model._setup_learn(N * iters)  # seeds env + streams; then make the 3rd vec-step end every episode
+    env.step_count.fill_(397)
+    if graph:
+        model.enable_graph_capture()
+    cb = model._init_callback(None)
+    while model.num_timesteps < N * iters:
+        model._learn_iteration(cb, None)
+    assert isinstance(model.action_noise, LegacyStreamOUActionNoise) and bool(model._graph) == graph
+    rs = np.random.RandomState(seed + N - 1)
+    prev = np.zeros((N, 2))
+    noises = []
+    for k in range(1, iters + 1):
+        z = np.stack([rs.normal(size=2) for _ in range(N)])
+        prev = prev + theta * (mu - prev) * dt + sigma * np.sqrt(dt) * z
+        noises.append(prev.astype(np.float32))
+        if k == 3:
+            prev = np.zeros((N, 2))  # every env truncated at step 400 -> reset(indices)
+        if k * N > N * warm:
+            rs.randint(0, min(k, R), size=B)
+            rs.randint(0, N, size=B)
+    st, w = rs.get_state(), legacy_rng.global_stream(model.device).cpu().numpy().view(np.uint32)
+    np.testing.assert_array_equal(w[:624], st[1])
+    assert (int(w[624]), int(w[625])) == (st[2], st[3])
+    np.testing.assert_array_equal(model.action_noise.noise_prev.cpu().numpy(), prev)
+    # warm-up rows: stored action = clip(scaled space sample + noise, -1, 1)
+    m0 = TD3("MlpPolicy", CSTRVecEnv(N), seed=seed, batch_size=B, buffer_size=N * R, learning_starts=10**9, policy_kwargs=dict(net_arch=[16, 16]))
+    m0.learn(N * warm)
+    a, a0 = model.replay_buffer.actions.cpu().numpy(), m0.replay_buffer.actions.cpu().numpy()
+    for k in range(warm):
+        np.testing.assert_array_equal(a[k], np.clip(a0[k] + noises[k], np.float32(-1), np.float32(1)))
