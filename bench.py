@@ -287,7 +287,11 @@ def main():
     args = parse()
     from core.common import distributed as dist_util
 
-    rank, local_rank, world = dist_util.init_from_env()
+    # rehearsal knobs (a 1-GPU box): CSTR_DIST_BACKEND=gloo + CSTR_BENCH_SINGLE_DEVICE=1 run N ranks on cuda:0 over gloo, which
+    # exercises this file's multi-rank path (RCCL refuses two ranks on one device); the driver's real runs use neither
+    rank, local_rank, world = dist_util.init_from_env(os.environ.get("CSTR_DIST_BACKEND"))
+    if os.environ.get("CSTR_BENCH_SINGLE_DEVICE") == "1":
+        local_rank = 0
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     assert th.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
