@@ -240,6 +240,15 @@ int cstr_bias_act_bwd_f32(const float *gy, const float *y, int act, float *gz, f
 int cstr_linear_act_fwd_f32(const float *x, int64_t x_group_stride, int64_t ldx, const float *w, const float *bias, int act, float *y,
                             int64_t groups, int64_t m, int64_t n, int64_t k, cstr_stream_t stream);
 
+/* cstr_linear_act_fwd_f32 for up to 8 INDEPENDENT layers of one shape in one launch (every agent's actor layer in MADDPG /
+ * IDDPG: core/maddpg/policies.py builds one MLP per agent; the reference evaluates them one after the other). Each set:
+ * y[m][n] = act(x[m] . w[n] + bias[n]) with x rows ldx apart and y rows ldy apart (y may be the agent's column block of the
+ * joint action). */
+#define CSTR_MAX_LINEAR_SETS 8
+typedef struct { const float *x; int64_t ldx; const float *w; const float *bias; float *y; int64_t ldy; } cstr_linear_set_t;
+int cstr_linear_act_fwd_sets_f32(const cstr_linear_set_t *sets, int n_sets, int act, int64_t m, int64_t n, int64_t k,
+                                 cstr_stream_t stream);
+
 /* Backward of a Linear w.r.t. its input, fused with the activation gradient of the layer BELOW it (autograd's mm backward +
  * threshold/tanh backward of core/common/torch_layers.py:110-183's Linear -> ReLU -> Linear):
  *   dz[g][m][k] = (sum_n gz[g][m][n] * w[g][n][k]) * act'(y[g][m][k])

@@ -165,6 +165,90 @@ class FastMLP:
         return x
 
 
+class _ActorGroupFn(th.autograd.Function):
+    """Grouped forward of several agents' actors where ONE agent is differentiated (MADDPG's actor loss: the other agents'
+    actions enter the joint critic input as constants, core/maddpg/maddpg.py:167-177). The buffer `out` receives every
+    agent's action in its column block and carries the differentiated agent's history."""
+
+    @staticmethod
+    def forward(ctx, out, group, inputs, col_ranges, agent: int, *owners):
+        acts_i = group._run(inputs, out, col_ranges, keep=agent)  # agent's per-layer outputs (contiguous), last one included
+        ctx.group, ctx.agent, ctx.cols = group, agent, col_ranges[agent]
+        ctx.save_for_backward(inputs[agent], *acts_i)
+        ctx.mark_dirty(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        x0, *ys = ctx.saved_tensors
+        layers = ctx.group.mlps[ctx.agent].layers
+        lo, hi = ctx.cols
+        gz = g_out[:, lo:hi].contiguous()
+        last_act = layers[-1][1]
+        if last_act != ACT_NONE:
+            dz = th.empty_like(gz)
+            hip_ops.bias_act_bwd(gz, ys[-1], last_act, dz, None)
+            gz = dz
+        for li in range(len(layers) - 1, -1, -1):
+            lin = layers[li][0]
+            x = x0 if li == 0 else ys[li - 1]
+            hip_ops.linear_bwd_weight(gz, x, lin.weight.grad, lin.bias.grad)
+            if li > 0:
+                gz = hip_ops.linear_bwd_input(gz, lin.weight, ys[li - 1], layers[li - 1][1])
+        return (None,) * len(ctx.needs_input_grad)
+
+
+class FastActorGroup:
+    """Every agent's deterministic actor MLP (identical architectures, parameters in per-agent arena slices) evaluated layer by
+    layer with ONE launch per layer (cstr_linear_act_fwd_sets_f32) instead of one chain per agent; the last layer writes each
+    agent's action into its column block of the caller's buffer (joint action / joint critic input): no torch.cat."""
+
+    def __init__(self, mlps: List["FastMLP"]):
+        self.mlps = mlps
+
+    @staticmethod
+    def supported(mlps: List["FastMLP"]) -> bool:
+        if not USE_FUSED_LINEAR or not 1 < len(mlps) <= hip_ops.nv.MAX_LINEAR_SETS:
+            return False
+        sig = lambda m: [(l.in_features, l.out_features, a) for l, a in m.layers]  # noqa: E731
+        return all(sig(m) == sig(mlps[0]) for m in mlps[1:])
+
+    def _run(self, inputs, out, col_ranges, keep: Optional[int] = None):
+        n_layers = len(self.mlps[0].layers)
+        hs, kept = list(inputs), []
+        m = inputs[0].shape[0]
+        for li in range(n_layers):
+            act = self.mlps[0].layers[li][1]
+            n = self.mlps[0].layers[li][0].out_features
+            last = li == n_layers - 1
+            if last:
+                ys = [out[:, lo:hi] for lo, hi in col_ranges]
+                if keep is not None:  # the differentiated agent's output is also needed contiguously by its backward
+                    ys[keep] = th.empty(m, n, dtype=out.dtype, device=out.device)
+            else:
+                buf = th.empty(len(self.mlps), m, n, dtype=out.dtype, device=out.device)
+                ys = [buf[j] for j in range(len(self.mlps))]
+            hip_ops.linear_act_fwd_sets([(hs[j], self.mlps[j].layers[li][0].weight, self.mlps[j].layers[li][0].bias, ys[j])
+                                         for j in range(len(self.mlps))], act)
+            if keep is not None:
+                kept.append(ys[keep])
+                if last:
+                    lo, hi = col_ranges[keep]
+                    out[:, lo:hi].copy_(ys[keep])
+            hs = ys
+        return kept
+
+    def forward(self, inputs, out: th.Tensor, col_ranges, grad_agent: Optional[int] = None) -> th.Tensor:
+        """inputs[j] [M, K0] (row-strided views ok); out [M, W]; agent j's action -> out[:, col_ranges[j][0]:col_ranges[j][1]].
+        grad_agent = i: agent i's parameters receive gradients (written into their arena views) through the returned buffer."""
+        if grad_agent is None or not th.is_grad_enabled():
+            with th.no_grad():
+                self._run(inputs, out, col_ranges)
+            return out
+        owners = [l.weight for l, _ in self.mlps[grad_agent].layers]
+        return _ActorGroupFn.apply(out, self, list(inputs), list(col_ranges), grad_agent, *owners)
+
+
 class _SquashedGaussianFn(th.autograd.Function):
     """`params` is either (mean, log_std_raw) as two [B, A] tensors or ONE merged-head GEMM output [B, 2A]."""
 

@@ -391,6 +391,25 @@ def linear_act_fwd(x, weight, bias, act: int, out=None):
     return y
 
 
+def linear_act_fwd_sets(sets, act: int):
+    """Several independent Linear + bias + activation layers of ONE shape in one launch. `sets`: [(x [M, K] (row-strided ok),
+    weight [N, K], bias [N], y [M, N] (row-strided ok: e.g. a column block of the joint action))]."""
+    sets = list(sets)
+    if not 0 < len(sets) <= nv.MAX_LINEAR_SETS:
+        raise ValueError(f"1..{nv.MAX_LINEAR_SETS} sets, got {len(sets)}")
+    m, k = sets[0][0].shape
+    n = sets[0][1].shape[0]
+    arr = (nv.LinearSet * len(sets))()
+    for i, (x, w, b, y) in enumerate(sets):
+        for t, nm, shape in ((x, "x", (m, k)), (y, "y", (m, n))):
+            if not (t.is_cuda and t.dtype == th.float32 and tuple(t.shape) == shape and t.stride(1) == 1):
+                raise ValueError(f"{nm}[{i}]: needs a float32 device matrix {shape} with unit column stride")
+        _chk(w, f"weight[{i}]", (n, k), th.float32), _chk(b, f"bias[{i}]", (n,), th.float32)
+        arr[i] = nv.LinearSet(x.data_ptr(), max(x.stride(0), k), w.data_ptr(), b.data_ptr(), y.data_ptr(), max(y.stride(0), n))
+    check(nv.lib().cstr_linear_act_fwd_sets_f32(arr, C.c_int(len(sets)), C.c_int(act), C.c_int64(m), C.c_int64(n), C.c_int64(k),
+                                                stream_ptr()), "cstr_linear_act_fwd_sets_f32")
+
+
 def linear_bwd_input(gz, weight, y, act: int, sum_groups: bool = False):
     """dz = (gz @ W) * act'(y): a Linear's input gradient fused with the activation gradient of the layer below (whose output
     y is this layer's input). gz [M, N] / [G, M, N], weight [N, K] / [G, N, K] contiguous. sum_groups: the G groups share one

@@ -106,9 +106,15 @@ class MADDPG(OffPolicyAlgorithm):
         pol = self.policy
         self.fused_learner = (all(fused.FastMLP.supported(m) for m in self.actor.mu_list)
                               and all(fused.FastMLP.supported(q) for nets in self.critic.q_networks_list for q in nets))
+        self._actor_group = self._actor_target_group = None
         if self.fused_learner:
             self._fast_actors = [fused.FastMLP(m) for m in self.actor.mu_list]
             self._fast_actor_targets = [fused.FastMLP(m) for m in self.actor_target.mu_list]
+            # all agents' actors layer by layer in ONE launch per layer (identical architectures, contiguous column slices)
+            ranges_ok = all(self.actor._range(k, i) is not None for k in ("obs", "act") for i in range(self.n_agents))
+            grouped = ranges_ok and self.actor._tiles_in_order("act") and fused.FastActorGroup.supported(self._fast_actors)
+            self._actor_group = fused.FastActorGroup(self._fast_actors) if grouped else None
+            self._actor_target_group = fused.FastActorGroup(self._fast_actor_targets) if grouped else None
 
             class _Nets:  # FastTwinCritic reads `.q_networks`
                 def __init__(self, nets):
@@ -124,6 +130,17 @@ class MADDPG(OffPolicyAlgorithm):
                                  "pass faithful_quirks=False for per-agent slices")
 
     # ---- acting ---------------------------------------------------------------------------------------------------
+    def _policy_out_device(self, obs: th.Tensor) -> th.Tensor:
+        """Joint action for the fused collect kernel: every agent's actor on its own observation slice (policies.py:87)."""
+        group = getattr(self, "_actor_group", None)
+        if group is None:
+            return super()._policy_out_device(obs)
+        A = self.actor
+        out = th.empty(obs.shape[0], self.action_space.shape[0], dtype=th.float32, device=obs.device)
+        group.forward([A._agent_obs_tensor_extract(j, obs) for j in range(self.n_agents)], out,
+                      [A._range("act", j) for j in range(self.n_agents)])
+        return out
+
     def _action_mode(self, warmup: bool) -> int:
         if not self.faithful_quirks:
             return super()._action_mode(warmup)
@@ -167,7 +184,7 @@ class MADDPG(OffPolicyAlgorithm):
 
     def _packed_batch(self, batch_size: int):
         if self._packed is None or self._packed.x_data.shape[0] != batch_size:
-            self._packed = self.replay_buffer.alloc_packed_batch(batch_size, with_pi=False)
+            self._packed = self.replay_buffer.alloc_packed_batch(batch_size, with_pi=True)  # x_pi = (obs | .) for the actor step
             self._static_batch = self._packed.samples
             self._target_q = [th.empty(batch_size, 1, dtype=th.float32, device=self.device) for _ in range(self.n_agents)]
         return self._packed
@@ -282,7 +299,18 @@ class MADDPG(OffPolicyAlgorithm):
             self._g_bufs = th.empty(2, B, 1, device=self.device)
         gq = self._g_bufs
         shared_next = shared_cur = None
-        if pb is not None:
+        if pb is not None and self._actor_target_group is not None:
+            with th.no_grad():  # :131-144: every target actor per layer in one launch, ONE smoothing launch for the joint action
+                a_t = th.empty(B, pb.act_dim, dtype=th.float32, device=self.device)
+                self._actor_target_group.forward([A._agent_obs_tensor_extract(i, rd.next_observations) for i in range(self.n_agents)],
+                                                 a_t, [C._range("act", i) for i in range(self.n_agents)])
+                queued = None
+                if self.noise_queue:  # teacher-forced: one tensor per agent, in agent order
+                    queued = th.cat([self.noise_queue.pop(0).to(self.device, th.float32) for _ in range(self.n_agents)], dim=1).contiguous()
+                hip_ops.target_smooth(a_t, queued, None if queued is not None else self._device_rng(), self.target_policy_noise,
+                                      self.target_noise_clip, pb.x_next[:, pb.obs_dim:])
+            shared_next, shared_cur = pb.x_next, pb.x_data
+        elif pb is not None:
             with th.no_grad():  # :131-144, one smoothing launch per agent, written into x_next's action columns
                 for i in range(self.n_agents):
                     a_t = self._fast_actor_targets[i](A._agent_obs_tensor_extract(i, rd.next_observations), train_params=False)
@@ -326,15 +354,22 @@ class MADDPG(OffPolicyAlgorithm):
             actor_loss_now = None
             if n_updates % self.policy_delay == 0:  # :167-185
                 agent_obs = A._agent_obs_tensor_extract(i, rd.observations)
-                if self.faithful_quirks:  # Q2: every agent's actor sees agent i's observation slice
-                    acts = [self._fast_actors[j](agent_obs, train_params=(j == i)) for j in range(self.n_agents)]
+                if pb is not None and self._actor_group is not None:
+                    # every agent's actor per layer in one launch, actions written into the critic input's columns (no cat);
+                    # Q2: every actor sees agent i's observation slice in the reference
+                    ins = [agent_obs if self.faithful_quirks else A._agent_obs_tensor_extract(j, rd.observations) for j in range(self.n_agents)]
+                    cols = [(pb.obs_dim + lo, pb.obs_dim + hi) for lo, hi in (C._range("act", j) for j in range(self.n_agents))]
+                    x_pi = self._actor_group.forward(ins, pb.x_pi.detach(), cols, grad_agent=i)
                 else:
-                    acts = [self._fast_actors[j](A._agent_obs_tensor_extract(j, rd.observations), train_params=(j == i))
-                            for j in range(self.n_agents)]
-                if pb is not None:  # (obs | all agents' actions) in ONE cat
-                    x_pi = th.cat([rd.observations] + acts, dim=1)
-                else:
-                    x_pi = C._input(i, rd.observations, th.cat(acts, dim=-1))
+                    if self.faithful_quirks:  # Q2: every agent's actor sees agent i's observation slice
+                        acts = [self._fast_actors[j](agent_obs, train_params=(j == i)) for j in range(self.n_agents)]
+                    else:
+                        acts = [self._fast_actors[j](A._agent_obs_tensor_extract(j, rd.observations), train_params=(j == i))
+                                for j in range(self.n_agents)]
+                    if pb is not None:  # (obs | all agents' actions) in ONE cat
+                        x_pi = th.cat([rd.observations] + acts, dim=1)
+                    else:
+                        x_pi = C._input(i, rd.observations, th.cat(acts, dim=-1))
                 qs_pi = self._fast_critics[i].forward_input(x_pi, train_params=False, only_first=True)
                 hip_ops.neg_mean_loss(qs_pi[0], gq[0], self._loss_now, self._loss_sums[f"actor{i}"])
                 fused.backward_q(qs_pi, gq)

@@ -200,6 +200,63 @@ __global__ __launch_bounds__(64 * WAVES) void linear_act_fwd_kernel(const float 
     }
 }
 
+// Pointer-table form: up to CSTR_MAX_LINEAR_SETS independent Linear layers of one shape -- every agent's actor layer in
+// MADDPG (core/maddpg/policies.py: one MLP per agent, parameters in per-agent arena slices) -- in ONE launch. Each set has
+// its own input, weight, bias and output; the output may be a column block of a wider row (the joint action).
+struct LinearSets { cstr_linear_set_t s[CSTR_MAX_LINEAR_SETS]; };
+
+template <int ACT, bool VEC, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void linear_act_fwd_sets_kernel(const LinearSets sets, const int M, const int N, const int K)
+{
+    __shared__ f32x4 part[WAVES > 1 ? WAVES - 1 : 1][64];
+    const cstr_linear_set_t &st = sets.s[blockIdx.z];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, h = lane >> 4;
+    const int n0 = blockIdx.x * 16, m0 = blockIdx.y * 16;
+    const float *xr = st.x + (int64_t)(m0 + r) * st.ldx;
+    const float *wr = st.w + (int64_t)(n0 + r) * K;
+    const bool row_ok = m0 + r < M, col_ok = n0 + r < N;
+    f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
+    constexpr int UNROLL = 4;
+    for (int c0 = 16 * wave; c0 < K; c0 += 16 * WAVES * UNROLL) {
+        float4 a[UNROLL], b[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const int k = c0 + 16 * WAVES * u + 4 * h;
+            a[u] = load_k4<VEC>(xr, k, K, row_ok);
+            b[u] = load_k4<VEC>(wr, k, K, col_ok);
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].x, b[u].x, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].y, b[u].y, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].z, b[u].z, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].w, b[u].w, acc1, 0, 0, 0);
+        }
+    }
+    f32x4 acc = acc0 + acc1;
+    if (WAVES > 1) {
+        if (wave > 0) part[wave - 1][lane] = acc;
+        __syncthreads();
+        if (wave > 0) return;
+#pragma unroll
+        for (int v = 0; v < WAVES - 1; ++v) acc += part[v][lane];
+    }
+    const int col = n0 + r;
+    if (col < N) {
+        const float bv = st.bias[col];
+        float *yo = st.y + (int64_t)(m0 + 4 * h) * st.ldy + col;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (m0 + 4 * h + e < M) {
+                float v = acc[e] + bv;
+                if (ACT == ACT_RELU) v = fmaxf(v, 0.0f);
+                if (ACT == ACT_TANH) v = tanhf(v);
+                yo[(int64_t)e * st.ldy] = v;
+            }
+        }
+    }
+}
+
 // Input gradient of a Linear fused with the activation gradient of the layer BELOW it:
 //   dz[m][k] = (sum_n gz[m][n] * W[n][k]) * act'(y[m][k])
 // where y = act(...) is the lower layer's output (= this layer's input): the rocBLAS dX GEMM and the element-wise pass of
@@ -1047,5 +1104,31 @@ extern "C" int cstr_gaussian_head_gemm_fwd_f32(const float *hidden, int64_t ldh,
     if (g > 0x7fffffff) return CSTR_E_UNSUPPORTED;
     gaussian_head_gemm_fwd_kernel<<<(unsigned)g, 64 * rows_per_wg, 0, (hipStream_t)stream>>>(hidden, (int)ldh, w, bias, params, eps, rng_ctl, action,
                                                                                 action_stride, logp, batch, act_dim, (int)k);
+    return (int)hipGetLastError();
+}
+
+extern "C" int cstr_linear_act_fwd_sets_f32(const cstr_linear_set_t *sets, int n_sets, int act, int64_t m, int64_t n, int64_t k,
+                                            cstr_stream_t stream)
+{
+    if (!sets || n_sets <= 0 || m <= 0 || n <= 0 || k <= 0) return CSTR_E_BADARG;
+    if (n_sets > CSTR_MAX_LINEAR_SETS || act < 0 || act > 2 || m > 0x7fffff || n > 0x7fffff || k > 0x7fffff || (m + 15) / 16 > 65535)
+        return CSTR_E_UNSUPPORTED;
+    LinearSets t;
+    bool vec = (k & 3) == 0;
+    for (int i = 0; i < n_sets; ++i) {
+        const cstr_linear_set_t &q = sets[i];
+        if (!q.x || !q.w || !q.bias || !q.y || q.ldx < k || q.ldy < n) return CSTR_E_BADARG;
+        vec = vec && (q.ldx & 3) == 0 && aligned16(q.x) && aligned16(q.w);
+        t.s[i] = q;
+    }
+    const dim3 grid((unsigned)((n + 15) / 16), (unsigned)((m + 15) / 16), (unsigned)n_sets);
+    const bool split = k > 32 && (int64_t)grid.x * grid.y * grid.z <= 2048;
+    hipStream_t s = (hipStream_t)stream;
+#define LIN(A, V, W) linear_act_fwd_sets_kernel<A, V, W><<<grid, 64 * W, 0, s>>>(t, (int)m, (int)n, (int)k)
+#define LIN_ACT(V, W) do { if (act == 0) LIN(0, V, W); else if (act == 1) LIN(1, V, W); else LIN(2, V, W); } while (0)
+    if (vec) { if (split) LIN_ACT(true, 4); else LIN_ACT(true, 1); }
+    else { if (split) LIN_ACT(false, 4); else LIN_ACT(false, 1); }
+#undef LIN_ACT
+#undef LIN
     return (int)hipGetLastError();
 }

@@ -444,3 +444,42 @@ def test_gaussian_head_with_its_linear_inside(ops, B, A, K):
     hip_ops.gaussian_head_fwd_(th.mm(h, w.t()), bias, e2, c2, a2, None)
     assert th.equal(e1, e2) and th.equal(c1, c2) and int(c1[1]) == B
     assert rel_err(a1.cpu().numpy(), a2.cpu().numpy(), 1.0) < 5e-6
+
+
+def test_grouped_actor_forward_and_single_agent_backward(ops):
+    """FastActorGroup (cstr_linear_act_fwd_sets_f32): four agents' actor MLPs, one launch per layer, actions written into the
+    column blocks of a joint buffer; one agent differentiated -- against the per-agent nn.Modules and autograd."""
+    from core.common import fused
+    from core.common.arena import ParamArena
+    from core.common.torch_layers import create_mlp
+
+    th.manual_seed(0)
+    n_agents, M, K0, D = 4, 96, 2, 8
+    seqs = [th.nn.Sequential(*create_mlp(K0, 1, [40, 24], th.nn.ReLU, squash_output=True)) for _ in range(n_agents)]
+    refs = [th.nn.Sequential(*create_mlp(K0, 1, [40, 24], th.nn.ReLU, squash_output=True)).cuda() for _ in range(n_agents)]
+    arena = ParamArena([p for sq in seqs for p in sq.parameters()], "cuda")
+    for sq, rf in zip(seqs, refs):
+        rf.load_state_dict({k: v.detach().clone() for k, v in sq.state_dict().items()})
+    mlps = [fused.FastMLP(sq) for sq in seqs]
+    assert fused.FastActorGroup.supported(mlps)
+    group = fused.FastActorGroup(mlps)
+    obs = th.randn(M, D, device="cuda")
+    ins = [obs[:, 2 * j:2 * j + 2] for j in range(n_agents)]
+    cols = [(D + j, D + j + 1) for j in range(n_agents)]
+    x = th.full((M, D + n_agents), 3.0, device="cuda")
+    group.forward(ins, x, cols)  # no gradient
+    want = th.cat([rf(i) for rf, i in zip(refs, ins)], dim=1)
+    assert rel_err(x[:, D:].cpu().numpy(), want.detach().cpu().numpy(), 1.0) < 2e-6 and float(x[:, :D].min()) == 3.0
+    agent = 2
+    arena.grad.fill_(5.0)
+    x2 = th.full((M, D + n_agents), 3.0, device="cuda")
+    out = group.forward(ins, x2, cols, grad_agent=agent)
+    assert out.requires_grad and rel_err(out[:, D:].detach().cpu().numpy(), want.detach().cpu().numpy(), 1.0) < 2e-6
+    g = th.randn(M, D + n_agents, device="cuda")
+    out.backward(g)
+    want[:, agent:agent + 1].backward(g[:, D + agent:D + agent + 1])
+    for (nm, p), (_, q) in zip(seqs[agent].named_parameters(), refs[agent].named_parameters()):
+        scale = max(1e-2, float(q.grad.abs().mean()))
+        assert rel_err(p.grad.cpu().numpy(), q.grad.cpu().numpy(), scale) < 2e-5, nm
+    others = [p for j, sq in enumerate(seqs) if j != agent for p in sq.parameters()]
+    assert all(bool((p.grad == 5.0).all()) for p in others)  # frozen agents' gradient views untouched
