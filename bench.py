@@ -33,6 +33,7 @@ for _p in (ROOT, os.path.join(ROOT, "pytorch-rl-enhancedstablebaselines_amd")):
 import numpy as np  # noqa: E402
 import torch as th  # noqa: E402
 
+F32_MFMA_PEAK_TFLOPS = 157.3  # dense f32-input MFMA, MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s measured achievable)
 
 
@@ -201,6 +202,19 @@ def other_kernels(model, batch):
     ent = th.ones(1, device=p.device)
     us = event_time_us(lambda: hip_ops.td_target_min(q, q, q, q, q, ent, 0.99, o), 200, stream, in_graph=True)
     out["td_target_min_kernel"] = dict(launch_us=round(us, 3), batch=batch, gbs=round(24 * batch / us / 1e3, 3))
+    # the MFMA Linear kernels at the learners' hidden-layer shape (batch x 256 x 256): latency-bound, a few per cent of the
+    # f32 matrix-core peak (157.3 TFLOP/s: v_mfma_f32_16x16x4_f32 at 64 FLOP/clk/SIMD, MI355X_MICROARCH.md)
+    h = 256
+    x, w, bias = th.randn(batch, h, device=p.device), th.randn(h, h, device=p.device) / 16, th.zeros(h, device=p.device)
+    gz, y = th.randn(batch, h, device=p.device), th.relu(th.randn(batch, h, device=p.device))
+    dw, db = th.empty(h, h, device=p.device), th.empty(h, device=p.device)
+    flops = 2.0 * batch * h * h
+    for name, fn in (("linear_act_fwd_kernel", lambda: hip_ops.linear_act_fwd(x, w, bias, 1)),
+                     ("linear_bwd_input_kernel", lambda: hip_ops.linear_bwd_input(gz, w, y, 1)),
+                     ("linear_bwd_weight_kernel", lambda: hip_ops.linear_bwd_weight(gz, x, dw, db))):
+        us = event_time_us(fn, 200, stream, in_graph=True)
+        out[name] = dict(launch_us=round(us, 3), shape=[batch, h, h], bound="mfma", tflops=round(flops / us / 1e6, 2),
+                         frac=round(flops / us / 1e6 / F32_MFMA_PEAK_TFLOPS, 4))
     return out
 
 
