@@ -759,3 +759,36 @@ def test_td3_ddpg_fused_path_equals_stock_aten_path_across_configurations(algo, 
         scale = max(float(p2.detach().abs().max()), 1e-3)
         assert float((p1 - p2).detach().abs().max()) < 2e-5 * scale + 2e-6, n1
     assert a._n_updates == b._n_updates == n_calls
+
+
+def test_reference_td3_cstr_recipe_runs_and_keeps_the_numpy_stream():
+    """The reference's own CSTR script (experiments/basic_test/TwoSeriesCSTR_TD3.py:28-75): one TwoSeriesCSTREnv(init_mode=
+    "static") in a DummyVecEnv, TD3 with NormalActionNoise(0, 0.1), lr 3e-4, buffer 1e5, batch 256, policy_delay 2, target
+    noise 0.2 / 0.5, seed 42 -- shortened (learning_starts 300 instead of 5000, 700 steps). The global legacy stream must end
+    where numpy's would: one normal pair per step, two randint draws per gradient step."""
+    from core import TD3
+    from core.common import legacy_rng
+    from core.common.noise import NormalActionNoise
+    from core.common.vec_env import DummyVecEnv
+    from twoseriescstr import TwoSeriesCSTREnv
+
+    vec_env = DummyVecEnv([lambda: TwoSeriesCSTREnv(init_mode="static")])
+    n_actions = vec_env.action_space.shape[0]
+    model = TD3(policy="MlpPolicy", env=vec_env, learning_rate=3e-4, buffer_size=int(1e5), learning_starts=300, batch_size=256, tau=0.005,
+                gamma=0.99, train_freq=(1, "step"), gradient_steps=1, action_noise=NormalActionNoise(mean=np.zeros(n_actions), sigma=0.1 * np.ones(n_actions)),
+                policy_delay=2, target_policy_noise=0.2, target_noise_clip=0.5, verbose=0, device="auto", seed=42)
+    steps = 700
+    model.learn(total_timesteps=steps)
+    assert model.num_timesteps == steps and model._n_updates == steps - 300 and vec_env.init_mode == "static"
+    rs = np.random.RandomState(42)  # n_envs = 1: seed + n_envs - 1
+    for k in range(1, steps + 1):
+        rs.normal(np.zeros(2), 0.1 * np.ones(2))
+        if k > 300:
+            rs.randint(0, k, size=256)
+            rs.randint(0, 1, size=256)
+    st, w = rs.get_state(), legacy_rng.global_stream(model.device).cpu().numpy().view(np.uint32)
+    np.testing.assert_array_equal(w[:624], st[1])
+    assert (int(w[624]), int(w[625])) == (st[2], st[3])
+    assert int(vec_env.step_count[0]) == steps - 400 and float(vec_env.static_init.abs().sum()) > 0  # one reset at step 400
+    for p in model.policy.parameters():
+        assert th.isfinite(p).all()
