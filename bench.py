@@ -299,6 +299,10 @@ def north_star_variant(n_envs: int, device: str, graph: bool, obs_dim: int = 8, 
 
 def main():
     args = parse()
+    # stdout carries exactly ONE line, the JSON result: libraries that print to fd 1 (RCCL's version banner on rank 0) go to stderr
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
     from core.common import distributed as dist_util
 
     # rehearsal knobs (a 1-GPU box): CSTR_DIST_BACKEND=gloo + CSTR_BENCH_SINGLE_DEVICE=1 run N ranks on cuda:0 over gloo, which
@@ -331,6 +335,16 @@ def main():
         env = CSTRVecEnv(N, obs_dim=args.obs_dim, integrator=args.integrator, device=f"cuda:{local_rank}")
         cls = SAC if args.algo == "sac" else TD3
         model = cls("MlpPolicy", env, seed=0, device=f"cuda:{local_rank}")  # class defaults: buffer 1e6 -> 244 rows x 4096
+    if os.environ.get("CSTR_BENCH_FORCE_DP") == "1" and world == 1:
+        # rehearsal knob (a 1-GPU box): the N > 1 launch structure -- graph segments with an RCCL all-reduce on each gradient
+        # arena between them -- in a world of one rank: measures what segmentation + the process group's enqueue cost
+        th.distributed.init_process_group("nccl", init_method="tcp://127.0.0.1:29533", rank=0, world_size=1,
+                                          device_id=th.device("cuda", local_rank))
+        dist_util.is_distributed = lambda: True
+        model._force_segment_boundaries = True
+        if os.environ.get("CSTR_GRAPH_COLLECTIVES", "auto") == "auto":
+            model._graph_collectives = dist_util.graph_collectives_ok(model.device)  # the start-up trial itself
+            print(f"[bench] collectives inside the graph: {model._graph_collectives}", file=sys.stderr)
     total = (args.warmup + args.steps) * N
     _, callback = model._setup_learn(total, NoopCallback(), True, "bench", False)
     use_graph = bool(args.graph)  # world > 1: graph segments with the RCCL all-reduces between them
@@ -391,9 +405,10 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(N, B, args.cpu_seconds)
             line["speedup_vs_cpu_port"] = round(value / line["cpu_baseline"]["value"], 2)
-        print(json.dumps(line), flush=True)
+        os.write(result_fd, (json.dumps(line) + "\n").encode())
     if world > 1:
         th.distributed.barrier()
+    if th.distributed.is_initialized():
         th.distributed.destroy_process_group()
 
 

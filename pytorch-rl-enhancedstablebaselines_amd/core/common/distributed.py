@@ -7,9 +7,12 @@ scale is folded into the Adam kernel (`grad_scale`), so gradient averaging costs
 Message sizes are tiny (SAC: 543 KB critic + entropy coefficient, 272 KB actor per step): the collective is
 latency-bound, not xGMI link-bound, so the two dependent all-reduces are issued as-is on the training stream and
 RCCL picks its low-latency (tree / one-shot) protocol; no bucketing beyond the per-optimiser arena is useful.
-Under hipGraph replay the collectives stay outside the graphs (OffPolicyAlgorithm._capture_segments).
+Under hipGraph replay the collectives are recorded into the iteration's graph when `graph_collectives_ok` (a start-up
+capture-and-replay trial on every rank) passes, and stay between graph segments otherwise
+(OffPolicyAlgorithm._capture_segments; CSTR_GRAPH_COLLECTIVES=auto|0|1).
 """
 import os
+import sys
 from typing import Optional, Tuple
 
 import torch as th
@@ -57,6 +60,48 @@ def allreduce_sum_(flat: th.Tensor) -> th.Tensor:
     if is_distributed():
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)
     return flat
+
+
+_GRAPH_COLLECTIVES_OK = None
+
+
+def graph_collectives_ok(device) -> bool:
+    """Start-up trial for recording collectives into hipGraphs: capture ONE all-reduce, replay it twice and check the sums on
+    every rank; all ranks agree on the verdict (MIN all-reduce). Only the RCCL backend on a GPU qualifies. Must be called by
+    every rank, outside any capture."""
+    global _GRAPH_COLLECTIVES_OK
+    if _GRAPH_COLLECTIVES_OK is not None:
+        return _GRAPH_COLLECTIVES_OK
+    device = th.device(device)
+    if not is_distributed() or dist.get_backend() != "nccl" or device.type != "cuda":
+        _GRAPH_COLLECTIVES_OK = False
+        return False
+    rank, world = dist.get_rank(), dist.get_world_size()
+    ok = True
+    try:
+        with th.cuda.device(device):
+            t = th.zeros(4096, dtype=th.float32, device=device)
+            dist.all_reduce(t)  # the communicator and its buffers exist before anything is recorded
+            th.cuda.synchronize(device)
+            side, g = th.cuda.Stream(device=device), th.cuda.CUDAGraph()
+            side.wait_stream(th.cuda.current_stream(device))
+            with th.cuda.stream(side):
+                g.capture_begin(capture_error_mode="thread_local")
+                dist.all_reduce(t)
+                g.capture_end()
+            th.cuda.current_stream(device).wait_stream(side)
+            for k in (1.0, 3.0):
+                t.fill_(k * (rank + 1))
+                g.replay()
+                th.cuda.synchronize(device)
+                ok = ok and bool((t == k * world * (world + 1) / 2).all())
+    except Exception as exc:  # noqa: BLE001 -- any failure means "keep the collectives between graph segments"
+        print(f"[distributed] collectives stay outside hipGraphs: {exc!r}", file=sys.stderr)
+        ok = False
+    verdict = th.tensor([1.0 if ok else 0.0], device=device)
+    dist.all_reduce(verdict, op=dist.ReduceOp.MIN)
+    _GRAPH_COLLECTIVES_OK = bool(verdict.item() == 1.0)
+    return _GRAPH_COLLECTIVES_OK
 
 
 def broadcast_(t: th.Tensor, src: int = 0) -> th.Tensor:

@@ -26,6 +26,11 @@ from core.common.type_aliases import RolloutReturn, TrainFreq, TrainFrequencyUni
 from core.common.utils import should_collect_more_steps
 from core.common.vec_env import CSTRVecEnv, VecEnv
 
+# Data-parallel runs under hipGraph replay. "auto" (default): record the RCCL all-reduces INTO the iteration's graph when a
+# start-up trial (distributed.graph_collectives_ok: capture + replay of one all-reduce, result checked on every rank) passes,
+# else run them eagerly BETWEEN graph segments; "0": always between segments; "1": always inside (no trial).
+GRAPH_COLLECTIVES = os.environ.get("CSTR_GRAPH_COLLECTIVES", "auto")
+
 
 class OffPolicyAlgorithm(BaseAlgorithm):
     def __init__(self, policy, env, learning_rate, buffer_size: int = 1_000_000, learning_starts: int = 100,
@@ -279,14 +284,15 @@ class OffPolicyAlgorithm(BaseAlgorithm):
 
     def _capture_segments(self, unroll: int = 1) -> list:
         """Record the iteration as hipGraph segments. A data-parallel run has an RCCL all-reduce between backward and
-        the optimiser step (three per SAC gradient step); collectives stay OUTSIDE the captured graphs -- every
-        `_eager_boundary` closes the current segment, runs the collective eagerly and opens the next segment in the same
-        memory pool (activations saved for a later segment's backward stay alive). Single-GPU runs have no boundary and
-        get one graph. Nothing executes while recording."""
+        the optimiser step (two per SAC gradient step). When the start-up trial passes (`_collectives_in_graph`) they are
+        recorded into the graph; otherwise collectives stay OUTSIDE the captured graphs -- every `_eager_boundary` closes the
+        current segment, runs the collective eagerly and opens the next segment in the same memory pool (activations saved
+        for a later segment's backward stay alive). Single-GPU runs have no boundary and get one graph."""
         import gc
 
         # like torch.cuda.graph(): collect garbage BEFORE recording and keep the collector off while recording -- a cycle
         # collection that destroys another model's CUDAGraph (or frees device memory) in the middle of a capture aborts
+        self._collectives_in_graph()  # decided (start-up trial, world > 1) before anything is being recorded
         gc.collect()
         gc_was_enabled = gc.isenabled()
         gc.disable()
@@ -319,10 +325,20 @@ class OffPolicyAlgorithm(BaseAlgorithm):
         th.cuda.synchronize(self.device)
         return items
 
+    def _collectives_in_graph(self) -> bool:
+        if getattr(self, "_graph_collectives", None) is None:
+            if GRAPH_COLLECTIVES in ("0", "1"):
+                self._graph_collectives = GRAPH_COLLECTIVES == "1"
+            else:
+                self._graph_collectives = self.world_size > 1 and dist_util.graph_collectives_ok(self.device)
+        return self._graph_collectives
+
     def _eager_boundary(self, fn) -> None:
         """Run `fn` (a collective) eagerly; when a capture is in progress, split the graph around it."""
         cap = getattr(self, "_cap", None)
-        if cap is None:
+        if cap is None or self._collectives_in_graph():
+            # no capture in progress, or the collective is recorded into the graph like any other launch (RCCL issues a
+            # blocking collective on the current stream) and the iteration stays ONE graph
             fn()
             return
         cap["graph"].capture_end()
