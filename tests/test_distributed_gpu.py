@@ -65,3 +65,52 @@ def test_two_ranks_one_gpu_stay_in_sync(tmp_path, use_graph):
     assert not th.equal(r0["obs"], r1["obs"]) and not th.equal(r0["ring_obs"], r1["ring_obs"])  # different env shards
     assert not th.equal(r0["mt"], r1["mt"])
     assert r0["sampler_seed"] == 11 + 64 - 1 and r1["sampler_seed"] == 11 + 64 + 64 - 1  # seed_r + n_envs - 1
+
+
+def _rccl_worker(rank, port, out_dir):
+    import sys
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    root = os.path.dirname(here)
+    for p in (root, os.path.join(root, "pytorch-rl-enhancedstablebaselines_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    from core.common import distributed as du
+    from core.common.vec_env import CSTRVecEnv
+    from core.sac import SAC
+
+    th.cuda.set_device(0)
+    th.distributed.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                                      device_id=th.device("cuda", 0))
+    du.is_distributed = lambda: True  # a world of one rank still issues its all-reduces (through RCCL)
+    assert du.graph_collectives_ok("cuda:0")  # the start-up trial: capture + replay of an RCCL all-reduce
+    N, B, iters, out = 64, 32, 14, {}
+    for mode in ("eager", "segmented", "in_graph"):
+        env = CSTRVecEnv(N, device="cuda:0")
+        model = SAC("MlpPolicy", env, seed=5, batch_size=B, buffer_size=N * 8, learning_starts=100, device="cuda:0",
+                    policy_kwargs=dict(net_arch=[32, 32]))
+        model._force_segment_boundaries = True  # the data-parallel launch structure
+        model._graph_collectives = mode == "in_graph"
+        model.enable_graph_capture(mode != "eager")
+        model.learn(N * iters)
+        th.cuda.synchronize()
+        if mode != "eager":
+            (segs,) = model._graph.values()
+            assert sum(isinstance(s, th.cuda.CUDAGraph) for s in segs) == (1 if mode == "in_graph" else 3)
+        out[mode] = dict(actor=model.policy.actor_arena.flat.cpu(), critic=model.policy.critic_arena.flat.cpu(),
+                         alpha=model.log_ent_coef.detach().cpu(), obs=env.obs.cpu(), n_updates=model._n_updates)
+    th.save(out, os.path.join(out_dir, "rccl.pt"))
+    th.distributed.destroy_process_group()
+
+
+def test_collectives_inside_the_graph_match_segmented_and_eager(tmp_path):
+    """The N > 1 launch structure in an RCCL world of ONE rank (all this box can hold): the all-reduces recorded INTO the
+    iteration graph (after the start-up trial passed) train bit-identically to collectives between graph segments and to
+    the eager loop."""
+    mp.spawn(_rccl_worker, args=(_free_port(), str(tmp_path)), nprocs=1, join=True)
+    out = th.load(tmp_path / "rccl.pt")
+    for mode in ("segmented", "in_graph"):
+        assert out[mode]["n_updates"] == out["eager"]["n_updates"] == 13
+        for k in ("actor", "critic", "alpha", "obs"):
+            assert th.equal(out[mode][k], out["eager"][k]), (mode, k)
