@@ -314,6 +314,15 @@ int cstr_gaussian_head_bwd_f32(const float *g_action, int64_t ga_stride, const f
                                int64_t action_stride, const float *params, const float *eps, float *g_params, float *g_bias,
                                int64_t batch, int act_dim, cstr_stream_t stream);
 
+/* The same backward carried one layer further when the head's Linear (w [2A][width], core/sac/policies.py:100-104) sits on
+ * a hidden layer with activation `act` (0 none, 1 ReLU, 2 Tanh) whose OUTPUT is `hidden` (rows ldh floats apart):
+ * g_params as above and dz [B][width] = (g_params . w) * act'(hidden) = d(loss)/d(that layer's pre-activation), the input
+ * of cstr_linear_bwd_weight_f32 / cstr_linear_bwd_input_f32. The head's dW / db: cstr_linear_bwd_weight_f32(g_params, hidden). */
+int cstr_gaussian_head_bwd_input_f32(const float *g_action, int64_t ga_stride, const float *g_logp, const float *action,
+                                     int64_t action_stride, const float *params, const float *eps, const float *w,
+                                     const float *hidden, int64_t ldh, int act, float *g_params, float *dz, int64_t batch,
+                                     int act_dim, int64_t width, cstr_stream_t stream);
+
 /* TD3 / MADDPG target policy smoothing (core/td3/td3.py:167-173; core/maddpg/maddpg.py:131-142) in one launch:
  * noise = clamp(N(0, sigma), -clip, clip); out = clamp(action + noise, -1, 1). action [B][A] contiguous (the target
  * actor's output); `noise` [B][A] (already scaled by sigma) is read when rng_ctl is NULL, otherwise sigma * N(0,1) is drawn

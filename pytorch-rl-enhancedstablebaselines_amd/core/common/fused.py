@@ -491,8 +491,15 @@ class _GaussianHeadFn(th.autograd.Function):
             if g_action.stride(1) != 1:
                 g_action = g_action.contiguous()
             g_action = g_action[:, g_action.shape[1] - ctx.a:]  # the action columns of d(loss)/d(critic input)
-        hip_ops.gaussian_head_bwd(g_action, None if g_logp is None else g_logp.contiguous(), action, params, eps, g_params,
-                                  ctx.bg if ctx.train_params else None)
+        g_logp = None if g_logp is None else g_logp.contiguous()
+        if USE_FUSED_LINEAR and ctx.below is not None and ctx.needs_input_grad[0] and w.is_contiguous() and h.stride(1) == 1:
+            # two launches: (d params, carried through the head's weights and the hidden activation) + (head dW, db)
+            dx = th.empty(h.shape[0], w.shape[1], dtype=h.dtype, device=h.device)
+            hip_ops.gaussian_head_bwd_input(g_action, g_logp, action, params, eps, w, h, ctx.below[0], g_params, dx)
+            if ctx.train_params:
+                hip_ops.linear_bwd_weight(g_params, h, ctx.wg, ctx.bg)
+            return (dx,) + (None,) * (10 + ctx.n_owners)
+        hip_ops.gaussian_head_bwd(g_action, g_logp, action, params, eps, g_params, ctx.bg if ctx.train_params else None)
         if ctx.train_params:
             th.mm(g_params.t(), h, out=ctx.wg)
         dx = _input_grad(g_params, w, h, ctx.below) if ctx.needs_input_grad[0] else None

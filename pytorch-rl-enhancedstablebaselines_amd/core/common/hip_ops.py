@@ -366,6 +366,23 @@ def gaussian_head_bwd(g_action, g_logp, action, params, eps, g_params, g_bias):
           "cstr_gaussian_head_bwd_f32")
 
 
+def gaussian_head_bwd_input(g_action, g_logp, action, params, eps, weight, hidden, act: int, g_params, dz):
+    """g_params (as gaussian_head_bwd) and dz = (g_params @ weight) * act'(hidden) in one launch; weight [2A, H], hidden [B, H]."""
+    b, a2 = params.shape
+    a = a2 // 2
+    h = weight.shape[1]
+    _chk(params, "params", (b, 2 * a), th.float32), _chk(eps, "eps", (b, a), th.float32), _chk(g_params, "g_params", (b, 2 * a), th.float32)
+    _chk(weight, "weight", (2 * a, h), th.float32), _chk(dz, "dz", (b, h), th.float32), _opt(g_logp, "g_logp", (b,), th.float32)
+    stride = _rows(action, "action", b, a)
+    ga_stride = 0 if g_action is None else _rows(g_action, "g_action", b, a)
+    ldh = _rows(hidden, "hidden", b, h)
+    check(nv.lib().cstr_gaussian_head_bwd_input_f32(ptr(g_action), C.c_int64(ga_stride), ptr(g_logp), ptr(action), C.c_int64(stride),
+                                                    ptr(params), ptr(eps), ptr(weight), ptr(hidden), C.c_int64(ldh), C.c_int(act),
+                                                    ptr(g_params), ptr(dz), C.c_int64(b), C.c_int(a), C.c_int64(h), stream_ptr()),
+          "cstr_gaussian_head_bwd_input_f32")
+    return dz
+
+
 def linear_act_fwd(x, weight, bias, act: int, out=None):
     """y = act(x @ W^T + b) in one launch (f32 matrix cores). x [M, K] or [G, M, K] with unit inner stride (rows / groups may
     be strided, a stride-0 group dimension shares the input), weight [N, K] / [G, N, K], bias [N] / [G, N] contiguous."""

@@ -773,6 +773,65 @@ __global__ __launch_bounds__(256) void gaussian_head_bwd_kernel(const float *__r
     }
 }
 
+// The same backward when the head's Linear sits on a fused hidden layer: besides g_params, the workgroup (4 rows) carries the
+// gradient through the head's weights and the hidden layer's activation,
+//   dz[b][c] = (sum_j g_params[b][j] * w[j][c]) * act'(hidden[b][c])      (2A <= 8 terms per element)
+// i.e. d(loss)/d(pre-activation) of the layer below -- what the Linear backward kernels take as input. The head's own
+// dW / db come from cstr_linear_bwd_weight_f32(g_params, hidden).
+constexpr int HEAD_BWD_ROWS = 4;
+
+template <int ACT>
+__global__ __launch_bounds__(256) void gaussian_head_bwd_input_kernel(const float *__restrict__ g_action, const int64_t ga_stride,
+                                                                      const float *__restrict__ g_logp, const float *__restrict__ action,
+                                                                      const int64_t action_stride, const float *__restrict__ params,
+                                                                      const float *__restrict__ eps, const float *__restrict__ w,
+                                                                      const float *__restrict__ hidden, const int64_t ldh,
+                                                                      float *__restrict__ g_params, float *__restrict__ dz,
+                                                                      const int64_t batch, const int act_dim, const int width)
+{
+    __shared__ float gp[HEAD_BWD_ROWS][2 * CSTR_MAX_HEAD_ACT];
+    const int64_t row0 = (int64_t)blockIdx.x * HEAD_BWD_ROWS;
+    const int t = threadIdx.x;
+    if (t < HEAD_BWD_ROWS * CSTR_MAX_HEAD_ACT) {
+        const int r = t / CSTR_MAX_HEAD_ACT, j = t % CSTR_MAX_HEAD_ACT;
+        const int64_t b = row0 + r;
+        if (b < batch && j < act_dim) {
+            const float gl = g_logp ? g_logp[b] : 0.0f;
+            const float a = action[b * action_stride + j], raw = params[b * 2 * act_dim + act_dim + j];
+            const float s = expf(fminf(fmaxf(raw, LOG_STD_MIN), LOG_STD_MAX));
+            const float one_m = 1.0f - a * a;
+            const float ga = g_action ? g_action[b * ga_stride + j] : 0.0f;
+            const float gu = ga * one_m + gl * (2.0f * a * one_m / (one_m + 1e-6f));
+            const float gls = (raw >= LOG_STD_MIN && raw <= LOG_STD_MAX) ? gu * eps[b * act_dim + j] * s - gl : 0.0f;
+            g_params[b * 2 * act_dim + j] = gu;
+            g_params[b * 2 * act_dim + act_dim + j] = gls;
+            gp[r][j] = gu;
+            gp[r][act_dim + j] = gls;
+        }
+    }
+    __syncthreads();
+    const int r = t >> 6, lane = t & 63;  // one wave per row
+    const int64_t b = row0 + r;
+    if (b >= batch) return;
+    float g[2 * CSTR_MAX_HEAD_ACT];
+#pragma unroll
+    for (int j = 0; j < 2 * CSTR_MAX_HEAD_ACT; ++j) g[j] = j < 2 * act_dim ? gp[r][j] : 0.0f;
+    for (int c = lane; c < width; c += 64) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 2 * CSTR_MAX_HEAD_ACT; ++j) {
+            if (j >= 2 * act_dim) break;
+            acc = __fmaf_rn(g[j], w[(int64_t)j * width + c], acc);
+        }
+        if (ACT != ACT_NONE) {
+            const float y = hidden[b * ldh + c];
+            if (ACT == ACT_RELU) acc = y > 0.0f ? acc : 0.0f;
+            if (ACT == ACT_TANH) acc = acc * (1.0f - y * y);
+        }
+        dz[b * width + c] = acc;
+    }
+}
+
 // ---- loss heads (single workgroup; batch <= 16384) -----------------------------------------------------
 
 // SAC entropy coefficient (core/sac/sac.py:230-243): ent_coef = exp(log_alpha); loss = -mean(log_alpha * (logp + H));
@@ -1025,6 +1084,23 @@ extern "C" int cstr_gaussian_head_bwd_f32(const float *g_action, int64_t ga_stri
     if (act_dim > CSTR_MAX_HEAD_ACT || batch > 65536) return CSTR_E_UNSUPPORTED;
     gaussian_head_bwd_kernel<<<1, 256, 0, (hipStream_t)stream>>>(g_action, ga_stride, g_logp, action, action_stride, params, eps,
                                                                  g_params, g_bias, batch, act_dim);
+    return (int)hipGetLastError();
+}
+
+extern "C" int cstr_gaussian_head_bwd_input_f32(const float *g_action, int64_t ga_stride, const float *g_logp, const float *action,
+                                               int64_t action_stride, const float *params, const float *eps, const float *w,
+                                               const float *hidden, int64_t ldh, int act, float *g_params, float *dz, int64_t batch,
+                                               int act_dim, int64_t width, cstr_stream_t stream)
+{
+    if (!action || !params || !eps || !w || !hidden || !g_params || !dz || batch <= 0 || act_dim <= 0 || width <= 0) return CSTR_E_BADARG;
+    if (action_stride < act_dim || ldh < width || (g_action && ga_stride < act_dim)) return CSTR_E_BADARG;
+    if (act < 0 || act > 2 || act_dim > CSTR_MAX_HEAD_ACT || width > 0x7fffff || batch > (int64_t)0x7fffffff * HEAD_BWD_ROWS) return CSTR_E_UNSUPPORTED;
+    const unsigned grid = (unsigned)((batch + HEAD_BWD_ROWS - 1) / HEAD_BWD_ROWS);
+    hipStream_t s = (hipStream_t)stream;
+#define HBI(A) gaussian_head_bwd_input_kernel<A><<<grid, 64 * HEAD_BWD_ROWS, 0, s>>>(g_action, ga_stride, g_logp, action, action_stride, \
+        params, eps, w, hidden, ldh, g_params, dz, batch, act_dim, (int)width)
+    if (act == 0) HBI(0); else if (act == 1) HBI(1); else HBI(2);
+#undef HBI
     return (int)hipGetLastError();
 }
 

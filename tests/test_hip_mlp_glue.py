@@ -446,6 +446,47 @@ def test_gaussian_head_with_its_linear_inside(ops, B, A, K):
     assert rel_err(a1.cpu().numpy(), a2.cpu().numpy(), 1.0) < 5e-6
 
 
+@pytest.mark.parametrize("B,A,H,act", [(256, 2, 256, 1), (33, 4, 300, 2), (5, 1, 64, 0), (1024, 2, 400, 1)])
+def test_gaussian_head_backward_carried_through_its_linear(ops, B, A, H, act):
+    """cstr_gaussian_head_bwd_input_f32 == cstr_gaussian_head_bwd_f32 + (g_params @ W) * act'(hidden) (f64 check of the
+    product); with cstr_linear_bwd_weight_f32(g_params, hidden) for the head's dW / db."""
+    from core.common import hip_ops
+
+    g = th.Generator(device="cuda").manual_seed(B + H)
+    wide = th.randn(B, H + 4, device="cuda", generator=g)
+    hidden = th.tanh(wide[:, :H]) if act == 2 else (wide[:, :H].clamp(min=0) if act == 1 else wide[:, :H])
+    if act:
+        wide[:, :H] = hidden
+        hidden = wide[:, :H]  # row-strided
+    w = th.randn(2 * A, H, device="cuda", generator=g) / H ** 0.5
+    params, eps = th.randn(B, 2 * A, device="cuda", generator=g), th.randn(B, A, device="cuda", generator=g)
+    params[0, A] = 5.0  # log_std beyond LOG_STD_MAX: its gradient is cut
+    x = th.zeros(B, 3 + A, device="cuda")
+    lp = th.empty(B, device="cuda")
+    hip_ops.gaussian_head_fwd_(params.clone(), th.zeros(2 * A, device="cuda"), eps, None, x[:, 3:], lp)
+    g_x, g_lp = th.randn(B, 3 + A, device="cuda", generator=g), th.randn(B, device="cuda", generator=g)
+    ref_gp, ref_gb = th.empty(B, 2 * A, device="cuda"), th.empty(2 * A, device="cuda")
+    hip_ops.gaussian_head_bwd(g_x[:, 3:], g_lp, x[:, 3:], params, eps, ref_gp, ref_gb)
+    ref_dz = ref_gp.double() @ w.double()
+    if act == 1:
+        ref_dz = ref_dz * (hidden > 0)
+    elif act == 2:
+        ref_dz = ref_dz * (1.0 - hidden.double() ** 2)
+    gp, dz = th.full((B, 2 * A), 7.0, device="cuda"), th.full((B, H), 7.0, device="cuda")
+    hip_ops.gaussian_head_bwd_input(g_x[:, 3:], g_lp, x[:, 3:], params, eps, w, hidden, act, gp, dz)
+    assert th.equal(gp, ref_gp)
+    assert rel_err(dz.cpu().numpy(), ref_dz.cpu().numpy(), max(1.0, float(ref_dz.abs().max()))) < 2e-6
+    dw, db = th.empty(2 * A, H, device="cuda"), th.empty(2 * A, device="cuda")
+    hip_ops.linear_bwd_weight(gp, hidden, dw, db)
+    ref_dw = gp.double().t() @ hidden.double()
+    assert rel_err(dw.cpu().numpy(), ref_dw.cpu().numpy(), max(1.0, float(ref_dw.abs().max()))) < 2e-6
+    assert rel_err(db.cpu().numpy(), ref_gb.cpu().numpy(), max(1.0, float(ref_gb.abs().max()))) < 2e-6
+    # no g_action / no g_logp forms
+    hip_ops.gaussian_head_bwd(None, g_lp, x[:, 3:], params, eps, ref_gp, None)
+    hip_ops.gaussian_head_bwd_input(None, g_lp, x[:, 3:], params, eps, w, hidden, act, gp, dz)
+    assert th.equal(gp, ref_gp)
+
+
 def test_grouped_actor_forward_and_single_agent_backward(ops):
     """FastActorGroup (cstr_linear_act_fwd_sets_f32): four agents' actor MLPs, one launch per layer, actions written into the
     column blocks of a joint buffer; one agent differentiated -- against the per-agent nn.Modules and autograd."""
