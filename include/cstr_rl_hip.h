@@ -265,6 +265,18 @@ int cstr_linear_bwd_input_f32(const float *gz, const float *w, const float *y, i
 int cstr_linear_bwd_weight_f32(const float *dz, const float *x, int64_t x_group_stride, int64_t ldx, float *dw, float *db,
                                int64_t groups, int64_t m, int64_t n, int64_t k, cstr_stream_t stream);
 
+/* The same for up to CSTR_MAX_LINEAR_SETS independent Linears (each with its own shape) in ONE launch: the parameter gradients
+ * of an MLP's layers once its backward chain has produced every dz. db may be NULL per set. */
+typedef struct cstr_wgrad_set {
+    const float *dz; /* [m][n] contiguous */
+    const float *x;  /* [m][k], rows ldx floats apart */
+    int64_t ldx;
+    float *dw;       /* [n][k] */
+    float *db;       /* [n] or NULL */
+    int64_t m, n, k;
+} cstr_wgrad_set_t;
+int cstr_linear_bwd_weight_sets_f32(const cstr_wgrad_set_t *sets, int n_sets, cstr_stream_t stream);
+
 /* Last hidden layer + scalar head of a Q network: create_mlp(..., output_dim = 1) (core/common/torch_layers.py:110-183;
  * ContinuousCritic.forward, core/common/policies.py:960-987) ends in y = act(z + b1), q = y . w2 + b2. The head is a
  * matrix-vector product, done in the epilogue of the previous GEMM: z [groups][m][k] is replaced by y IN PLACE and

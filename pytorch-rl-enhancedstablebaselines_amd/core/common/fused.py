@@ -15,6 +15,7 @@ a hand-written HIP kernel, and gradients are written STRAIGHT into the flat aren
 The nn.Modules keep owning the parameters (state_dict / API); `FastMLP` only reads their tensors. Arithmetic per
 element is the reference's (core/common/torch_layers.py:110-183, core/common/distributions.py:161-260).
 """
+import contextlib
 import os
 from typing import List, Optional, Tuple
 
@@ -74,12 +75,45 @@ def _own_grad(ctx, gy: th.Tensor, y: th.Tensor) -> th.Tensor:
     return gz
 
 
+_pending_wgrads: Optional[list] = None
+
+
+@contextlib.contextmanager
+def deferred_weight_grads():
+    """Inside this context the fused layers' backward passes only QUEUE their (2-D) weight / bias gradients; leaving it
+    computes all of them in one launch (`cstr_linear_bwd_weight_sets_f32`). Parameter gradients are leaves of the backward
+    pass -- nothing but the optimiser waits for them -- so an MLP's backward becomes its dz chain + ONE launch."""
+    global _pending_wgrads
+    if not USE_FUSED_LINEAR or _pending_wgrads is not None:
+        yield
+        return
+    _pending_wgrads = []
+    try:
+        yield
+    finally:
+        pending, _pending_wgrads = _pending_wgrads, None
+    for i in range(0, len(pending), hip_ops.nv.MAX_LINEAR_SETS):
+        chunk = pending[i:i + hip_ops.nv.MAX_LINEAR_SETS]
+        if len(chunk) == 1:
+            hip_ops.linear_bwd_weight(*chunk[0])
+        else:
+            hip_ops.linear_bwd_weight_sets(chunk)
+
+
+def _weight_grad(gz: th.Tensor, x: th.Tensor, wgrad: th.Tensor, bgrad: Optional[th.Tensor]) -> None:
+    """dW (+ db) of one fused Linear: one launch now, or queued when a `deferred_weight_grads` context is open."""
+    if _pending_wgrads is not None and gz.dim() == 2 and x.dim() == 2:
+        _pending_wgrads.append((gz, x, wgrad, bgrad))
+    else:
+        hip_ops.linear_bwd_weight(gz, x, wgrad, bgrad)
+
+
 def _param_grads(ctx, gz: th.Tensor, x: th.Tensor) -> None:
     """dW = gz^T x and db = column sums of gz, written into the gradient arena views."""
     if not ctx.train_params:
         return
     if USE_FUSED_LINEAR:
-        hip_ops.linear_bwd_weight(gz, x, ctx.wgrad, ctx.bgrad)  # one launch for both
+        _weight_grad(gz, x, ctx.wgrad, ctx.bgrad)  # one launch for both
         return
     th.bmm(gz.transpose(1, 2), x, out=ctx.wgrad) if gz.dim() == 3 else th.mm(gz.t(), x, out=ctx.wgrad)
     hip_ops.bias_act_bwd(gz, None, ACT_NONE, gz, ctx.bgrad)
@@ -192,7 +226,7 @@ class _ActorGroupFn(th.autograd.Function):
         for li in range(len(layers) - 1, -1, -1):
             lin = layers[li][0]
             x = x0 if li == 0 else ys[li - 1]
-            hip_ops.linear_bwd_weight(gz, x, lin.weight.grad, lin.bias.grad)
+            _weight_grad(gz, x, lin.weight.grad, lin.bias.grad)
             if li > 0:
                 gz = hip_ops.linear_bwd_input(gz, lin.weight, ys[li - 1], layers[li - 1][1])
         return (None,) * len(ctx.needs_input_grad)
@@ -497,7 +531,7 @@ class _GaussianHeadFn(th.autograd.Function):
             dx = th.empty(h.shape[0], w.shape[1], dtype=h.dtype, device=h.device)
             hip_ops.gaussian_head_bwd_input(g_action, g_logp, action, params, eps, w, h, ctx.below[0], g_params, dx)
             if ctx.train_params:
-                hip_ops.linear_bwd_weight(g_params, h, ctx.wg, ctx.bg)
+                _weight_grad(g_params, h, ctx.wg, ctx.bg)
             return (dx,) + (None,) * (10 + ctx.n_owners)
         hip_ops.gaussian_head_bwd(g_action, g_logp, action, params, eps, g_params, ctx.bg if ctx.train_params else None)
         if ctx.train_params:
@@ -514,10 +548,11 @@ class QOut(tuple):
 
 def backward_q(qs: "QOut", grads: th.Tensor) -> None:
     """autograd.backward for a critic output with d(loss)/dQ given as a [G, B, 1] tensor."""
-    if qs.stacked is not None:
-        th.autograd.backward([qs.stacked], [grads[:qs.stacked.shape[0]]])
-    else:
-        th.autograd.backward(list(qs), [grads[i] for i in range(len(qs))])
+    with deferred_weight_grads():
+        if qs.stacked is not None:
+            th.autograd.backward([qs.stacked], [grads[:qs.stacked.shape[0]]])
+        else:
+            th.autograd.backward(list(qs), [grads[i] for i in range(len(qs))])
 
 
 class FastTwinCritic:

@@ -469,6 +469,28 @@ def linear_bwd_weight(dz, x, dw, db=None):
                                               C.c_int64(m), C.c_int64(n), C.c_int64(k), stream_ptr()), "cstr_linear_bwd_weight_f32")
 
 
+def linear_bwd_weight_sets(sets):
+    """`linear_bwd_weight` for several independent (2-D) Linears of any shapes in one launch. `sets`: [(dz [M, N], x [M, K]
+    (row-strided ok), dw [N, K] view, db [N] view or None)]."""
+    sets = list(sets)
+    if not 0 < len(sets) <= nv.MAX_LINEAR_SETS:
+        raise ValueError(f"1..{nv.MAX_LINEAR_SETS} sets, got {len(sets)}")
+    arr = (nv.WgradSet * len(sets))()
+    for i, (dz, x, dw, db) in enumerate(sets):
+        if dz.dim() != 2:
+            raise ValueError(f"dz[{i}]: needs a matrix")
+        m, n = dz.shape
+        k = x.shape[-1]
+        _f32c(dz, f"dz[{i}]"), _f32c(dw, f"dw[{i}]")
+        if not (x.is_cuda and x.dtype == th.float32 and x.dim() == 2 and x.stride(1) == 1 and x.shape[0] == m):
+            raise ValueError(f"x[{i}]: needs a float32 device matrix with unit inner stride and as many rows as dz")
+        if dw.numel() != n * k or (db is not None and _f32c(db, f"db[{i}]").numel() != n):
+            raise ValueError(f"dw / db[{i}] do not match dz {tuple(dz.shape)} and x {tuple(x.shape)}")
+        arr[i] = nv.WgradSet(dz.data_ptr(), x.data_ptr(), max(x.stride(0), k), dw.data_ptr(), None if db is None else db.data_ptr(),
+                             m, n, k)
+    check(nv.lib().cstr_linear_bwd_weight_sets_f32(arr, C.c_int(len(sets)), stream_ptr()), "cstr_linear_bwd_weight_sets_f32")
+
+
 def target_smooth(action, noise, rng_ctl, sigma: float, clip: float, out):
     """out = clamp(action + clamp(noise, -clip, clip), -1, 1); noise given ([B, A], already scaled) or drawn (rng_ctl)."""
     b, a = action.shape

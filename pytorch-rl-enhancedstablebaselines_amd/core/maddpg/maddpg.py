@@ -347,7 +347,8 @@ class MADDPG(OffPolicyAlgorithm):
             if len(qs) == 2:
                 fused.backward_q(qs, gq)  # :162-164
             else:
-                th.autograd.backward([qs[0]], [gq[0] + gq[1]])
+                with fused.deferred_weight_grads():
+                    th.autograd.backward([qs[0]], [gq[0] + gq[1]])
             self._allreduce_grads(pol.critic_slices[i])
             C.optimizer_list[i].step()
             critic_loss_now = self._loss_now.clone() if self.debug_capture else None

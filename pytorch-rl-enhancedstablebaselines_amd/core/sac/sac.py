@@ -224,10 +224,11 @@ class SAC(OffPolicyAlgorithm):
                  else self._fast_critic(rd.observations, actions_pi, train_params=False))
         q1_pi, q2_pi = qs_pi
         hip_ops.sac_actor_loss(log_prob, q1_pi, q2_pi, ent_coef, g_lp, gq1, gq2, sto("actor", self._loss_now["actor"]), acc("actor"))
-        if qs_pi.stacked is not None:  # :279-281
-            th.autograd.backward([log_prob, qs_pi.stacked], [g_lp, gq])
-        else:
-            th.autograd.backward([log_prob, q1_pi, q2_pi], [g_lp, gq1, gq2])
+        with fused.deferred_weight_grads():  # :279-281; the actor's dW / db of all layers in one launch
+            if qs_pi.stacked is not None:
+                th.autograd.backward([log_prob, qs_pi.stacked], [g_lp, gq])
+            else:
+                th.autograd.backward([log_prob, q1_pi, q2_pi], [g_lp, gq1, gq2])
         self._allreduce_grads(pol.actor_arena)
         if gradient_step % self.target_update_interval == 0:  # :281 and :284-287 (disjoint arenas) in one launch
             self.actor.optimizer.step_with(polyak=(pol.critic_arena, pol.critic_target_arena, self.tau))

@@ -183,7 +183,8 @@ class TD3(OffPolicyAlgorithm):
         if len(qs) == 2:
             fused.backward_q(qs, gq)
         else:
-            th.autograd.backward([q1], [gq1 + gq2])
+            with fused.deferred_weight_grads():
+                th.autograd.backward([q1], [gq1 + gq2])
         self._allreduce_grads(pol.critic_arena)
         self.critic.optimizer.step()
         actor_done = False

@@ -339,18 +339,14 @@ __global__ __launch_bounds__(64 * WAVES) void linear_bwd_input_kernel(const floa
 // k0 + r of row 16c + 4h + e). The workgroups of the first k strip also add up the dz values they load anyway: db needs no
 // extra pass and, being reduced inside one workgroup in a fixed order, stays deterministic.
 template <int WAVES>
-__global__ __launch_bounds__(64 * WAVES) void linear_bwd_weight_kernel(const float *__restrict__ dz, const float *__restrict__ x,
-                                                                       const int64_t x_group_stride, const int ldx,
-                                                                       float *__restrict__ dw, float *__restrict__ db, const int M,
-                                                                       const int N, const int K)
+__device__ __forceinline__ void linear_bwd_weight_tile(const float *__restrict__ dz, const float *__restrict__ x, const int ldx,
+                                                       float *__restrict__ dw, float *__restrict__ db, const int M, const int N,
+                                                       const int K, const int64_t g)
 {
     __shared__ f32x4 part[WAVES > 1 ? WAVES - 1 : 1][64];
     __shared__ float colpart[WAVES][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, h = lane >> 4;
     const int k0 = blockIdx.x * 16, n0 = blockIdx.y * 16;
-    const int64_t g = blockIdx.z;
-    dz += g * (int64_t)M * N;
-    x += g * x_group_stride;
     const bool n_ok = n0 + r < N, k_ok = k0 + r < K;
     const bool want_db = db != nullptr && blockIdx.x == 0;
     f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -403,6 +399,28 @@ __global__ __launch_bounds__(64 * WAVES) void linear_bwd_weight_kernel(const flo
         for (int v = 0; v < WAVES; ++v) sum += (colpart[v][lane] + colpart[v][lane + 16]) + (colpart[v][lane + 32] + colpart[v][lane + 48]);
         db[g * N + n0 + lane] = sum;
     }
+}
+
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void linear_bwd_weight_kernel(const float *__restrict__ dz, const float *__restrict__ x,
+                                                                       const int64_t x_group_stride, const int ldx,
+                                                                       float *__restrict__ dw, float *__restrict__ db, const int M,
+                                                                       const int N, const int K)
+{
+    const int64_t g = blockIdx.z;
+    linear_bwd_weight_tile<WAVES>(dz + g * (int64_t)M * N, x + g * x_group_stride, ldx, dw, db, M, N, K, g);
+}
+
+// Several Linears' weight + bias gradients in ONE launch (an MLP's layers after its backward chain has produced every dz:
+// the parameter gradients are leaves nobody waits for): blockIdx.z selects the operand set, every set has its own shape.
+struct WgradSets { cstr_wgrad_set_t s[CSTR_MAX_LINEAR_SETS]; };
+
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void linear_bwd_weight_sets_kernel(const WgradSets sets)
+{
+    const cstr_wgrad_set_t &q = sets.s[blockIdx.z];
+    if ((int64_t)blockIdx.x * 16 >= q.k || (int64_t)blockIdx.y * 16 >= q.n) return;  // the grid covers the largest set
+    linear_bwd_weight_tile<WAVES>(q.dz, q.x, (int)q.ldx, q.dw, q.db, (int)q.m, (int)q.n, (int)q.k, 0);
 }
 
 // ---- last hidden layer + scalar head of a Q network ------------------------------------------------------------
@@ -1163,6 +1181,28 @@ extern "C" int cstr_linear_bwd_weight_f32(const float *dz, const float *x, int64
     hipStream_t s = (hipStream_t)stream;
     if (m > 32) linear_bwd_weight_kernel<4><<<grid, 256, 0, s>>>(dz, x, x_group_stride, (int)ldx, dw, db, (int)m, (int)n, (int)k);
     else linear_bwd_weight_kernel<1><<<grid, 64, 0, s>>>(dz, x, x_group_stride, (int)ldx, dw, db, (int)m, (int)n, (int)k);
+    return (int)hipGetLastError();
+}
+
+extern "C" int cstr_linear_bwd_weight_sets_f32(const cstr_wgrad_set_t *sets, int n_sets, cstr_stream_t stream)
+{
+    if (!sets || n_sets <= 0) return CSTR_E_BADARG;
+    if (n_sets > CSTR_MAX_LINEAR_SETS) return CSTR_E_UNSUPPORTED;
+    WgradSets t;
+    int64_t kt = 1, nt = 1, m_min = INT64_MAX;
+    for (int i = 0; i < n_sets; ++i) {
+        const cstr_wgrad_set_t &q = sets[i];
+        if (!q.dz || !q.x || !q.dw || q.m <= 0 || q.n <= 0 || q.k <= 0 || q.ldx < q.k) return CSTR_E_BADARG;
+        if (q.m > 0x7fffff || q.n > 0x7fffff || q.k > 0x7fffff || (q.n + 15) / 16 > 65535) return CSTR_E_UNSUPPORTED;
+        kt = kt > (q.k + 15) / 16 ? kt : (q.k + 15) / 16;
+        nt = nt > (q.n + 15) / 16 ? nt : (q.n + 15) / 16;
+        m_min = m_min < q.m ? m_min : q.m;
+        t.s[i] = q;
+    }
+    const dim3 grid((unsigned)kt, (unsigned)nt, (unsigned)n_sets);
+    hipStream_t s = (hipStream_t)stream;
+    if (m_min > 32) linear_bwd_weight_sets_kernel<4><<<grid, 256, 0, s>>>(t);
+    else linear_bwd_weight_sets_kernel<1><<<grid, 64, 0, s>>>(t);
     return (int)hipGetLastError();
 }
 
