@@ -353,6 +353,26 @@ int cstr_sac_alpha_f32(const float *log_alpha, const float *logp, float target_e
 int cstr_twin_q_loss_f32(const float *q1, const float *q2, const float *target, float scale, float *gq1, float *gq2,
                          float *loss_out, float *loss_sum, int64_t batch, cstr_stream_t stream);
 
+/* TD target + twin-critic loss (+ optionally SAC's entropy-coefficient loss) in ONE launch: cstr_td_target_min_f32,
+ * cstr_twin_q_loss_f32 and cstr_sac_alpha_f32 back to back, bit for bit (core/sac/sac.py:230-261; core/td3/td3.py:167-182).
+ * q1_t / q2_t: the target critics on the next state; next_logp NULL for TD3; `alpha` NULL (or log_alpha NULL) = no
+ * entropy-coefficient part, then the target uses ent_coef[0]; with it the target uses exp(log_alpha[0]) and ent_coef is
+ * ignored. target_out [B] may be NULL. */
+typedef struct cstr_alpha_part {
+    const float *log_alpha; /* [1] */
+    const float *logp_pi;   /* [B] log pi(a|s) of the actor pass on the sampled observations */
+    float target_entropy;
+    float *grad_out;        /* [1] d loss / d log_alpha */
+    float *ent_coef_out;    /* [1] exp(log_alpha) */
+    float *loss_out;        /* [1] or NULL: stored */
+    float *loss_sum;        /* [1] or NULL: accumulated */
+    float *ent_coef_sum;    /* [1] or NULL: accumulated */
+} cstr_alpha_part_t;
+int cstr_td_twin_q_loss_f32(const float *q1_t, const float *q2_t, const float *next_logp, const float *rew, const float *done,
+                            const float *ent_coef, float gamma, const float *q1, const float *q2, float scale, float *target_out,
+                            float *gq1, float *gq2, float *loss_out, float *loss_sum, const cstr_alpha_part_t *alpha,
+                            int64_t batch, cstr_stream_t stream);
+
 /* SAC actor loss as a backward root (core/sac/sac.py:273-275): loss = mean(ent_coef * logp - min(q1, q2)). */
 int cstr_sac_actor_loss_f32(const float *logp, const float *q1, const float *q2, const float *ent_coef, float *g_logp, float *gq1,
                             float *gq2, float *loss_out, float *loss_sum, int64_t batch, cstr_stream_t stream);

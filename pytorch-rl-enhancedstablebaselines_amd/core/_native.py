@@ -20,7 +20,7 @@ RNG_CTL_WORDS, MAX_HEAD_ACT, MAX_LINEAR_SETS = 4, 4, 8
 SYMBOLS = (
     "cstr_abi_version", "cstr_error_string", "cstr_default_coef", "cstr_vec_step_f32", "cstr_reset_draw_f32",
     "cstr_replay_add_f32", "cstr_collect_step_f32", "cstr_mt19937_seed", "cstr_mt19937_normal_f32", "cstr_mt19937_normal_f64", "cstr_replay_sample_mt19937_f32", "cstr_replay_sample_packed_mt19937_f32",
-    "cstr_adam_multi_f32", "cstr_gaussian_head_fwd_f32", "cstr_gaussian_head_gemm_fwd_f32", "cstr_gaussian_head_bwd_f32", "cstr_gaussian_head_bwd_input_f32", "cstr_linear_act_fwd_f32", "cstr_linear_act_fwd_sets_f32", "cstr_linear_bwd_input_f32", "cstr_linear_bwd_weight_f32", "cstr_linear_bwd_weight_sets_f32", "cstr_target_smooth_f32", "cstr_hidden_head_fwd_f32", "cstr_hidden_head_bwd_f32", "cstr_vecnorm_init_f64", "cstr_vecnorm_step_f64", "cstr_vecnorm_apply_f32",
+    "cstr_adam_multi_f32", "cstr_gaussian_head_fwd_f32", "cstr_gaussian_head_gemm_fwd_f32", "cstr_gaussian_head_bwd_f32", "cstr_gaussian_head_bwd_input_f32", "cstr_linear_act_fwd_f32", "cstr_linear_act_fwd_sets_f32", "cstr_linear_bwd_input_f32", "cstr_linear_bwd_weight_f32", "cstr_linear_bwd_weight_sets_f32", "cstr_td_twin_q_loss_f32", "cstr_target_smooth_f32", "cstr_hidden_head_fwd_f32", "cstr_hidden_head_bwd_f32", "cstr_vecnorm_init_f64", "cstr_vecnorm_step_f64", "cstr_vecnorm_apply_f32",
     "cstr_td_target_min_f32", "cstr_polyak_f32", "cstr_adam_f32", "cstr_bias_act_fwd_f32", "cstr_bias_act_bwd_f32",
     "cstr_squashed_gaussian_fwd_f32", "cstr_squashed_gaussian_bwd_f32", "cstr_sac_alpha_f32", "cstr_twin_q_loss_f32",
     "cstr_sac_actor_loss_f32", "cstr_neg_mean_loss_f32",
@@ -59,6 +59,12 @@ class WgradSet(C.Structure):
     """cstr_wgrad_set_t"""
     _fields_ = [("dz", C.c_void_p), ("x", C.c_void_p), ("ldx", C.c_int64), ("dw", C.c_void_p), ("db", C.c_void_p),
                 ("m", C.c_int64), ("n", C.c_int64), ("k", C.c_int64)]
+
+
+class AlphaPart(C.Structure):
+    """cstr_alpha_part_t"""
+    _fields_ = [("log_alpha", C.c_void_p), ("logp_pi", C.c_void_p), ("target_entropy", C.c_float), ("grad_out", C.c_void_p),
+                ("ent_coef_out", C.c_void_p), ("loss_out", C.c_void_p), ("loss_sum", C.c_void_p), ("ent_coef_sum", C.c_void_p)]
 
 
 class VecNormCfg(C.Structure):

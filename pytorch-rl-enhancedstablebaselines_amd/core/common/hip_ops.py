@@ -589,6 +589,37 @@ def twin_q_loss(q1, q2, target, scale: float, gq1, gq2, loss_out=None, loss_sum=
                                         ptr(loss_sum), C.c_int64(b), stream_ptr()), "cstr_twin_q_loss_f32")
 
 
+def td_twin_q_loss(q1_t, q2_t, next_logp, rew, done, ent_coef, gamma: float, q1, q2, scale: float, target_out, gq1, gq2,
+                   loss_out=None, loss_sum=None, alpha=None):
+    """`td_target_min` + `twin_q_loss` (+ `sac_alpha`) in one launch. `alpha` = None or a dict(log_alpha, logp_pi,
+    target_entropy, grad_out, ent_coef_out, loss_out=None, loss_sum=None, ent_coef_sum=None): SAC's entropy-coefficient loss
+    rides along and the target uses exp(log_alpha) (`ent_coef` is ignored then)."""
+    b = q1.numel()
+    for t, nm in ((q1_t, "q1_t"), (q2_t, "q2_t"), (rew, "rew"), (done, "done"), (q1, "q1"), (q2, "q2"), (gq1, "gq1"), (gq2, "gq2")):
+        _vec(t, nm, b)
+    if next_logp is not None:
+        _vec(next_logp, "next_logp", b)
+        if alpha is None:
+            if ent_coef is None:
+                raise ValueError("next_logp needs ent_coef or the alpha part")
+            _vec(ent_coef, "ent_coef", 1)
+    if target_out is not None:
+        _vec(target_out, "target_out", b)
+    part = None
+    if alpha is not None:
+        _vec(alpha["logp_pi"], "logp_pi", b)
+        for nm in ("log_alpha", "grad_out", "ent_coef_out"):
+            _vec(alpha[nm], nm, 1)
+        part = nv.AlphaPart(alpha["log_alpha"].data_ptr(), alpha["logp_pi"].data_ptr(), float(alpha["target_entropy"]),
+                            alpha["grad_out"].data_ptr(), alpha["ent_coef_out"].data_ptr(),
+                            *(None if alpha.get(k) is None else alpha[k].data_ptr() for k in ("loss_out", "loss_sum", "ent_coef_sum")))
+    check(nv.lib().cstr_td_twin_q_loss_f32(ptr(q1_t), ptr(q2_t), ptr(next_logp), ptr(rew), ptr(done),
+                                           ptr(None if alpha is not None else ent_coef), C.c_float(gamma), ptr(q1), ptr(q2),
+                                           C.c_float(scale), ptr(target_out), ptr(gq1), ptr(gq2), ptr(loss_out), ptr(loss_sum),
+                                           None if part is None else C.byref(part), C.c_int64(b), stream_ptr()),
+          "cstr_td_twin_q_loss_f32")
+
+
 def sac_actor_loss(logp, q1, q2, ent_coef, g_logp, gq1, gq2, loss_out=None, loss_sum=None):
     b = logp.numel()
     for t, nm in ((logp, "logp"), (q1, "q1"), (q2, "q2"), (g_logp, "g_logp"), (gq1, "gq1"), (gq2, "gq2")):

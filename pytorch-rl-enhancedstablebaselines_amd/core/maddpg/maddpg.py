@@ -339,11 +339,12 @@ class MADDPG(OffPolicyAlgorithm):
             with th.no_grad():  # :148-151
                 x_next = shared_next if shared_next is not None else self.critic_target._input(i, rd.next_observations, next_actions)
                 qs_t = self._fast_critic_targets[i].forward_input(x_next, train_params=False)
-                hip_ops.td_target_min(qs_t[0], qs_t[-1], None, rd.rewards, rd.dones, None, self.gamma, self._target_q[i])
             x_cur = shared_cur if shared_cur is not None else C._input(i, rd.observations, rd.actions)
             qs = self._fast_critics[i].forward_input(x_cur)  # :154
             scale = 1.0 if len(qs) == 2 else 0.5
-            hip_ops.twin_q_loss(qs[0], qs[-1], self._target_q[i], scale, gq[0], gq[1], self._loss_now, self._loss_sums[f"critic{i}"])
+            # TD target (:148-151) + critic loss (:157-159) in one launch
+            hip_ops.td_twin_q_loss(qs_t[0], qs_t[-1], None, rd.rewards, rd.dones, None, self.gamma, qs[0], qs[-1], scale,
+                                   self._target_q[i], gq[0], gq[1], self._loss_now, self._loss_sums[f"critic{i}"])
             if len(qs) == 2:
                 fused.backward_q(qs, gq)  # :162-164
             else:

@@ -185,32 +185,32 @@ class SAC(OffPolicyAlgorithm):
         else:
             actions_pi, log_prob = self._fast_actor.action_log_prob(rd.observations)  # :222
 
-        if self.ent_coef_optimizer is not None:  # :230-243
-            # ent_coef = exp(log_ent_coef) BEFORE the update (:230); the updated value is first used by the next gradient
-            # step, so the optimiser step itself may wait for the critic's all-reduce (one collective instead of two)
-            hip_ops.sac_alpha(self.log_ent_coef.detach(), log_prob.detach(), self.target_entropy, self._ent_arena.grad[0:1],
-                              s["ent_coef"] if single else self._ent_coef_buf, acc("ent_coef_loss"), acc("ent_coef"),
-                              loss_out=s["ent_coef_loss"] if single else None)
-            if not self._ent_rides_critic:
-                self._allreduce_grads(self._ent_arena)
-                self.ent_coef_optimizer.step()
-            ent_coef = s["ent_coef"] if single else self._ent_coef_buf
-        else:
-            ent_coef = self.ent_coef_tensor.reshape(1)
-            s["ent_coef"] += ent_coef
-
-        with th.no_grad():  # :245-254
+        # :230-261. ONE launch for the three batch reductions between the forward passes and the critic backward: the entropy
+        # coefficient's loss (ent_coef = exp(log_ent_coef) BEFORE the update, :230; the updated value is first used by the
+        # next gradient step, so its optimiser step may wait for the critic's all-reduce: one collective instead of two),
+        # the TD target (:245-254) and the critic loss (:258-261)
+        with th.no_grad():
             if pb is not None:
                 x_next, next_log_prob = self._fast_actor.action_log_prob(rd.next_observations, train_params=False, xbuf=pb.x_next)
                 q1_t, q2_t = self._fast_critic_target.forward_input(x_next, train_params=False)
             else:
                 next_actions, next_log_prob = self._fast_actor.action_log_prob(rd.next_observations, train_params=False)
                 q1_t, q2_t = self._fast_critic_target(rd.next_observations, next_actions, train_params=False)
-            hip_ops.td_target_min(q1_t, q2_t, next_log_prob, rd.rewards, rd.dones, ent_coef, self.gamma, self._target_q)
-
         qs = self._fast_critic.forward_input(pb.x_data) if pb is not None else self._fast_critic(rd.observations, rd.actions)  # :258
         q1, q2 = qs
-        hip_ops.twin_q_loss(q1, q2, self._target_q, 0.5, gq1, gq2, sto("critic", self._loss_now["critic"]), acc("critic"))  # :261
+        if self.ent_coef_optimizer is not None:
+            ent_coef = s["ent_coef"] if single else self._ent_coef_buf
+            alpha = dict(log_alpha=self.log_ent_coef.detach(), logp_pi=log_prob.detach(), target_entropy=self.target_entropy,
+                         grad_out=self._ent_arena.grad[0:1], ent_coef_out=ent_coef, loss_out=s["ent_coef_loss"] if single else None,
+                         loss_sum=acc("ent_coef_loss"), ent_coef_sum=acc("ent_coef"))
+        else:
+            ent_coef, alpha = self.ent_coef_tensor.reshape(1), None
+            s["ent_coef"] += ent_coef
+        hip_ops.td_twin_q_loss(q1_t, q2_t, next_log_prob, rd.rewards, rd.dones, ent_coef, self.gamma, q1, q2, 0.5, self._target_q,
+                               gq1, gq2, sto("critic", self._loss_now["critic"]), acc("critic"), alpha=alpha)
+        if self.ent_coef_optimizer is not None and not self._ent_rides_critic:
+            self._allreduce_grads(self._ent_arena)
+            self.ent_coef_optimizer.step()
         fused.backward_q(qs, gq)  # :266-268
         self._allreduce_grads(pol.critic_arena)
         if self.ent_coef_optimizer is not None and self._ent_rides_critic:

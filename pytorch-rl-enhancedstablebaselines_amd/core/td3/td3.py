@@ -175,11 +175,13 @@ class TD3(OffPolicyAlgorithm):
                 noise = noise.clamp(-self.target_noise_clip, self.target_noise_clip)
                 next_actions = (self._fast_actor_target(rd.next_observations, train_params=False) + noise).clamp(-1, 1)
                 qs = self._fast_critic_target(rd.next_observations, next_actions, train_params=False)
-            hip_ops.td_target_min(qs[0], qs[-1], None, rd.rewards, rd.dones, None, self.gamma, self._target_q)
+            q1_t, q2_t = qs[0], qs[-1]
         qs = self._fast_critic.forward_input(pb.x_data) if pb is not None else self._fast_critic(rd.observations, rd.actions)  # :179
         q1, q2 = qs[0], qs[-1]
-        # n_critics == 1 (DDPG): loss = mse(q1, t) -> scale 0.5 of the doubled term
-        hip_ops.twin_q_loss(q1, q2, self._target_q, 1.0 if len(qs) == 2 else 0.5, gq1, gq2, self._loss_now["critic"], s["critic"])
+        # TD target (:174-176) + critic loss (:182) in one launch; n_critics == 1 (DDPG): loss = mse(q1, t) -> scale 0.5 of
+        # the doubled term
+        hip_ops.td_twin_q_loss(q1_t, q2_t, None, rd.rewards, rd.dones, None, self.gamma, q1, q2, 1.0 if len(qs) == 2 else 0.5,
+                               self._target_q, gq1, gq2, self._loss_now["critic"], s["critic"])
         if len(qs) == 2:
             fused.backward_q(qs, gq)
         else:

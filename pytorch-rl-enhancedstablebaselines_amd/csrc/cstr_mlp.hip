@@ -898,6 +898,55 @@ __global__ __launch_bounds__(256) void twin_q_loss_kernel(const float *__restric
     }
 }
 
+// TD target + twin-critic loss (+ SAC's entropy-coefficient loss) in ONE single-workgroup launch: the three reductions over
+// the batch that sit between the forward passes and the critic backward. Per element exactly td_target_min_kernel
+// (cstr_learner.hip), twin_q_loss_kernel and sac_alpha_kernel above, so the results are those kernels' bit for bit.
+//   t = rew + (1 - done) * gamma * (min(q1_t, q2_t) - alpha * next_logp);  loss = scale * (mse(q1, t) + mse(q2, t))
+// alpha = exp(log_alpha) when the entropy-coefficient part rides along (its value BEFORE this step's update, sac.py:230),
+// the given constant otherwise.
+__global__ __launch_bounds__(256) void td_twin_q_loss_kernel(const float *__restrict__ q1_t, const float *__restrict__ q2_t,
+                                                             const float *__restrict__ next_logp, const float *__restrict__ rew,
+                                                             const float *__restrict__ done, const float *__restrict__ ent_coef,
+                                                             const float gamma, const float *__restrict__ q1,
+                                                             const float *__restrict__ q2, const float scale,
+                                                             float *__restrict__ target_out, float *__restrict__ gq1,
+                                                             float *__restrict__ gq2, float *__restrict__ loss_out,
+                                                             float *__restrict__ loss_sum, const cstr_alpha_part_t ap, const int batch)
+{
+    __shared__ float sm[4];
+    const bool with_alpha = ap.log_alpha != nullptr;
+    const float la = with_alpha ? ap.log_alpha[0] : 0.0f;
+    const float ec = with_alpha ? expf(la) : (ent_coef ? ent_coef[0] : 0.0f);
+    const float k = scale * 2.0f / (float)batch;
+    float a1 = 0.0f, a2 = 0.0f, aa = 0.0f;
+    for (int b = threadIdx.x; b < batch; b += 256) {
+        float q = fminf(q1_t[b], q2_t[b]);
+        if (next_logp) q = q - ec * next_logp[b];
+        const float t = rew[b] + (1.0f - done[b]) * gamma * q;
+        if (target_out) target_out[b] = t;
+        const float d1 = q1[b] - t, d2 = q2[b] - t;
+        gq1[b] = k * d1;
+        gq2[b] = k * d2;
+        a1 += d1 * d1;
+        a2 += d2 * d2;
+        if (with_alpha) aa += ap.logp_pi[b] + ap.target_entropy;
+    }
+    const float s1 = block_sum_256(a1, sm), s2 = block_sum_256(a2, sm);
+    const float mean = with_alpha ? block_sum_256(aa, sm) / (float)batch : 0.0f;
+    if (threadIdx.x == 0) {
+        const float loss = scale * (s1 / (float)batch + s2 / (float)batch);
+        if (loss_out) loss_out[0] = loss;
+        if (loss_sum) loss_sum[0] += loss;
+        if (with_alpha) {
+            ap.grad_out[0] = -mean;
+            ap.ent_coef_out[0] = ec;
+            if (ap.loss_out) ap.loss_out[0] = -(la * mean);
+            if (ap.loss_sum) ap.loss_sum[0] += -(la * mean);
+            if (ap.ent_coef_sum) ap.ent_coef_sum[0] += ec;
+        }
+    }
+}
+
 // SAC actor loss (core/sac/sac.py:273-275): loss = mean(ent_coef * logp - min(q1, q2));
 // d/d logp = ent_coef / B;  d/d q_k = -1/B for the smaller one (first index on ties, like th.min), 0 for the other
 __global__ __launch_bounds__(256) void sac_actor_loss_kernel(const float *__restrict__ logp, const float *__restrict__ q1,
@@ -1031,6 +1080,24 @@ extern "C" int cstr_twin_q_loss_f32(const float *q1, const float *q2, const floa
     if (!q1 || !q2 || !target || !gq1 || !gq2 || batch <= 0) return CSTR_E_BADARG;
     if (batch > CSTR_MAX_SAMPLE_BATCH) return CSTR_E_UNSUPPORTED;
     twin_q_loss_kernel<<<1, 256, 0, (hipStream_t)stream>>>(q1, q2, target, scale, gq1, gq2, loss_out, loss_sum, (int)batch);
+    return (int)hipGetLastError();
+}
+
+extern "C" int cstr_td_twin_q_loss_f32(const float *q1_t, const float *q2_t, const float *next_logp, const float *rew, const float *done,
+                                       const float *ent_coef, float gamma, const float *q1, const float *q2, float scale,
+                                       float *target_out, float *gq1, float *gq2, float *loss_out, float *loss_sum,
+                                       const cstr_alpha_part_t *alpha, int64_t batch, cstr_stream_t stream)
+{
+    if (!q1_t || !q2_t || !rew || !done || !q1 || !q2 || !gq1 || !gq2 || batch <= 0) return CSTR_E_BADARG;
+    cstr_alpha_part_t ap = {};
+    if (alpha && alpha->log_alpha) {
+        if (!alpha->logp_pi || !alpha->grad_out || !alpha->ent_coef_out) return CSTR_E_BADARG;
+        ap = *alpha;
+    }
+    if (next_logp && !ap.log_alpha && !ent_coef) return CSTR_E_BADARG;  // an entropy term needs its coefficient
+    if (batch > CSTR_MAX_SAMPLE_BATCH) return CSTR_E_UNSUPPORTED;
+    td_twin_q_loss_kernel<<<1, 256, 0, (hipStream_t)stream>>>(q1_t, q2_t, next_logp, rew, done, ent_coef, gamma, q1, q2, scale,
+                                                              target_out, gq1, gq2, loss_out, loss_sum, ap, (int)batch);
     return (int)hipGetLastError();
 }
 

@@ -106,6 +106,47 @@ def test_fused_linear_matches_module(ops, M, K, N, act):
     assert rel_err(x3.grad.cpu().numpy(), x2.grad.cpu().numpy(), max(1e-2, float(x2.grad.abs().mean()))) < 1e-5
 
 
+@pytest.mark.parametrize("B", [1, 256, 1000])
+def test_target_loss_and_entropy_coefficient_in_one_launch(ops, B):
+    """cstr_td_twin_q_loss_f32 == cstr_td_target_min_f32 -> cstr_twin_q_loss_f32 (-> cstr_sac_alpha_f32), bit for bit, in
+    the SAC form (entropy term, alpha part riding along), the SAC fixed-coefficient form and the TD3 form."""
+    g = th.Generator(device="cuda").manual_seed(B)
+    r = lambda *sh: th.randn(*sh, device="cuda", generator=g)  # noqa: E731
+    q1t, q2t, q1, q2, rew = (r(B, 1) * 3 for _ in range(5))
+    nlp, lp = r(B), r(B)
+    done = (th.rand(B, 1, device="cuda", generator=g) < 0.2).float()
+    la = th.tensor([-0.3], device="cuda")
+    z = lambda: th.zeros(1, device="cuda")  # noqa: E731
+    for form in ("sac", "sac_fixed", "td3"):
+        # three launches
+        t_ref, g1_ref, g2_ref = th.empty(B, 1, device="cuda"), th.empty(B, 1, device="cuda"), th.empty(B, 1, device="cuda")
+        loss_ref, acc_ref, grad_ref, ec_ref, al_ref, als_ref, ecs_ref = z(), z() + 10, z(), z(), z(), z() + 5, z() + 7
+        if form == "sac":
+            ops.sac_alpha(la, lp, -2.0, grad_ref, ec_ref, als_ref, ecs_ref, loss_out=al_ref)
+        else:
+            ec_ref.fill_(0.37)
+        ops.td_target_min(q1t, q2t, None if form == "td3" else nlp, rew, done, None if form == "td3" else ec_ref, 0.99, t_ref)
+        scale = 1.0 if form == "td3" else 0.5
+        ops.twin_q_loss(q1, q2, t_ref, scale, g1_ref, g2_ref, loss_ref, acc_ref)
+        # one launch
+        t, g1, g2 = th.empty(B, 1, device="cuda"), th.empty(B, 1, device="cuda"), th.empty(B, 1, device="cuda")
+        loss, acc, grad, ec, al, als, ecs = z(), z() + 10, z(), z(), z(), z() + 5, z() + 7
+        alpha = None
+        if form == "sac":
+            alpha = dict(log_alpha=la, logp_pi=lp, target_entropy=-2.0, grad_out=grad, ent_coef_out=ec, loss_out=al, loss_sum=als,
+                         ent_coef_sum=ecs)
+        else:
+            ec.fill_(0.37)
+        ops.td_twin_q_loss(q1t, q2t, None if form == "td3" else nlp, rew, done, None if form != "sac_fixed" else ec, 0.99, q1, q2,
+                           scale, t, g1, g2, loss, acc, alpha=alpha)
+        for got, want in ((t, t_ref), (g1, g1_ref), (g2, g2_ref), (loss, loss_ref), (acc, acc_ref), (grad, grad_ref), (ec, ec_ref),
+                          (al, al_ref), (als, als_ref), (ecs, ecs_ref)):
+            assert th.equal(got, want), form
+        ops.td_twin_q_loss(q1t, q2t, None, rew, done, None, 0.99, q1, q2, scale, None, g1, g2)  # no target / loss outputs
+    with pytest.raises(ValueError):
+        ops.td_twin_q_loss(q1t, q2t, nlp, rew, done, None, 0.99, q1, q2, 0.5, None, g1, g2)  # entropy term without coefficient
+
+
 def test_loss_heads(ops):
     g = th.Generator().manual_seed(0)
     for B in (1, 64, 256, 1000):
