@@ -306,9 +306,9 @@ int cstr_squashed_gaussian_bwd_f32(const float *g_action, const float *g_logp, c
  * params [B][2A] = the head GEMM's output, gets `bias` [2A] added in place (NULL: already biased); eps [B][A] ~ N(0,1) is READ
  * when rng_ctl is NULL and DRAWN (and written, for the backward) when rng_ctl is given; action = tanh(mean + exp(clamp(
  * log_std)) * eps) with row stride `action_stride` (>= A: it may be a column block of the critic's input); logp [B] or NULL.
- * rng_ctl: uint64[CSTR_RNG_CTL_WORDS] in HBM = { seed, offset, ticket, - }: Philox4x32-10 counter RNG + Box-Muller, the
- * offset advances by B per launch on the device (graph-replay safe). */
-#define CSTR_RNG_CTL_WORDS 4
+ * rng_ctl: uint64[CSTR_RNG_CTL_WORDS] in HBM = { seed, offset, ticket, -, sub-tickets[8] (cstr_policy_rows_fwd_f32), - }:
+ * Philox4x32-10 counter RNG + Box-Muller, the offset advances by B per launch on the device (graph-replay safe). */
+#define CSTR_RNG_CTL_WORDS 16
 #define CSTR_MAX_HEAD_ACT 4
 int cstr_gaussian_head_fwd_f32(float *params, const float *bias, float *eps, uint64_t *rng_ctl, float *action,
                                int64_t action_stride, float *logp, int64_t batch, int act_dim, cstr_stream_t stream);
@@ -334,6 +334,25 @@ int cstr_gaussian_head_bwd_input_f32(const float *g_action, int64_t ga_stride, c
                                      int64_t action_stride, const float *params, const float *eps, const float *w,
                                      const float *hidden, int64_t ldh, int act, float *g_params, float *dz, int64_t batch,
                                      int act_dim, int64_t width, cstr_stream_t stream);
+
+/* A whole policy network for MANY rows, inference only (no activations kept, no backward): create_mlp(k0, ., [h1, h2]) with
+ * activation `act` on both hidden layers (core/common/torch_layers.py:110-183) + the action head, ONE launch.
+ * head 0: SAC's squashed Gaussian (core/sac/policies.py:147-175): w3 [2A][h2] = (mu | log_std) weights, b3 [2A]; the action
+ *         (rows action_stride apart, e.g. the action columns of a critic input) = tanh(mu + exp(clamp(log_std)) * eps), eps
+ *         read ([m][A]) or drawn from the Philox stream `rng_ctl` (same stream positions as cstr_gaussian_head_fwd_f32:
+ *         counter = offset + row; the offset advances by m); logp [m] optional.
+ * head 1: deterministic actor (core/td3/policies.py:75-78): w3 [A][h2], b3 [A], action = out_act(h2 w3^T + b3); eps, rng_ctl
+ *         and logp must be NULL.
+ * h1, h2 multiples of 4, k0 <= 256, 16 * (h1 + h2 + 8) floats of LDS <= 64 KB. */
+typedef struct cstr_policy_mlp {
+    int32_t k0, h1, h2, act_dim;
+    int32_t act, head, out_act, reserved;
+    const float *w1, *b1; /* [h1][k0], [h1] */
+    const float *w2, *b2; /* [h2][h1], [h2] */
+    const float *w3, *b3; /* head */
+} cstr_policy_mlp_t;
+int cstr_policy_rows_fwd_f32(const cstr_policy_mlp_t *net, const float *x, int64_t ldx, const float *eps, uint64_t *rng_ctl,
+                             float *action, int64_t action_stride, float *logp, int64_t m, cstr_stream_t stream);
 
 /* TD3 / MADDPG target policy smoothing (core/td3/td3.py:167-173; core/maddpg/maddpg.py:131-142) in one launch:
  * noise = clamp(N(0, sigma), -clip, clip); out = clamp(action + noise, -1, 1). action [B][A] contiguous (the target

@@ -26,6 +26,10 @@ from core.common import hip_ops
 
 ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2
 
+# inference passes with more rows than this run the whole policy network in one launch (cstr_policy_rows_fwd_f32): a workgroup
+# per 16 rows; below it the per-layer kernels spread the same work over more CUs and win (tools/policy_probe.py)
+WHOLE_NET_MIN_ROWS = 1024
+
 # Linear + bias + activation forward in ONE launch (cstr_linear_act_fwd_f32, f32 matrix cores) where it beats the rocBLAS GEMM
 # + epilogue pair: measured on MI355X (tools/linear_probe.py) for every K at batch-sized M and for narrow inputs (K <= 32) at
 # any M; the 4096-row x 256 x 256 layers of the collect-time actor stay on rocBLAS. CSTR_FUSED_LINEAR=0 turns it off.
@@ -176,6 +180,18 @@ class FastMLP:
         except NotImplementedError:
             return False
 
+    def _whole_net_ok(self, x: th.Tensor, train_params: bool) -> bool:
+        """No gradient wanted, many rows, and the network is create_mlp(k0, A <= 8, [H1, H2]) with one hidden activation."""
+        if not USE_FUSED_LINEAR or (th.is_grad_enabled() and (train_params or x.requires_grad)):
+            return False
+        layers = self.layers
+        if len(layers) != 3 or x.dim() != 2 or x.shape[0] <= WHOLE_NET_MIN_ROWS or x.stride(1) != 1 or layers[0][1] != layers[1][1]:
+            return False
+        l1, l2, l3 = (lin for lin, _ in layers)
+        return (l3.out_features <= 2 * hip_ops.nv.MAX_HEAD_ACT
+                and hip_ops.policy_rows_supported(l1.in_features, l1.out_features, l2.out_features, l3.out_features)
+                and all(lin.weight.is_contiguous() and lin.weight.data_ptr() % 16 == 0 for lin in (l2, l3)) and l1.weight.is_contiguous())
+
     def tail_below(self, train_params: bool):
         """what a fused consumer of this MLP's output needs to run the last layer's activation / bias gradient itself"""
         return (self.layers[-1][1], None)
@@ -183,6 +199,10 @@ class FastMLP:
     def __call__(self, x: th.Tensor, train_params: bool = True, out_grad_is_dz: bool = False) -> th.Tensor:
         """`out_grad_is_dz`: the consumer is a fused layer built with `below=self.tail_below(...)` (see _input_grad)."""
         layers = self.layers
+        if self._whole_net_ok(x, train_params):  # a deterministic actor's rollout pass: ONE launch, nothing kept
+            (l1, act), (l2, _), (l3, out_act) = layers
+            out = th.empty(x.shape[0], l3.out_features, dtype=x.dtype, device=x.device)
+            return hip_ops.policy_rows_fwd(x, l1.weight, l1.bias, l2.weight, l2.bias, l3.weight, l3.bias, act, 1, out_act, out)
         scalar_head = len(layers) >= 2 and layers[-1][0].out_features == 1 and layers[-1][1] == ACT_NONE
         plain = layers[:-2] if scalar_head else layers
         below = None
@@ -422,6 +442,20 @@ class FastSacActor:
         if self.rng_ctl is not None:
             self.rng_ctl.copy_(hip_ops.new_rng_ctl(seed, self.rng_ctl.device))
 
+    def _whole_net_ok(self, obs: th.Tensor, train_params: bool) -> bool:
+        """No gradient wanted and the network is create_mlp(obs, ., [H1, H2]) with one activation: cstr_policy_rows_fwd_f32."""
+        if not USE_FUSED_LINEAR or (th.is_grad_enabled() and (train_params or obs.requires_grad)):
+            return False
+        if obs.shape[0] <= WHOLE_NET_MIN_ROWS:  # batch-sized passes: the per-layer kernels spread over more CUs (tools/policy_probe.py)
+            return False
+        layers = self.latent.layers
+        if len(layers) != 2 or layers[0][1] != layers[1][1] or obs.dim() != 2 or obs.stride(1) != 1:
+            return False
+        (l1, _), (l2, _) = layers
+        return (hip_ops.policy_rows_supported(l1.in_features, l1.out_features, l2.out_features, 2 * self.act_dim)
+                and l1.weight.is_contiguous() and l2.weight.is_contiguous() and l2.weight.data_ptr() % 16 == 0
+                and self._hw.is_contiguous() and self._hw.data_ptr() % 16 == 0)
+
     def dist_params(self, obs: th.Tensor, train_params: bool = True) -> th.Tensor:
         """[B, 2A] = [mean | log_std_raw]"""
         h = self.latent(obs, train_params)
@@ -447,9 +481,18 @@ class FastSacActor:
             if xbuf is not None:
                 return th.cat((xbuf[:, :xbuf.shape[1] - self.act_dim], action), dim=1), logp
             return action, logp
-        h = self.latent(obs, train_params, out_grad_is_dz=True)  # this head runs the latent net's last activation gradient
         if self.rng_ctl is None:
             self.rng_ctl = hip_ops.new_rng_ctl(th.initial_seed(), obs.device)
+        if self._whole_net_ok(obs, train_params):
+            # inference (rollout, target pass): latent net + head + sampling in ONE launch, nothing kept for a backward
+            n = obs.shape[0]
+            (l1, act), (l2, _) = self.latent.layers
+            action = xbuf[:, xbuf.shape[1] - self.act_dim:] if xbuf is not None else th.empty(n, self.act_dim, dtype=obs.dtype, device=obs.device)
+            logp = th.empty(n, dtype=obs.dtype, device=obs.device) if want_logp else None
+            hip_ops.policy_rows_fwd(obs, l1.weight, l1.bias, l2.weight, l2.bias, self._hw, self._hb, act, 0, ACT_NONE, action,
+                                    eps=eps, rng_ctl=None if eps is not None else self.rng_ctl, logp=logp)
+            return (xbuf if xbuf is not None else action), logp
+        h = self.latent(obs, train_params, out_grad_is_dz=True)  # this head runs the latent net's last activation gradient
         grad = th.is_grad_enabled() and (h.requires_grad or train_params)
         tp = train_params and grad
         below = self.latent.tail_below(train_params) if h.requires_grad else None

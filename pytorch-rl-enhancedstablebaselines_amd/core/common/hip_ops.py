@@ -318,8 +318,8 @@ def bias_act_bwd(gy, y, act: int, gz, gbias):
 
 
 def new_rng_ctl(seed: int, device) -> th.Tensor:
-    """{seed, offset, ticket, -} of the in-kernel Philox stream (cstr_gaussian_head_fwd_f32), int64 bit patterns"""
-    return th.tensor([int(seed) & 0x7FFFFFFFFFFFFFFF, 0, 0, 0], dtype=th.int64).to(device)
+    """{seed, offset, ticket, -, sub-tickets[8], -} of the in-kernel Philox stream (cstr_gaussian_head_fwd_f32), int64 bit patterns"""
+    return th.tensor([int(seed) & 0x7FFFFFFFFFFFFFFF] + [0] * (nv.RNG_CTL_WORDS - 1), dtype=th.int64).to(device)
 
 
 def gaussian_head_fwd_(params, bias, eps, rng_ctl, action, logp):
@@ -381,6 +381,34 @@ def gaussian_head_bwd_input(g_action, g_logp, action, params, eps, weight, hidde
                                                     ptr(g_params), ptr(dz), C.c_int64(b), C.c_int(a), C.c_int64(h), stream_ptr()),
           "cstr_gaussian_head_bwd_input_f32")
     return dz
+
+
+POLICY_LDS_FLOATS = 16 * 1024  # 64 KB
+
+
+def policy_rows_supported(k0: int, h1: int, h2: int, n_out: int) -> bool:
+    return (k0 <= 256 and h1 % 4 == 0 and h2 % 4 == 0 and 16 * (h1 + h2 + 8) <= POLICY_LDS_FLOATS
+            and n_out <= 2 * nv.MAX_HEAD_ACT)
+
+
+def policy_rows_fwd(x, w1, b1, w2, b2, w3, b3, act: int, head: int, out_act: int, action, eps=None, rng_ctl=None, logp=None):
+    """A two-hidden-layer policy network + action head for all rows of x in ONE launch, inference only (cstr_policy_rows_fwd_f32).
+    head 0: squashed-Gaussian sample (w3 [2A, H2]; noise from `eps` [M, A] or the Philox stream `rng_ctl`; optional `logp`);
+    head 1: deterministic out_act(h2 @ w3^T + b3). `action` [M, A] may be a column block of a wider row-major matrix."""
+    m, k0 = x.shape
+    h1, h2, n_out = w1.shape[0], w2.shape[0], w3.shape[0]
+    a = n_out // 2 if head == 0 else n_out
+    if not (x.is_cuda and x.dtype == th.float32 and x.dim() == 2 and x.stride(1) == 1):
+        raise ValueError("x: needs a float32 device matrix with unit column stride")
+    _chk(w1, "w1", (h1, k0), th.float32), _chk(b1, "b1", (h1,), th.float32), _chk(w2, "w2", (h2, h1), th.float32)
+    _chk(b2, "b2", (h2,), th.float32), _chk(w3, "w3", (n_out, h2), th.float32), _chk(b3, "b3", (n_out,), th.float32)
+    _opt(eps, "eps", (m, a), th.float32), _opt(rng_ctl, "rng_ctl", (nv.RNG_CTL_WORDS,), th.int64), _opt(logp, "logp", (m,), th.float32)
+    stride = _rows(action, "action", m, a)
+    net = nv.PolicyMlp(k0, h1, h2, a, act, head, out_act, 0, w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), w3.data_ptr(),
+                       b3.data_ptr())
+    check(nv.lib().cstr_policy_rows_fwd_f32(C.byref(net), ptr(x), C.c_int64(max(x.stride(0), k0)), ptr(eps), ptr(rng_ctl), ptr(action),
+                                            C.c_int64(stride), ptr(logp), C.c_int64(m), stream_ptr()), "cstr_policy_rows_fwd_f32")
+    return action
 
 
 def linear_act_fwd(x, weight, bias, act: int, out=None):

@@ -850,6 +850,211 @@ __global__ __launch_bounds__(256) void gaussian_head_bwd_input_kernel(const floa
     }
 }
 
+// ---- whole policy network, inference only ------------------------------------------------------------------------
+// create_mlp(obs_dim, ., [H1, H2]) + the action head for MANY rows and no backward (the rollout's 4096-row policy pass, the
+// target's pi(next_obs) pass): ONE launch instead of three to six. A workgroup owns 16 rows and keeps their activations
+// in LDS the whole way:
+//   phase 1  h1 = act(x W1^T + b1)          K0 <= 64 inputs: plain FMAs, x staged in LDS
+//   phase 2  h2 = act(h1 W2^T + b2)         f32 matrix cores: 8 waves take the 16-column tiles round robin, A = h1 from LDS
+//                                           (row stride H1 + 4 floats: conflict-free 16-byte reads), B = W2 rows from L2
+//   phase 3  head: n_out <= 8 dot products per row (one wave per row, like gaussian_head_gemm_fwd_kernel), then either the
+//            squashed-Gaussian sample (HEAD 0: noise from the Philox stream or given, tanh, optional log-prob) or the
+//            deterministic output activation (HEAD 1: TD3 / DDPG actors).
+// Every workgroup streams all of W2 (H1 x H2 x 4 bytes from L2) for 16 x H1 x H2 MACs: at 4096 rows that is one workgroup
+// per CU and the matrix-core time of 16 x 256 x 256 (about 3.4 us) bounds the launch, not the weight traffic.
+struct PolicyArgs {
+    const float *x; int64_t ldx; int k0;
+    const float *w1, *b1; int h1;
+    const float *w2, *b2; int h2;
+    const float *w3, *b3; int act_dim, out_act;
+    const float *eps_in; uint64_t *rng_ctl;
+    float *action; int64_t action_stride; float *logp; int64_t m;
+};
+
+constexpr int POLICY_ROWS = 16, POLICY_WAVES = 8;
+
+// "Last workgroup out" with a two-level ticket for large grids: 256 same-address atomics serialise to ~4 us; here the
+// workgroups draw from 8 sub-counters (blockIdx & 7: different L2 channels, in parallel) and only the last of each group
+// touches the top counter. Same contract as last_block_ticket (cstr_device.h): counters self-reset for the next launch.
+__device__ __forceinline__ bool last_block_ticket_tree(unsigned long long *top, unsigned long long *sub)
+{
+    __shared__ int tree_is_last;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned g = blockIdx.x & 7u, G = gridDim.x;
+        const unsigned long long members = (G >> 3) + (g < (G & 7u) ? 1u : 0u), groups = G < 8u ? G : 8u;
+        int last = 0;
+        if (atomicAdd(sub + g, 1ULL) == members - 1ULL) {
+            sub[g] = 0ULL;
+            if (atomicAdd(top, 1ULL) == groups - 1ULL) {
+                *top = 0ULL;
+                last = 1;
+            }
+        }
+        tree_is_last = last;
+    }
+    __syncthreads();
+    return tree_is_last != 0;
+}
+
+// One hidden layer for the workgroup's 16 rows: out[16][N] (LDS, row stride so) = act(in[16][K] W^T + b). The waves take the
+// 16-column tiles round robin, TWO per pass: every lane issues ALL of its loads for both tiles (up to 256 k values each) at
+// once (A = input rows, shared by the two tiles: global memory for the first layer, LDS after it; B = weight rows from L2), so
+// a layer of up to 16 x POLICY_WAVES columns costs one memory round trip.
+template <int ACT, bool A_GLOBAL, bool VEC>
+__device__ __forceinline__ void policy_layer(const float *__restrict__ in, const int64_t in_stride, const bool in_row_ok, const int K,
+                                             const float *__restrict__ w, const float *__restrict__ bias, const int N,
+                                             float *__restrict__ out, const int so)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, h = lane >> 4;
+    const int tiles = (N + 15) >> 4;
+    const float *ar = in + r * in_stride;
+    for (int t = wave; t < tiles; t += 2 * POLICY_WAVES) {
+        const int n0 = t * 16, n1 = n0 + 16 * POLICY_WAVES;
+        const bool ok0 = n0 + r < N, ok1 = n1 + r < N;
+        const bool second = t + POLICY_WAVES < tiles;  // wave-uniform
+        const float *wr0 = w + (int64_t)(n0 + r) * K, *wr1 = w + (int64_t)(n1 + r) * K;
+        f32x4 c00 = {0.0f, 0.0f, 0.0f, 0.0f}, c01 = c00, c10 = c00, c11 = c00;
+        constexpr int UNROLL = 16;
+        for (int c0 = 0; c0 < K; c0 += 16 * UNROLL) {
+            float4 av[UNROLL], b0[UNROLL], b1[UNROLL];
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+                const int k = c0 + 16 * u + 4 * h;
+                b0[u] = load_k4<VEC>(wr0, k, K, ok0);
+                av[u] = A_GLOBAL ? load_k4<VEC>(ar, k, K, in_row_ok) : load_k4<true>(ar, k, K, true);
+            }
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) b1[u] = load_k4<VEC>(wr1, c0 + 16 * u + 4 * h, K, ok1 && second);
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+                if (c0 + 16 * u >= K) break;  // wave-uniform: no matrix-core passes on all-zero chunks (K = 4: one chunk)
+                c00 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u].x, b0[u].x, c00, 0, 0, 0);
+                c01 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u].y, b0[u].y, c01, 0, 0, 0);
+                c00 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u].z, b0[u].z, c00, 0, 0, 0);
+                c01 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u].w, b0[u].w, c01, 0, 0, 0);
+            }
+            if (second) {
+#pragma unroll
+                for (int u = 0; u < UNROLL; ++u) {
+                    if (c0 + 16 * u >= K) break;
+                    c10 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u].x, b1[u].x, c10, 0, 0, 0);
+                    c11 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u].y, b1[u].y, c11, 0, 0, 0);
+                    c10 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u].z, b1[u].z, c10, 0, 0, 0);
+                    c11 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u].w, b1[u].w, c11, 0, 0, 0);
+                }
+            }
+        }
+        // column = lane & 15, row = 4 * (lane >> 4) + register
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int col = (half ? n1 : n0) + r;
+            if (half ? (ok1 && second) : ok0) {
+                const f32x4 acc = half ? c10 + c11 : c00 + c01;
+                const float bb = bias[col];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = acc[e] + bb;
+                    if (ACT == ACT_RELU) v = fmaxf(v, 0.0f);
+                    if (ACT == ACT_TANH) v = tanhf(v);
+                    out[(4 * h + e) * so + col] = v;
+                }
+            }
+        }
+    }
+}
+
+template <int ACT, int HEAD, bool VEC0>
+__global__ __launch_bounds__(64 * POLICY_WAVES) void policy_rows_fwd_kernel(const PolicyArgs a)
+{
+    extern __shared__ float policy_lds[];
+    const int H1 = a.h1, H2 = a.h2, S1 = H1 + 4, S2 = H2 + 4;
+    float *h1s = policy_lds, *h2s = h1s + POLICY_ROWS * S1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t m0 = (int64_t)blockIdx.x * POLICY_ROWS;
+    const uint64_t seed = a.rng_ctl ? a.rng_ctl[0] : 0ull, base = a.rng_ctl ? a.rng_ctl[1] : 0ull;
+    const int n_out = HEAD == 0 ? 2 * a.act_dim : a.act_dim;
+    policy_layer<ACT, true, VEC0>(a.x + m0 * a.ldx, a.ldx, m0 + (lane & 15) < a.m, a.k0, a.w1, a.b1, H1, h1s, S1);
+    __syncthreads();
+    policy_layer<ACT, false, true>(h1s, S1, true, H1, a.w2, a.b2, H2, h2s, S2);
+    __syncthreads();
+
+    // head: POLICY_ROWS / POLICY_WAVES = 2 rows per wave, evaluated together (one pass over the head's weights)
+    constexpr int RPW = POLICY_ROWS / POLICY_WAVES;
+    float p[RPW][2 * CSTR_MAX_HEAD_ACT];
+#pragma unroll
+    for (int q = 0; q < RPW; ++q)
+#pragma unroll
+        for (int j = 0; j < 2 * CSTR_MAX_HEAD_ACT; ++j) p[q][j] = 0.0f;
+    for (int c = lane * 4; c < H2; c += 256) {
+        float4 hv[RPW];
+#pragma unroll
+        for (int q = 0; q < RPW; ++q) hv[q] = *reinterpret_cast<const float4 *>(h2s + (wave + q * POLICY_WAVES) * S2 + c);
+#pragma unroll
+        for (int j = 0; j < 2 * CSTR_MAX_HEAD_ACT; ++j) {
+            if (j >= n_out) break;
+            const float4 wv = *reinterpret_cast<const float4 *>(a.w3 + (int64_t)j * H2 + c);
+#pragma unroll
+            for (int q = 0; q < RPW; ++q) p[q][j] += (hv[q].x * wv.x + hv[q].y * wv.y) + (hv[q].z * wv.z + hv[q].w * wv.w);
+        }
+    }
+    // the reduced head outputs meet in LDS (h1s is free again); then ONE wave samples all 16 rows, a lane per row: the
+    // Philox / Box-Muller / tanh / log chain is ~1.5 k instructions, run once instead of once per row
+    float *ps = h1s;  // [POLICY_ROWS][2 * CSTR_MAX_HEAD_ACT]
+#pragma unroll
+    for (int q = 0; q < RPW; ++q) {
+#pragma unroll
+        for (int j = 0; j < 2 * CSTR_MAX_HEAD_ACT; ++j) {
+            if (j >= n_out) break;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) p[q][j] += __shfl_xor(p[q][j], o, 64);
+            if (lane == 0) ps[(wave + q * POLICY_WAVES) * 2 * CSTR_MAX_HEAD_ACT + j] = p[q][j] + a.b3[j];
+        }
+    }
+    __syncthreads();
+    const int64_t row = m0 + lane;
+    if (wave == 0 && lane < POLICY_ROWS && row < a.m) {
+        const float *pr = ps + lane * 2 * CSTR_MAX_HEAD_ACT;
+        if (HEAD == 1) {
+            for (int j = 0; j < n_out; ++j) {
+                float v = pr[j];
+                if (a.out_act == ACT_RELU) v = fmaxf(v, 0.0f);
+                if (a.out_act == ACT_TANH) v = tanhf(v);
+                a.action[row * a.action_stride + j] = v;
+            }
+        } else {
+            const float half_log_2pi = 0.91893853320467274178f;
+            float lp = 0.0f, corr = 0.0f;
+            for (int j0 = 0; j0 < a.act_dim; j0 += 2) {
+                float e[2] = {0.0f, 0.0f};
+                if (!a.eps_in) {
+                    const uint64_t ctr = base + (uint64_t)row;
+                    uint32_t rnd[4];
+                    philox4x32_10((uint32_t)ctr, (uint32_t)(ctr >> 32), (uint32_t)(j0 >> 1), 0u, (uint32_t)seed, (uint32_t)(seed >> 32), rnd);
+                    box_muller(rnd[0], rnd[1], e[0], e[1]);
+                }
+                for (int jj = 0; jj < 2 && j0 + jj < a.act_dim; ++jj) {
+                    const int j = j0 + jj;
+                    if (a.eps_in) e[jj] = a.eps_in[row * a.act_dim + j];
+                    const float mu = pr[j], raw = pr[a.act_dim + j];
+                    const float ls = fminf(fmaxf(raw, LOG_STD_MIN), LOG_STD_MAX);
+                    const float sd = expf(ls);
+                    const float u = mu + sd * e[jj];
+                    const float act = tanhf(u);
+                    const float d = u - mu, var = sd * sd;
+                    lp += -(d * d) / (2.0f * var) - logf(sd) - half_log_2pi;
+                    corr += logf(1.0f - act * act + 1e-6f);
+                    a.action[row * a.action_stride + j] = act;
+                }
+            }
+            if (a.logp) a.logp[row] = lp - corr;
+        }
+    }
+    if (a.rng_ctl && last_block_ticket_tree(reinterpret_cast<unsigned long long *>(a.rng_ctl + 2),
+                                            reinterpret_cast<unsigned long long *>(a.rng_ctl + 4)) && tid == 0)
+        a.rng_ctl[1] = base + (uint64_t)a.m;
+}
+
 // ---- loss heads (single workgroup; batch <= 16384) -----------------------------------------------------
 
 // SAC entropy coefficient (core/sac/sac.py:230-243): ent_coef = exp(log_alpha); loss = -mean(log_alpha * (logp + H));
@@ -1186,6 +1391,35 @@ extern "C" int cstr_gaussian_head_bwd_input_f32(const float *g_action, int64_t g
         params, eps, w, hidden, ldh, g_params, dz, batch, act_dim, (int)width)
     if (act == 0) HBI(0); else if (act == 1) HBI(1); else HBI(2);
 #undef HBI
+    return (int)hipGetLastError();
+}
+
+extern "C" int cstr_policy_rows_fwd_f32(const cstr_policy_mlp_t *net, const float *x, int64_t ldx, const float *eps, uint64_t *rng_ctl,
+                                       float *action, int64_t action_stride, float *logp, int64_t m, cstr_stream_t stream)
+{
+    if (!net || !x || !action || m <= 0) return CSTR_E_BADARG;
+    const cstr_policy_mlp_t &n = *net;
+    if (!n.w1 || !n.b1 || !n.w2 || !n.b2 || !n.w3 || !n.b3 || n.k0 <= 0 || n.h1 <= 0 || n.h2 <= 0 || n.act_dim <= 0) return CSTR_E_BADARG;
+    if (ldx < n.k0 || action_stride < n.act_dim) return CSTR_E_BADARG;
+    if (n.head == 0 && (eps == nullptr) == (rng_ctl == nullptr)) return CSTR_E_BADARG;  // exactly one noise source
+    if (n.head != 0 && (eps || rng_ctl || logp)) return CSTR_E_BADARG;
+    const size_t lds = (size_t)POLICY_ROWS * (n.h1 + 4 + n.h2 + 4) * sizeof(float);
+    if (n.act < 0 || n.act > 2 || n.out_act < 0 || n.out_act > 2 || n.head < 0 || n.head > 1 || n.k0 > 256 || (n.h1 & 3) || (n.h2 & 3) ||
+        lds > 64 * 1024 || !aligned16(n.w2) || !aligned16(n.w3) || (n.head == 0 ? 2 : 1) * n.act_dim > 2 * CSTR_MAX_HEAD_ACT ||
+        (n.head == 0 && n.act_dim > CSTR_MAX_HEAD_ACT) || (m + POLICY_ROWS - 1) / POLICY_ROWS > 0x7fffffff)
+        return CSTR_E_UNSUPPORTED;
+    PolicyArgs a = {x, ldx, n.k0, n.w1, n.b1, n.h1, n.w2, n.b2, n.h2, n.w3, n.b3, n.act_dim, n.out_act, eps, rng_ctl,
+                    action, action_stride, logp, m};
+    const unsigned grid = (unsigned)((m + POLICY_ROWS - 1) / POLICY_ROWS);
+    const bool vec0 = (n.k0 & 3) == 0 && (ldx & 3) == 0 && aligned16(x) && aligned16(n.w1);
+    hipStream_t s = (hipStream_t)stream;
+#define POL2(A, H) do { if (vec0) policy_rows_fwd_kernel<A, H, true><<<grid, 64 * POLICY_WAVES, lds, s>>>(a); \
+                        else policy_rows_fwd_kernel<A, H, false><<<grid, 64 * POLICY_WAVES, lds, s>>>(a); } while (0)
+#define POL(A, H) POL2(A, H)
+    if (n.head == 0) { if (n.act == 0) POL(0, 0); else if (n.act == 1) POL(1, 0); else POL(2, 0); }
+    else { if (n.act == 0) POL(0, 1); else if (n.act == 1) POL(1, 1); else POL(2, 1); }
+#undef POL2
+#undef POL
     return (int)hipGetLastError();
 }
 

@@ -324,9 +324,9 @@ def test_gaussian_head_kernels_match_unfused_path_and_rng_statistics(ops):
     pz = th.zeros(n, 2 * A, device="cuda")
     e1, e2, act = th.empty(n, A, device="cuda"), th.empty(n, A, device="cuda"), th.empty(n, A, device="cuda")
     hip_ops.gaussian_head_fwd_(pz, None, e1, ctl, act, None)
-    assert ctl.cpu().tolist() == [1234, n, 0, 0]
+    assert ctl.cpu().tolist() == [1234, n] + [0] * 14
     hip_ops.gaussian_head_fwd_(pz, None, e2, ctl, act, None)
-    assert ctl.cpu().tolist() == [1234, 2 * n, 0, 0]
+    assert ctl.cpu().tolist() == [1234, 2 * n] + [0] * 14
     assert th.equal(act, th.tanh(e2))  # mean 0, log_std 0: action = tanh(eps)
     x = th.cat([e1, e2]).double().flatten()
     assert abs(float(x.mean())) < 4e-3 and abs(float(x.var()) - 1.0) < 6e-3
@@ -359,7 +359,7 @@ def test_target_smoothing_kernel(ops):
     n = 1 << 18
     big, out = th.zeros(n, A, device="cuda"), th.empty(n, A, device="cuda")
     hip_ops.target_smooth(big, None, ctl, 0.2, 0.5, out)
-    assert ctl.cpu().tolist() == [9, n, 0, 0]
+    assert ctl.cpu().tolist() == [9, n] + [0] * 14
     z = out.double().flatten()
     assert abs(float(z.mean())) < 2e-3 and abs(float(z.std()) - 0.2 * 0.98872) < 1e-3  # N(0, 0.2) clamped at 2.5 sigma
     assert float(z.abs().max()) == 0.5
@@ -568,6 +568,46 @@ def test_weight_gradients_of_several_layers_in_one_launch(ops):
         th.autograd.backward([mlp(x)], [gy])
         assert fused.USE_FUSED_LINEAR is False or float(grads().min()) == 7.0  # nothing written yet
     assert th.equal(grads(), ref) and float(ref.abs().max()) > 0.0
+
+
+@pytest.mark.parametrize("M,K0,H1,H2,A,act", [(4096, 4, 256, 256, 2, 1), (256, 4, 256, 256, 2, 1), (100, 8, 400, 300, 4, 2), (1, 3, 64, 32, 1, 1),
+                                              (37, 8, 64, 64, 2, 0)])
+def test_whole_policy_network_in_one_launch(ops, M, K0, H1, H2, A, act):
+    """cstr_policy_rows_fwd_f32 against the layer-by-layer evaluation (f64 reference for the hidden layers): squashed-Gaussian
+    head with given noise, the same head drawing from the Philox stream (same positions as cstr_gaussian_head_fwd_f32), and
+    the deterministic head."""
+    from core.common import hip_ops
+
+    g = th.Generator(device="cuda").manual_seed(M + H1)
+    r = lambda *sh: th.randn(*sh, device="cuda", generator=g)  # noqa: E731
+    x = r(M, K0 + 3)[:, :K0]  # row-strided
+    w1, b1, w2, b2 = r(H1, K0) / K0 ** 0.5, r(H1) * 0.1, r(H2, H1) / H1 ** 0.5, r(H2) * 0.1
+    w3, b3, eps = r(2 * A, H2) / H2 ** 0.5, r(2 * A) * 0.1, r(M, A)
+    f = {0: lambda t: t, 1: th.relu, 2: th.tanh}[act]
+    h2 = f(f(x.double() @ w1.double().t() + b1.double()) @ w2.double().t() + b2.double())
+    params = (h2 @ w3.double().t()).float()  # bias added by the head kernel
+    ref_a, ref_lp = th.empty(M, A, device="cuda"), th.empty(M, device="cuda")
+    hip_ops.gaussian_head_fwd_(params.clone(), b3, eps, None, ref_a, ref_lp)
+    xbuf, lp = th.full((M, 5 + A), 9.0, device="cuda"), th.empty(M, device="cuda")
+    hip_ops.policy_rows_fwd(x, w1, b1, w2, b2, w3, b3, act, 0, 0, xbuf[:, 5:], eps=eps, logp=lp)
+    assert float(xbuf[:, :5].min()) == 9.0
+    assert rel_err(xbuf[:, 5:].cpu().numpy(), ref_a.cpu().numpy(), 1.0) < 1e-5
+    assert rel_err(lp.cpu().numpy(), ref_lp.cpu().numpy(), 1.0) < 2e-4  # log(1 - a^2 + 1e-6) amplifies near saturation
+    # in-kernel noise: the stream positions of the separate head kernel
+    c1, c2 = hip_ops.new_rng_ctl(77, "cuda"), hip_ops.new_rng_ctl(77, "cuda")
+    c1[1] = c2[1] = 1000
+    a1, a2, e2 = th.empty(M, A, device="cuda"), th.empty(M, A, device="cuda"), th.empty(M, A, device="cuda")
+    hip_ops.policy_rows_fwd(x, w1, b1, w2, b2, w3, b3, act, 0, 0, a1, rng_ctl=c1)
+    hip_ops.gaussian_head_fwd_(params.clone(), b3, e2, c2, a2, None)
+    assert th.equal(c1, c2) and int(c1[1]) == 1000 + M and int(c1[2]) == 0
+    assert rel_err(a1.cpu().numpy(), a2.cpu().numpy(), 1.0) < 1e-5
+    # deterministic head (TD3 actor): tanh(h2 W3^T + b3) with the first A rows of w3
+    out = th.empty(M, A, device="cuda")
+    hip_ops.policy_rows_fwd(x, w1, b1, w2, b2, w3[:A].contiguous(), b3[:A].contiguous(), act, 1, 2, out)
+    ref = th.tanh(h2 @ w3[:A].double().t() + b3[:A].double())
+    assert rel_err(out.cpu().numpy(), ref.cpu().numpy(), 1.0) < 1e-5
+    with pytest.raises(Exception):
+        hip_ops.policy_rows_fwd(x, w1, b1, w2, b2, w3, b3, act, 0, 0, a1)  # no noise source
 
 
 def test_grouped_actor_forward_and_single_agent_backward(ops):
