@@ -106,10 +106,13 @@ def deferred_weight_grads():
 
 def _weight_grad(gz: th.Tensor, x: th.Tensor, wgrad: th.Tensor, bgrad: Optional[th.Tensor]) -> None:
     """dW (+ db) of one fused Linear: one launch now, or queued when a `deferred_weight_grads` context is open."""
-    if _pending_wgrads is not None and gz.dim() == 2 and x.dim() == 2:
-        _pending_wgrads.append((gz, x, wgrad, bgrad))
-    else:
+    if _pending_wgrads is None:
         hip_ops.linear_bwd_weight(gz, x, wgrad, bgrad)
+    elif gz.dim() == 2:
+        _pending_wgrads.append((gz, x, wgrad, bgrad))
+    else:  # stacked networks: one set per group (a 2-D x is the input the groups share)
+        for g in range(gz.shape[0]):
+            _pending_wgrads.append((gz[g], x[g] if x.dim() == 3 else x, wgrad[g], None if bgrad is None else bgrad[g]))
 
 
 def _param_grads(ctx, gz: th.Tensor, x: th.Tensor) -> None:
@@ -404,7 +407,10 @@ class _HiddenHeadFn(th.autograd.Function):
         dz = th.empty_like(y)
         hip_ops.hidden_head_bwd(gq.contiguous(), y, ctx.act, w2, dz, gb1, gw2, gb2)
         if ctx.train_params:
-            th.bmm(dz.transpose(1, 2), x, out=gw1) if ctx.batched else th.mm(dz.t(), x, out=gw1)
+            if USE_FUSED_LINEAR:
+                _weight_grad(dz, x, gw1, None)  # gb1 came out of the head kernel
+            else:
+                th.bmm(dz.transpose(1, 2), x, out=gw1) if ctx.batched else th.mm(dz.t(), x, out=gw1)
         dx = _input_grad(dz, w1, x, ctx.below) if ctx.needs_input_grad[0] else None
         return (dx,) + (None,) * (8 + ctx.n_owners)
 
