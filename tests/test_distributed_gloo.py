@@ -38,6 +38,7 @@ def _worker(rank, world, port, out_dir):
 
     r, lr_, w = du.init_from_env(backend="gloo")
     assert (r, w) == (rank, world) and du.rank_world() == (rank, world) and du.is_distributed()
+    assert du.graph_collectives_ok("cpu") is False  # only RCCL on a GPU qualifies for collectives inside hipGraphs
 
     # different init per rank, then rank-0 broadcast of the flat arena
     net = _mlp(100 + rank)
@@ -91,6 +92,6 @@ def test_shard_seeds_are_the_global_env_seeds():
 def test_single_process_defaults():
     from core.common import distributed as du
 
-    assert du.rank_world() == (0, 1) and not du.is_distributed()
+    assert du.rank_world() == (0, 1) and not du.is_distributed() and du.graph_collectives_ok("cpu") is False
     t = th.ones(4)
     assert du.allreduce_sum_(t) is t and th.equal(t, th.ones(4))
