@@ -15,6 +15,8 @@ Extra objects on the JSON line:
                 right after the timed region). At N=4096 the launch moves 426 KB and is latency-bound.
   roofline_stream  the same kernel at N = 2^22 envs (436 MB per launch, far above every cache): what the kernel
                 reaches when it is actually bandwidth-bound. Never to be confused with the end-to-end figure.
+  roofline_mfma the longest launch of the iteration, the rollout's whole policy network in one launch (f32 matrix cores):
+                algorithmic FLOPs per launch / measured launch duration against the dense f32 MFMA peak.
   kernels       per-kernel average launch duration / algorithmic GB/s for the other HIP kernels of the step
   cpu_baseline  the oracle port (C env step + ring add + MT19937 sampler with OpenMP, torch-CPU SAC step)
                 timed on this box's host cores on a bounded sample of the same workload (rank 0, N=1 only).
@@ -407,6 +409,9 @@ def main():
                                         "the bandwidth-bound regime of the same kernel")
             line["roofline_stream"] = roofline_collect(1 << 22, args.obs_dim, args.integrator, 30)
             line["kernels"] = other_kernels(model, B)
+            pk = line["kernels"]["policy_rows_fwd_kernel"]  # the LONGEST launch of the iteration, matrix-core bound
+            line["roofline_mfma"] = dict(bound="mfma", kernel="policy_rows_fwd_kernel", achieved=pk["tflops"], peak=F32_MFMA_PEAK_TFLOPS,
+                                         unit="TFLOP/s", frac=pk["frac"], traffic=None, launch_us=pk["launch_us"], shape=pk["shape"])
         if world == 1 and not args.no_variant and args.algo == "sac" and (args.obs_dim, args.integrator) == (4, "euler"):
             del model, env
             dev = f"cuda:{local_rank}"
