@@ -215,6 +215,10 @@ typedef struct {
     float *param; const float *grad; float *exp_avg; float *exp_avg_sq; int64_t *adam_ctl; const double *lr;
     double beta1, beta2, eps; float grad_scale; int64_t n;
     const float *polyak_source; double tau;
+    /* optional (NULL = none): a tile-major shadow copy (cstr_policy_swizzle_f32) of the [shadow_n][shadow_k] weight matrix that
+     * starts shadow_begin floats into `param` -- rewritten by the same threads that update those weights, so the policy
+     * kernel's copy never lags the parameters. shadow_begin and shadow_k are multiples of 4. */
+    float *shadow; int64_t shadow_begin, shadow_n, shadow_k;
 } cstr_adam_seg_t;
 int cstr_adam_multi_f32(const cstr_adam_seg_t *segs, int n_segs, cstr_stream_t stream);
 
@@ -350,7 +354,13 @@ typedef struct cstr_policy_mlp {
     const float *w1, *b1; /* [h1][k0], [h1] */
     const float *w2, *b2; /* [h2][h1], [h2] */
     const float *w3, *b3; /* head */
+    const float *w2_swizzled; /* NULL, or w2 in the tile-major layout of cstr_policy_swizzle_f32 (full-line loads) */
 } cstr_policy_mlp_t;
+/* Tile-major copy of a weight matrix w [n][k] (k a multiple of 4) for the matrix-core operand loads of
+ * cstr_policy_rows_fwd_f32: out[((tile * ceil(k/16) + chunk) * 64 + lane) * 4 + e] = w[16 tile + (lane & 15)][16 chunk +
+ * 4 (lane >> 4) + e], zeros outside the matrix; out holds ceil(n/16) * ceil(k/16) * 256 floats. A wave's operand load then
+ * reads 1 KB of consecutive bytes instead of sixteen 64-byte row pieces. */
+int cstr_policy_swizzle_f32(const float *w, int64_t n, int64_t k, float *out, cstr_stream_t stream);
 int cstr_policy_rows_fwd_f32(const cstr_policy_mlp_t *net, const float *x, int64_t ldx, const float *eps, uint64_t *rng_ctl,
                              float *action, int64_t action_stride, float *logp, int64_t m, cstr_stream_t stream);
 

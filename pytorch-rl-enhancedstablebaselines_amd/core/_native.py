@@ -20,7 +20,7 @@ RNG_CTL_WORDS, MAX_HEAD_ACT, MAX_LINEAR_SETS = 16, 4, 8
 SYMBOLS = (
     "cstr_abi_version", "cstr_error_string", "cstr_default_coef", "cstr_vec_step_f32", "cstr_reset_draw_f32",
     "cstr_replay_add_f32", "cstr_collect_step_f32", "cstr_mt19937_seed", "cstr_mt19937_normal_f32", "cstr_mt19937_normal_f64", "cstr_replay_sample_mt19937_f32", "cstr_replay_sample_packed_mt19937_f32",
-    "cstr_adam_multi_f32", "cstr_gaussian_head_fwd_f32", "cstr_gaussian_head_gemm_fwd_f32", "cstr_gaussian_head_bwd_f32", "cstr_gaussian_head_bwd_input_f32", "cstr_linear_act_fwd_f32", "cstr_linear_act_fwd_sets_f32", "cstr_linear_bwd_input_f32", "cstr_linear_bwd_weight_f32", "cstr_linear_bwd_weight_sets_f32", "cstr_td_twin_q_loss_f32", "cstr_policy_rows_fwd_f32", "cstr_target_smooth_f32", "cstr_hidden_head_fwd_f32", "cstr_hidden_head_bwd_f32", "cstr_vecnorm_init_f64", "cstr_vecnorm_step_f64", "cstr_vecnorm_apply_f32",
+    "cstr_adam_multi_f32", "cstr_gaussian_head_fwd_f32", "cstr_gaussian_head_gemm_fwd_f32", "cstr_gaussian_head_bwd_f32", "cstr_gaussian_head_bwd_input_f32", "cstr_linear_act_fwd_f32", "cstr_linear_act_fwd_sets_f32", "cstr_linear_bwd_input_f32", "cstr_linear_bwd_weight_f32", "cstr_linear_bwd_weight_sets_f32", "cstr_td_twin_q_loss_f32", "cstr_policy_rows_fwd_f32", "cstr_policy_swizzle_f32", "cstr_target_smooth_f32", "cstr_hidden_head_fwd_f32", "cstr_hidden_head_bwd_f32", "cstr_vecnorm_init_f64", "cstr_vecnorm_step_f64", "cstr_vecnorm_apply_f32",
     "cstr_td_target_min_f32", "cstr_polyak_f32", "cstr_adam_f32", "cstr_bias_act_fwd_f32", "cstr_bias_act_bwd_f32",
     "cstr_squashed_gaussian_fwd_f32", "cstr_squashed_gaussian_bwd_f32", "cstr_sac_alpha_f32", "cstr_twin_q_loss_f32",
     "cstr_sac_actor_loss_f32", "cstr_neg_mean_loss_f32",
@@ -47,7 +47,8 @@ class AdamSeg(C.Structure):
     """cstr_adam_seg_t"""
     _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
                 ("adam_ctl", C.c_void_p), ("lr", C.c_void_p), ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double),
-                ("grad_scale", C.c_float), ("n", C.c_int64), ("polyak_source", C.c_void_p), ("tau", C.c_double)]
+                ("grad_scale", C.c_float), ("n", C.c_int64), ("polyak_source", C.c_void_p), ("tau", C.c_double),
+                ("shadow", C.c_void_p), ("shadow_begin", C.c_int64), ("shadow_n", C.c_int64), ("shadow_k", C.c_int64)]
 
 
 class LinearSet(C.Structure):
@@ -71,7 +72,7 @@ class PolicyMlp(C.Structure):
     """cstr_policy_mlp_t"""
     _fields_ = [("k0", C.c_int32), ("h1", C.c_int32), ("h2", C.c_int32), ("act_dim", C.c_int32), ("act", C.c_int32), ("head", C.c_int32),
                 ("out_act", C.c_int32), ("reserved", C.c_int32), ("w1", C.c_void_p), ("b1", C.c_void_p), ("w2", C.c_void_p),
-                ("b2", C.c_void_p), ("w3", C.c_void_p), ("b3", C.c_void_p)]
+                ("b2", C.c_void_p), ("w3", C.c_void_p), ("b3", C.c_void_p), ("w2_swizzled", C.c_void_p)]
 
 
 class VecNormCfg(C.Structure):

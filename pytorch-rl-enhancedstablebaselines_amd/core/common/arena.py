@@ -149,6 +149,7 @@ class FlatAdam:
         self.lr_dev = th.tensor([lr], dtype=th.float64, device=dev)
         self._lr_on_device = float(lr)
         self.grad_scale = 1.0  # 1 / world_size after a summing all-reduce
+        self.shadow = None  # (tile-major copy, offset in the arena, rows, cols, parameter) of ONE weight matrix, see add_weight_shadow
 
     def zero_grad(self, set_to_none: bool = False) -> None:
         self.arena.zero_grad()
@@ -164,13 +165,42 @@ class FlatAdam:
     def step(self, closure=None) -> None:
         g = self.param_groups[0]
         with th.cuda.device(self.arena.device):
+            if self.shadow is not None:  # the multi-segment kernel is the one that keeps a shadow copy current
+                hip_ops.adam_multi([self._segment()])
+                return
             hip_ops.adam(self.arena.flat, self.arena.grad, self.exp_avg, self.exp_avg_sq, self.ctl, self.lr_dev,
                          g["betas"][0], g["betas"][1], g["eps"], self.grad_scale)
 
     def _segment(self) -> tuple:
         g = self.param_groups[0]
-        return (self.arena.flat, self.arena.grad, self.exp_avg, self.exp_avg_sq, self.ctl, self.lr_dev, g["betas"][0], g["betas"][1],
-                g["eps"], self.grad_scale)
+        seg = (self.arena.flat, self.arena.grad, self.exp_avg, self.exp_avg_sq, self.ctl, self.lr_dev, g["betas"][0], g["betas"][1],
+               g["eps"], self.grad_scale)
+        return seg if self.shadow is None else seg + (self.shadow[:4],)
+
+    def add_weight_shadow(self, param: nn.Parameter) -> th.Tensor:
+        """Keep a tile-major copy (hip_ops.policy_swizzle) of ONE [N, K] weight matrix of this arena for the policy kernel's
+        operand loads: every step rewrites it together with the weights; `refresh_shadow()` after anything else changed them."""
+        if self.shadow is not None:
+            if self.shadow[4] is param:
+                return self.shadow[0]
+            raise ValueError("one weight shadow per optimiser")
+        o = self.arena.offset_of[id(param)]
+        n, k = param.shape
+        if o % 4 or k % 4:
+            raise ValueError("shadowed matrix: offset and width must be multiples of 4")
+        with th.cuda.device(self.arena.device):
+            self.shadow = (hip_ops.policy_swizzle(param.detach()), o, n, k, param)
+        self._shadow_version = param._version
+        return self.shadow[0]
+
+    def refresh_shadow(self, force: bool = True) -> None:
+        """Re-derive the shadow copy from the weights (after load_state_dict / set_parameters / a broadcast: anything that
+        changed them other than step()). force=False: only when torch's version counter of the parameter moved."""
+        if self.shadow is None or (not force and self.shadow[4]._version == self._shadow_version):
+            return
+        with th.cuda.device(self.arena.device):
+            hip_ops.policy_swizzle(self.shadow[4].detach(), self.shadow[0])
+        self._shadow_version = self.shadow[4]._version
 
     def step_with(self, *others: "FlatAdam", polyak=None) -> None:
         """This optimiser's step, the others' and -- polyak=(source arena, target arena, tau) -- a soft target update of

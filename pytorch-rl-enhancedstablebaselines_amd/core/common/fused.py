@@ -426,6 +426,21 @@ def hidden_head(x, w1, b1, w2, b2, grads, act: int, train_params: bool, owners=(
     return hip_ops.hidden_head_fwd_(z, b1, act, w2, b2, q)
 
 
+def _weight_shadow(optimizer, weight: nn.Parameter) -> Optional[th.Tensor]:
+    """The tile-major copy of `weight` that `optimizer` (a FlatAdam over the arena holding it) keeps current with every step
+    (arena.FlatAdam.add_weight_shadow), or None. Changes made by torch since the last look (load_state_dict, ...) are caught
+    through the parameter's version counter; OffPolicyAlgorithm._setup_learn refreshes it before captured graphs replay."""
+    from core.common.arena import FlatAdam
+
+    if not isinstance(optimizer, FlatAdam) or id(weight) not in optimizer.arena.offset_of or weight.shape[1] % 4:
+        return None
+    if optimizer.shadow is not None and optimizer.shadow[4] is not weight:
+        return None
+    shadow = optimizer.add_weight_shadow(weight)
+    optimizer.refresh_shadow(force=False)
+    return shadow
+
+
 class FastSacActor:
     """core/sac/policies.py:147-175 on the fused path. With `head` = (stacked [2, A, H] weight view, [2, A] bias view and
     their gradient views) the mu and log_std heads are ONE GEMM with N = 2A."""
@@ -496,7 +511,8 @@ class FastSacActor:
             action = xbuf[:, xbuf.shape[1] - self.act_dim:] if xbuf is not None else th.empty(n, self.act_dim, dtype=obs.dtype, device=obs.device)
             logp = th.empty(n, dtype=obs.dtype, device=obs.device) if want_logp else None
             hip_ops.policy_rows_fwd(obs, l1.weight, l1.bias, l2.weight, l2.bias, self._hw, self._hb, act, 0, ACT_NONE, action,
-                                    eps=eps, rng_ctl=None if eps is not None else self.rng_ctl, logp=logp)
+                                    eps=eps, rng_ctl=None if eps is not None else self.rng_ctl, logp=logp,
+                                    w2_swz=_weight_shadow(getattr(self.actor, "optimizer", None), l2.weight))
             return (xbuf if xbuf is not None else action), logp
         h = self.latent(obs, train_params, out_grad_is_dz=True)  # this head runs the latent net's last activation gradient
         grad = th.is_grad_enabled() and (h.requires_grad or train_params)

@@ -254,8 +254,9 @@ def adam(param, grad, exp_avg, exp_avg_sq, adam_ctl, lr_dev, beta1=0.9, beta2=0.
 
 
 def adam_multi(segments):
-    """Several flat-arena updates in one launch; `segments` = iterable of adam()'s positional argument tuples, or
-    ("polyak", source, target, tau) for a soft target update (<= 4 segments, mutually independent)."""
+    """Several flat-arena updates in one launch; `segments` = iterable of adam()'s positional argument tuples (optionally
+    followed by a shadow = (tile-major copy tensor, begin, n, k): see policy_swizzle), or ("polyak", source, target, tau) for
+    a soft target update (<= 4 segments, mutually independent)."""
     segs = list(segments)
     arr = (nv.AdamSeg * len(segs))()
     for i, seg in enumerate(segs):
@@ -263,15 +264,23 @@ def adam_multi(segments):
             _, source, target, tau = seg
             n = source.numel()
             _chk(source, "source", (n,), th.float32), _chk(target, "target", (n,), th.float32)
-            arr[i] = nv.AdamSeg(target.data_ptr(), None, None, None, None, None, 0.0, 0.0, 0.0, 1.0, n, source.data_ptr(), float(tau))
+            arr[i] = nv.AdamSeg(target.data_ptr(), None, None, None, None, None, 0.0, 0.0, 0.0, 1.0, n, source.data_ptr(), float(tau),
+                                None, 0, 0, 0)
             continue
-        param, grad, exp_avg, exp_avg_sq, adam_ctl, lr_dev, beta1, beta2, eps, grad_scale = seg
+        param, grad, exp_avg, exp_avg_sq, adam_ctl, lr_dev, beta1, beta2, eps, grad_scale = seg[:10]
+        shadow = seg[10] if len(seg) > 10 else None
         n = param.numel()
         for t, nm in ((param, "param"), (grad, "grad"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq")):
             _chk(t, nm, (n,), th.float32)
         _chk(adam_ctl, "adam_ctl", (nv.ADAM_CTL_WORDS,), th.int64), _chk(lr_dev, "lr", (1,), th.float64)
+        sh = (None, 0, 0, 0)
+        if shadow is not None:
+            t, begin, rows, cols = shadow
+            if _f32c(t, "shadow").numel() != swizzled_numel(rows, cols) or begin % 4 or cols % 4 or begin + rows * cols > n:
+                raise ValueError("shadow: wrong size or position")
+            sh = (t.data_ptr(), begin, rows, cols)
         arr[i] = nv.AdamSeg(param.data_ptr(), grad.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(), adam_ctl.data_ptr(),
-                            lr_dev.data_ptr(), beta1, beta2, eps, grad_scale, n, None, 0.0)
+                            lr_dev.data_ptr(), beta1, beta2, eps, grad_scale, n, None, 0.0, *sh)
     check(nv.lib().cstr_adam_multi_f32(arr, C.c_int(len(segs)), stream_ptr()), "cstr_adam_multi_f32")
 
 
@@ -386,12 +395,28 @@ def gaussian_head_bwd_input(g_action, g_logp, action, params, eps, weight, hidde
 POLICY_LDS_FLOATS = 16 * 1024  # 64 KB
 
 
+def swizzled_numel(n: int, k: int) -> int:
+    return -(-n // 16) * -(-k // 16) * 256
+
+
+def policy_swizzle(w, out=None):
+    """Tile-major copy of a weight matrix [N, K] (K % 4 == 0) for the policy kernel's matrix-core operand loads
+    (cstr_policy_swizzle_f32): a wave's load then reads 1 KB of consecutive bytes."""
+    n, k = w.shape
+    _chk(w, "w", (n, k), th.float32)
+    if out is None:
+        out = th.empty(swizzled_numel(n, k), dtype=th.float32, device=w.device)
+    _chk(out, "out", (swizzled_numel(n, k),), th.float32)
+    check(nv.lib().cstr_policy_swizzle_f32(ptr(w), C.c_int64(n), C.c_int64(k), ptr(out), stream_ptr()), "cstr_policy_swizzle_f32")
+    return out
+
+
 def policy_rows_supported(k0: int, h1: int, h2: int, n_out: int) -> bool:
     return (k0 <= 256 and h1 % 4 == 0 and h2 % 4 == 0 and 16 * (h1 + h2 + 8) <= POLICY_LDS_FLOATS
             and n_out <= 2 * nv.MAX_HEAD_ACT)
 
 
-def policy_rows_fwd(x, w1, b1, w2, b2, w3, b3, act: int, head: int, out_act: int, action, eps=None, rng_ctl=None, logp=None):
+def policy_rows_fwd(x, w1, b1, w2, b2, w3, b3, act: int, head: int, out_act: int, action, eps=None, rng_ctl=None, logp=None, w2_swz=None):
     """A two-hidden-layer policy network + action head for all rows of x in ONE launch, inference only (cstr_policy_rows_fwd_f32).
     head 0: squashed-Gaussian sample (w3 [2A, H2]; noise from `eps` [M, A] or the Philox stream `rng_ctl`; optional `logp`);
     head 1: deterministic out_act(h2 @ w3^T + b3). `action` [M, A] may be a column block of a wider row-major matrix."""
@@ -404,8 +429,10 @@ def policy_rows_fwd(x, w1, b1, w2, b2, w3, b3, act: int, head: int, out_act: int
     _chk(b2, "b2", (h2,), th.float32), _chk(w3, "w3", (n_out, h2), th.float32), _chk(b3, "b3", (n_out,), th.float32)
     _opt(eps, "eps", (m, a), th.float32), _opt(rng_ctl, "rng_ctl", (nv.RNG_CTL_WORDS,), th.int64), _opt(logp, "logp", (m,), th.float32)
     stride = _rows(action, "action", m, a)
+    if w2_swz is not None:
+        _chk(w2_swz, "w2_swz", (swizzled_numel(h2, h1),), th.float32)
     net = nv.PolicyMlp(k0, h1, h2, a, act, head, out_act, 0, w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), w3.data_ptr(),
-                       b3.data_ptr())
+                       b3.data_ptr(), None if w2_swz is None else w2_swz.data_ptr())
     check(nv.lib().cstr_policy_rows_fwd_f32(C.byref(net), ptr(x), C.c_int64(max(x.stride(0), k0)), ptr(eps), ptr(rng_ctl), ptr(action),
                                             C.c_int64(stride), ptr(logp), C.c_int64(m), stream_ptr()), "cstr_policy_rows_fwd_f32")
     return action

@@ -136,6 +136,9 @@ class OffPolicyAlgorithm(BaseAlgorithm):
                                        NormalActionNoise, OrnsteinUhlenbeckActionNoise, VectorizedActionNoise)
 
         self.replay_buffer.normalizer = self._vec_normalize_env  # sample(..., env=self._vec_normalize_env), sac.py:215
+        opt = getattr(getattr(self.policy, "actor", None), "optimizer", None)
+        if hasattr(opt, "refresh_shadow"):  # weights may have been loaded / set since the last learn(): graphs replay, Python does not
+            opt.refresh_shadow()
         base = self.action_noise
         if isinstance(base, VectorizedActionNoise) and base.n_envs == self.env.num_envs:
             base = base.base_noise
@@ -248,6 +251,9 @@ class OffPolicyAlgorithm(BaseAlgorithm):
 
     def _graph_iteration(self, log_interval: Optional[int]) -> None:
         vn = self._vec_normalize_env
+        opt = getattr(getattr(self.policy, "actor", None), "optimizer", None)
+        if getattr(opt, "shadow", None) is not None:  # torch changed the actor's weights (a callback, load_state_dict): the
+            opt.refresh_shadow(force=False)           # replayed graph reads their tile-major copy -- one version compare
         unroll = self._graph_unroll_now()
         key = (id(self._denv.coef), self.batch_size, self.gradient_steps, self._graph_phase(), None if vn is None else (id(vn), vn.cfg_key),
                unroll)

@@ -58,10 +58,13 @@ __device__ __forceinline__ void adam1(float &p, float g, float &m, float &v, con
     p = p + (a.step_size_neg * m) / denom;
 }
 
+// tile-major shadow of one weight matrix inside the arena (cstr_policy_swizzle_f32's layout), kept current by the update itself
+struct AdamShadow { float4 *out; int64_t begin4, end4; int k, kc; };
+
 __device__ __forceinline__ void adam_body(float *__restrict__ param, const float *__restrict__ grad, float *__restrict__ exp_avg,
                                           float *__restrict__ exp_avg_sq, int64_t *__restrict__ adam_ctl,
                                           const double *__restrict__ lr, const double beta1, const double beta2, const double eps,
-                                          const float gscale, const int64_t n)
+                                          const float gscale, const int64_t n, const AdamShadow sh = AdamShadow{nullptr, 0, 0, 4, 1})
 {
     __shared__ AdamScalars sa;
     if (threadIdx.x == 0) {
@@ -98,6 +101,11 @@ __device__ __forceinline__ void adam_body(float *__restrict__ param, const float
             __builtin_nontemporal_store(vv, reinterpret_cast<v4f *>(v4 + i));
         } else {
             p4[i] = p; m4[i] = m; v4[i] = v;
+        }
+        if (sh.out && i >= sh.begin4 && i < sh.end4) {  // this float4 is one lane's operand quad of the matrix
+            const int64_t e = (i - sh.begin4) * 4;
+            const int row = (int)(e / sh.k), col = (int)(e - (int64_t)row * sh.k);
+            sh.out[((int64_t)(row >> 4) * sh.kc + (col >> 4)) * 64 + (row & 15) + 16 * ((col & 15) >> 2)] = p;
         }
     }
     for (int64_t i = (nv << 2) + tid; i < n; i += stride) {
@@ -148,7 +156,11 @@ __global__ void adam_multi_kernel(const AdamSegs segs)
         polyak_body(s.polyak_source, s.param, (float)s.tau, (float)(1.0 - s.tau), s.n);
         return;
     }
-    adam_body(s.param, s.grad, s.exp_avg, s.exp_avg_sq, s.adam_ctl, s.lr, s.beta1, s.beta2, s.eps, s.grad_scale, s.n);
+    AdamShadow sh = {nullptr, 0, 0, 4, 1};
+    if (s.shadow)
+        sh = AdamShadow{reinterpret_cast<float4 *>(s.shadow), s.shadow_begin >> 2, (s.shadow_begin + s.shadow_n * s.shadow_k) >> 2,
+                        (int)s.shadow_k, (int)((s.shadow_k + 15) >> 4)};
+    adam_body(s.param, s.grad, s.exp_avg, s.exp_avg_sq, s.adam_ctl, s.lr, s.beta1, s.beta2, s.eps, s.grad_scale, s.n, sh);
 }
 
 }  // namespace
@@ -198,6 +210,9 @@ extern "C" int cstr_adam_multi_f32(const cstr_adam_seg_t *segs, int n_segs, cstr
         } else {
             if (!s.param || !s.grad || !s.exp_avg || !s.exp_avg_sq || !s.adam_ctl || !s.lr || s.n <= 0) return CSTR_E_BADARG;
             if (!aligned16(s.param) || !aligned16(s.grad) || !aligned16(s.exp_avg) || !aligned16(s.exp_avg_sq)) return CSTR_E_BADARG;
+            if (s.shadow && (!aligned16(s.shadow) || s.shadow_begin < 0 || (s.shadow_begin & 3) || s.shadow_n <= 0 || s.shadow_k <= 0 ||
+                             (s.shadow_k & 3) || s.shadow_k > 0x7fffffff || s.shadow_begin + s.shadow_n * s.shadow_k > s.n))
+                return CSTR_E_BADARG;
         }
         int block, g;
         flat_launch_shape((s.n + 3) / 4, block, g);

@@ -868,7 +868,7 @@ struct PolicyArgs {
     const float *w2, *b2; int h2;
     const float *w3, *b3; int act_dim, out_act;
     const float *eps_in; uint64_t *rng_ctl;
-    float *action; int64_t action_stride; float *logp; int64_t m;
+    float *action; int64_t action_stride; float *logp; int64_t m; const float *w2s;
 };
 
 constexpr int POLICY_ROWS = 16, POLICY_WAVES = 8;
@@ -901,7 +901,7 @@ __device__ __forceinline__ bool last_block_ticket_tree(unsigned long long *top, 
 // 16-column tiles round robin, TWO per pass: every lane issues ALL of its loads for both tiles (up to 256 k values each) at
 // once (A = input rows, shared by the two tiles: global memory for the first layer, LDS after it; B = weight rows from L2), so
 // a layer of up to 16 x POLICY_WAVES columns costs one memory round trip.
-template <int ACT, bool A_GLOBAL, bool VEC>
+template <int ACT, bool A_GLOBAL, bool VEC, bool SWZ = false>
 __device__ __forceinline__ void policy_layer(const float *__restrict__ in, const int64_t in_stride, const bool in_row_ok, const int K,
                                              const float *__restrict__ w, const float *__restrict__ bias, const int N,
                                              float *__restrict__ out, const int so)
@@ -909,6 +909,8 @@ __device__ __forceinline__ void policy_layer(const float *__restrict__ in, const
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, h = lane >> 4;
     const int tiles = (N + 15) >> 4;
     const float *ar = in + r * in_stride;
+    const float4 *wsw = reinterpret_cast<const float4 *>(w);
+    const int kc = (K + 15) >> 4;
     for (int t = wave; t < tiles; t += 2 * POLICY_WAVES) {
         const int n0 = t * 16, n1 = n0 + 16 * POLICY_WAVES;
         const bool ok0 = n0 + r < N, ok1 = n1 + r < N;
@@ -921,11 +923,17 @@ __device__ __forceinline__ void policy_layer(const float *__restrict__ in, const
 #pragma unroll
             for (int u = 0; u < UNROLL; ++u) {
                 const int k = c0 + 16 * u + 4 * h;
-                b0[u] = load_k4<VEC>(wr0, k, K, ok0);
+                // SWZ: `w` is the tile-major copy [tile][k chunk][lane] of float4 (cstr_policy_swizzle_f32): a wave's load
+                // instruction reads 1 KB of consecutive bytes instead of sixteen 64-byte row pieces (7.2 -> ~2 us per 256 KB)
+                b0[u] = SWZ ? (k < K ? wsw[((int64_t)t * kc + (c0 >> 4) + u) * 64 + lane] : make_float4(0.0f, 0.0f, 0.0f, 0.0f))
+                            : load_k4<VEC>(wr0, k, K, ok0);
                 av[u] = A_GLOBAL ? load_k4<VEC>(ar, k, K, in_row_ok) : load_k4<true>(ar, k, K, true);
             }
 #pragma unroll
-            for (int u = 0; u < UNROLL; ++u) b1[u] = load_k4<VEC>(wr1, c0 + 16 * u + 4 * h, K, ok1 && second);
+            for (int u = 0; u < UNROLL; ++u)
+                b1[u] = SWZ ? ((second && c0 + 16 * u + 4 * h < K) ? wsw[((int64_t)(t + POLICY_WAVES) * kc + (c0 >> 4) + u) * 64 + lane]
+                                                                    : make_float4(0.0f, 0.0f, 0.0f, 0.0f))
+                            : load_k4<VEC>(wr1, c0 + 16 * u + 4 * h, K, ok1 && second);
 #pragma unroll
             for (int u = 0; u < UNROLL; ++u) {
                 if (c0 + 16 * u >= K) break;  // wave-uniform: no matrix-core passes on all-zero chunks (K = 4: one chunk)
@@ -964,6 +972,21 @@ __device__ __forceinline__ void policy_layer(const float *__restrict__ in, const
     }
 }
 
+// w [n][k] -> tile-major float4 entries (see cstr_policy_swizzle_f32 in the header); one thread per entry
+__global__ void policy_swizzle_kernel(const float *__restrict__ w, const int n, const int k, float4 *__restrict__ out, const int64_t entries)
+{
+    const int kc = (k + 15) >> 4;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < entries; i += (int64_t)gridDim.x * blockDim.x) {
+        const int lane = (int)(i & 63);
+        const int64_t tc = i >> 6;
+        const int tile = (int)(tc / kc), chunk = (int)(tc - (int64_t)tile * kc);
+        const int row = 16 * tile + (lane & 15), col = 16 * chunk + 4 * (lane >> 4);
+        float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (row < n && col < k) v = *reinterpret_cast<const float4 *>(w + (int64_t)row * k + col);  // k % 4 == 0
+        out[i] = v;
+    }
+}
+
 template <int ACT, int HEAD, bool VEC0>
 __global__ __launch_bounds__(64 * POLICY_WAVES) void policy_rows_fwd_kernel(const PolicyArgs a)
 {
@@ -976,7 +999,8 @@ __global__ __launch_bounds__(64 * POLICY_WAVES) void policy_rows_fwd_kernel(cons
     const int n_out = HEAD == 0 ? 2 * a.act_dim : a.act_dim;
     policy_layer<ACT, true, VEC0>(a.x + m0 * a.ldx, a.ldx, m0 + (lane & 15) < a.m, a.k0, a.w1, a.b1, H1, h1s, S1);
     __syncthreads();
-    policy_layer<ACT, false, true>(h1s, S1, true, H1, a.w2, a.b2, H2, h2s, S2);
+    if (a.w2s) policy_layer<ACT, false, true, true>(h1s, S1, true, H1, a.w2s, a.b2, H2, h2s, S2);
+    else policy_layer<ACT, false, true>(h1s, S1, true, H1, a.w2, a.b2, H2, h2s, S2);
     __syncthreads();
 
     // head: POLICY_ROWS / POLICY_WAVES = 2 rows per wave, evaluated together (one pass over the head's weights)
@@ -1394,6 +1418,17 @@ extern "C" int cstr_gaussian_head_bwd_input_f32(const float *g_action, int64_t g
     return (int)hipGetLastError();
 }
 
+extern "C" int cstr_policy_swizzle_f32(const float *w, int64_t n, int64_t k, float *out, cstr_stream_t stream)
+{
+    if (!w || !out || n <= 0 || k <= 0) return CSTR_E_BADARG;
+    if ((k & 3) || !aligned16(w) || !aligned16(out) || n > 0x7ffffff || k > 0x7ffffff) return CSTR_E_UNSUPPORTED;
+    const int64_t entries = ((n + 15) / 16) * ((k + 15) / 16) * 64;
+    int block, grid;
+    flat_launch_shape(entries, block, grid);
+    policy_swizzle_kernel<<<grid, block, 0, (hipStream_t)stream>>>(w, (int)n, (int)k, reinterpret_cast<float4 *>(out), entries);
+    return (int)hipGetLastError();
+}
+
 extern "C" int cstr_policy_rows_fwd_f32(const cstr_policy_mlp_t *net, const float *x, int64_t ldx, const float *eps, uint64_t *rng_ctl,
                                        float *action, int64_t action_stride, float *logp, int64_t m, cstr_stream_t stream)
 {
@@ -1409,7 +1444,8 @@ extern "C" int cstr_policy_rows_fwd_f32(const cstr_policy_mlp_t *net, const floa
         (n.head == 0 && n.act_dim > CSTR_MAX_HEAD_ACT) || (m + POLICY_ROWS - 1) / POLICY_ROWS > 0x7fffffff)
         return CSTR_E_UNSUPPORTED;
     PolicyArgs a = {x, ldx, n.k0, n.w1, n.b1, n.h1, n.w2, n.b2, n.h2, n.w3, n.b3, n.act_dim, n.out_act, eps, rng_ctl,
-                    action, action_stride, logp, m};
+                    action, action_stride, logp, m, n.w2_swizzled};
+    if (n.w2_swizzled && !aligned16(n.w2_swizzled)) return CSTR_E_BADARG;
     const unsigned grid = (unsigned)((m + POLICY_ROWS - 1) / POLICY_ROWS);
     const bool vec0 = (n.k0 & 3) == 0 && (ldx & 3) == 0 && aligned16(x) && aligned16(n.w1);
     hipStream_t s = (hipStream_t)stream;

@@ -610,6 +610,51 @@ def test_whole_policy_network_in_one_launch(ops, M, K0, H1, H2, A, act):
         hip_ops.policy_rows_fwd(x, w1, b1, w2, b2, w3, b3, act, 0, 0, a1)  # no noise source
 
 
+@pytest.mark.parametrize("N,K", [(256, 256), (300, 400), (20, 8), (16, 64)])
+def test_tile_major_weight_copy_and_its_adam_shadow(ops, N, K):
+    """cstr_policy_swizzle_f32 against the torch permutation; the policy kernel with the copy is bit-identical to the one
+    without; cstr_adam_multi_f32 keeps the copy equal to swizzle(updated weights) step after step."""
+    from core.common import hip_ops
+    from core.common.arena import FlatAdam, ParamArena
+
+    g = th.Generator(device="cuda").manual_seed(N + K)
+    w = th.randn(N, K, device="cuda", generator=g)
+    t, kc = -(-N // 16), -(-K // 16)
+    wp = th.zeros(t * 16, kc * 16, device="cuda")
+    wp[:N, :K] = w
+    ref = wp.reshape(t, 16, kc, 4, 4).permute(0, 2, 3, 1, 4).contiguous().reshape(-1)  # [tile][k chunk][h][r][4]
+    assert th.equal(hip_ops.policy_swizzle(w), ref)
+    if K % 4 == 0 and K >= 8:
+        M, K0, A = 100, 4, 2
+        r = lambda *sh: th.randn(*sh, device="cuda", generator=g)  # noqa: E731
+        x, w1, b1, b2, w3, b3, eps = r(M, K0), r(K, K0), r(K), r(N), r(2 * A, N) / N ** 0.5, r(2 * A), r(M, A)
+        a1, a2 = th.empty(M, A, device="cuda"), th.empty(M, A, device="cuda")
+        hip_ops.policy_rows_fwd(x, w1, b1, w / K ** 0.5, b2, w3, b3, 1, 0, 0, a1, eps=eps)
+        hip_ops.policy_rows_fwd(x, w1, b1, w / K ** 0.5, b2, w3, b3, 1, 0, 0, a2, eps=eps, w2_swz=hip_ops.policy_swizzle(w / K ** 0.5))
+        assert th.equal(a1, a2)
+    # an arena with other parameters around the matrix; three steps with and without the shadow
+    def make():
+        th.manual_seed(3)
+        ps = [th.nn.Parameter(th.randn(7)), th.nn.Parameter(th.randn(N, K)), th.nn.Parameter(th.randn(5, 3))]
+        arena = ParamArena(ps, "cuda")
+        return ps, arena, FlatAdam(arena, lr=1e-2)
+
+    (ps_a, ar_a, opt_a), (ps_b, ar_b, opt_b) = make(), make()
+    shadow = opt_b.add_weight_shadow(ps_b[1])
+    assert th.equal(shadow, hip_ops.policy_swizzle(ps_b[1].detach()))
+    for step in range(3):
+        grad = th.randn(ar_a.numel, device="cuda", generator=g)
+        ar_a.grad.copy_(grad), ar_b.grad.copy_(grad)
+        opt_a.step()
+        opt_b.step() if step != 1 else opt_b.step_with()
+        assert th.equal(ar_a.flat, ar_b.flat)  # same arithmetic through either kernel
+        assert th.equal(shadow, hip_ops.policy_swizzle(ps_b[1].detach()))
+    with th.no_grad():
+        ps_b[1].mul_(2.0)  # torch changes the weights: the version counter moves
+    opt_b.refresh_shadow(force=False)
+    assert th.equal(shadow, hip_ops.policy_swizzle(ps_b[1].detach()))
+
+
 def test_grouped_actor_forward_and_single_agent_backward(ops):
     """FastActorGroup (cstr_linear_act_fwd_sets_f32): four agents' actor MLPs, one launch per layer, actions written into the
     column blocks of a joint buffer; one agent differentiated -- against the per-agent nn.Modules and autograd."""

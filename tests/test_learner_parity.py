@@ -540,6 +540,44 @@ def test_single_gym_env_facade_matches_golden(golden):
     assert isinstance(venv, CSTRVecEnv) and venv.num_envs == 5 and venv.target_C2 == 0.25
 
 
+def test_policy_kernel_weight_copy_follows_the_actor_under_graph_replay():
+    """Rollouts with more than 1024 envs read a tile-major copy of the actor's second layer (FlatAdam.add_weight_shadow): it
+    must equal swizzle(weights) after graph-replayed training steps, after torch changes the weights in the middle of a
+    learn() call (a callback) and after set_parameters between learn() calls."""
+    from core.common import hip_ops
+    from core.common.callbacks import BaseCallback
+    from core.common.vec_env import CSTRVecEnv
+    from core.sac import SAC
+
+    n = 2048
+    model = SAC("MlpPolicy", CSTRVecEnv(n), seed=0, learning_starts=n * 2, policy_kwargs=dict(net_arch=[64, 64]))
+    model.enable_graph_capture()
+    model.learn(n * 12)
+    opt, w2 = model.actor.optimizer, model.actor.latent_pi[2].weight
+    assert opt.shadow is not None and opt.shadow[4] is w2 and model._graph  # the copy exists and graphs replay
+    in_sync = lambda: th.equal(opt.shadow[0], hip_ops.policy_swizzle(w2.detach()))  # noqa: E731
+    assert in_sync()
+
+    class Meddle(BaseCallback):
+        def _on_step(self) -> bool:
+            if self.n_calls == 3:
+                with th.no_grad():
+                    w2.mul_(0.5)
+            return True
+
+    before = w2.detach().clone()
+    model.learn(n * 8, callback=Meddle(), reset_num_timesteps=False)
+    assert in_sync() and not th.equal(before, w2)
+    import copy
+
+    params = copy.deepcopy(model.get_parameters())
+    with th.no_grad():
+        w2.add_(1.0)
+    model.set_parameters(params)
+    model.learn(n * 4, reset_num_timesteps=False)
+    assert in_sync()
+
+
 @pytest.mark.parametrize("algo", ["sac", "td3"])
 def test_learning_improves_episode_return(algo):
     """End-to-end sanity of the whole stack (env kernel, ring, sampler, fused learner, graph replay): a few seconds of
