@@ -157,7 +157,10 @@ def linear(x: th.Tensor, weight: th.Tensor, bias: th.Tensor, act: int, train_par
 class FastMLP:
     """Reads an nn.Sequential built by create_mlp (Linear [+ ReLU | Tanh] ...) and evaluates it with `linear`."""
 
-    def __init__(self, seq: nn.Sequential):
+    def __init__(self, seq: nn.Sequential, optimizer=None):
+        """`optimizer`: the FlatAdam that updates these parameters, if the many-row inference pass may keep a tile-major
+        copy of the second layer with it (see _weight_shadow)."""
+        self.optimizer = optimizer
         self.layers: List[Tuple[nn.Linear, int]] = []
         mods = list(seq)
         i = 0
@@ -205,7 +208,8 @@ class FastMLP:
         if self._whole_net_ok(x, train_params):  # a deterministic actor's rollout pass: ONE launch, nothing kept
             (l1, act), (l2, _), (l3, out_act) = layers
             out = th.empty(x.shape[0], l3.out_features, dtype=x.dtype, device=x.device)
-            return hip_ops.policy_rows_fwd(x, l1.weight, l1.bias, l2.weight, l2.bias, l3.weight, l3.bias, act, 1, out_act, out)
+            return hip_ops.policy_rows_fwd(x, l1.weight, l1.bias, l2.weight, l2.bias, l3.weight, l3.bias, act, 1, out_act, out,
+                                           w2_swz=_weight_shadow(self.optimizer, l2.weight))
         scalar_head = len(layers) >= 2 and layers[-1][0].out_features == 1 and layers[-1][1] == ACT_NONE
         plain = layers[:-2] if scalar_head else layers
         below = None

@@ -50,7 +50,7 @@ class TD3(OffPolicyAlgorithm):
         self.fused_learner = (isinstance(self.actor.optimizer, FlatAdam) and isinstance(self.critic.optimizer, FlatAdam)
                               and fused.FastMLP.supported(self.actor.mu) and all(fused.FastMLP.supported(q) for q in self.critic.q_networks))
         if self.fused_learner:
-            self._fast_actor, self._fast_actor_target = fused.FastMLP(self.actor.mu), fused.FastMLP(self.actor_target.mu)
+            self._fast_actor, self._fast_actor_target = fused.FastMLP(self.actor.mu, self.actor.optimizer), fused.FastMLP(self.actor_target.mu)
             self._fast_critic, self._fast_critic_target = fused.FastTwinCritic(self.critic, self.policy.critic_stack), fused.FastTwinCritic(self.critic_target, self.policy.critic_target_stack)
 
     def _policy_out_device(self, obs: th.Tensor) -> th.Tensor:
