@@ -289,6 +289,19 @@ class OffPolicyAlgorithm(BaseAlgorithm):
             self._graph_host_bookkeeping(log_interval)
 
     def _capture_segments(self, unroll: int = 1) -> list:
+        """`_record_segments`, and if recording WITH the collectives inside the graph raises (every rank runs the same code,
+        so every rank gets here), once more with the collectives between graph segments."""
+        try:
+            return self._record_segments(unroll)
+        except Exception as exc:  # noqa: BLE001
+            if not (self.world_size > 1 and getattr(self, "_graph_collectives", False) and GRAPH_COLLECTIVES == "auto"):
+                raise
+            print(f"[graph] recording the collectives into the graph failed ({exc!r}); keeping them between graph segments", file=sys.stderr)
+            self._graph_collectives = False
+            th.cuda.synchronize(self.device)
+            return self._record_segments(unroll)
+
+    def _record_segments(self, unroll: int = 1) -> list:
         """Record the iteration as hipGraph segments. A data-parallel run has an RCCL all-reduce between backward and
         the optimiser step (two per SAC gradient step). When the start-up trial passes (`_collectives_in_graph`) they are
         recorded into the graph; otherwise collectives stay OUTSIDE the captured graphs -- every `_eager_boundary` closes the
