@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define CSTR_ABI_VERSION 2
+#define CSTR_ABI_VERSION 3
 
 #define CSTR_OK 0
 #define CSTR_E_BADARG (-1)      /* null pointer / non-positive size / misaligned buffer */

@@ -101,7 +101,7 @@ def lib() -> C.CDLL:
             raise NativeError(f"{LIB_PATH} does not export {missing}")
         l.cstr_error_string.restype = C.c_char_p
         l.cstr_default_coef.restype = None
-        if l.cstr_abi_version() != 2:
+        if l.cstr_abi_version() != 3:
             raise NativeError("libcstr_rl_hip.so ABI version mismatch")
         _lib = l
     return _lib
