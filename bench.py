@@ -412,8 +412,15 @@ def main():
             line["roofline_stream"] = roofline_collect(1 << 22, args.obs_dim, args.integrator, 30)
             line["kernels"] = other_kernels(model, B)
             pk = line["kernels"]["policy_rows_fwd_kernel"]  # the LONGEST launch of the iteration, matrix-core bound
+            traffic = None  # HBM bytes per launch from the committed PMC passes (tools/pmc_policy.sh), bench shape only
+            if pk["shape"] == [4096, 4, 256, 256, 4]:
+                try:
+                    with open(os.path.join(ROOT, "profiles", "r01_policy_pmc.json")) as fh:
+                        traffic = json.load(fh)["policy_rows_fwd_kernel"]["4096"]["traffic_bytes"]
+                except (OSError, KeyError, ValueError):
+                    pass
             line["roofline_mfma"] = dict(bound="mfma", kernel="policy_rows_fwd_kernel", achieved=pk["tflops"], peak=F32_MFMA_PEAK_TFLOPS,
-                                         unit="TFLOP/s", frac=pk["frac"], traffic=None, launch_us=pk["launch_us"], shape=pk["shape"])
+                                         unit="TFLOP/s", frac=pk["frac"], traffic=traffic, launch_us=pk["launch_us"], shape=pk["shape"])
         if world == 1 and not args.no_variant and args.algo == "sac" and (args.obs_dim, args.integrator) == (4, "euler"):
             del model, env
             dev = f"cuda:{local_rank}"
