@@ -1,13 +1,22 @@
 #!/usr/bin/env python3
 """bench.py -- env-steps/sec of SAC on 4096 vectorised two-series CSTR envs per GPU (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]            (N > 1: launched by torch.distributed.run)
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+N > 1 runs N ranks, one per GPU, over RCCL. Either the caller starts them (torch.distributed.run: WORLD_SIZE / RANK /
+LOCAL_RANK / MASTER_* in the environment), or -- plain `python bench.py --gpus N` -- this file does: the parent, BEFORE
+any GPU call, starts N fresh child processes of itself with that environment, relays rank 0's single JSON line and exits
+non-zero unless the job really ran N ranks (`n_gpus`, `rccl_world`, `allreduce_checksum` on the line prove it).
 
 A "step" is ONE iteration of `core.SAC("MlpPolicy", env).learn()` at the class defaults
-(reference: core/common/off_policy_algorithm.py:331-351): one vec-step of 4096 envs (actor forward + fused
-collect kernel) followed by one gradient step (HIP sampler, MLP fwd/bwd on PyTorch-ROCm, HIP td-target,
-three flat Adam launches, HIP polyak). Inputs are resident in HBM before the timed region. The timed region
-is bracketed by a barrier + torch.cuda.synchronize() on both sides; the MAX over ranks is reported.
+(reference: core/common/off_policy_algorithm.py:331-351): one vec-step of 4096 envs (the whole actor network + sampling
+in one f32-MFMA launch, then the fused collect kernel) followed by one gradient step (HIP MT19937 sampler, MLP
+forward/backward on hand-written f32-MFMA Linear kernels [the rocBLAS/PyTorch-ROCm variant is reported beside it],
+HIP td-target + losses, flat Adam launches, HIP polyak), replayed from a captured hipGraph. Inputs are resident in HBM
+before the timed region. The timed region is bracketed by a barrier + torch.cuda.synchronize() on both sides; the MAX
+over ranks is reported. A K-step region shorter than MIN_TIMED_S is repeated (whole multiples of K, every repeat
+bracketed the same way) until the total reaches it: `steps` stays the CLI value, `timed_steps_total` is the real count.
+The run FAILS (non-zero exit) if hipGraph replay was requested but the timed iterations ran eagerly.
 
 Extra objects on the JSON line:
   roofline      dominant hand-written kernel (the fused collect step: 104 algorithmic B per env-step)
@@ -37,6 +46,10 @@ import torch as th  # noqa: E402
 
 F32_MFMA_PEAK_TFLOPS = 157.3  # dense f32-input MFMA, MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s measured achievable)
+MIN_TIMED_S = 0.25  # a timed region shorter than this is repeated (20 steps = 2.9 ms must not stand alone)
+# the reference's own Python on CPU, measured in the survey container (8 cores, no GPU; SURVEY 6 / BASELINE.md 2): unmodified
+# reference SAC("MlpPolicy").learn() on DummyVecEnv(4096 x TwoSeriesCSTREnv), class defaults. It cannot travel to the GPU box.
+REFERENCE_PYTHON_ENV_STEPS_PER_S = 4.2e3
 
 
 def parse():
@@ -311,8 +324,48 @@ def north_star_variant(n_envs: int, device: str, graph: bool, obs_dim: int = 8, 
                 value=round(steps * n_envs / dt, 1), unit="env-steps/s", ms_per_step=round(1e3 * dt / steps, 4))
 
 
+def launch_ranks(args) -> int:
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes of this file (RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_* set), relay rank 0's JSON line, return non-zero unless every rank exited 0 and the line says n_gpus == N.
+    Nothing here touches the GPU (`torch.cuda.device_count()` only counts devices) and nothing re-execs this process."""
+    import socket
+    import subprocess
+
+    n = args.gpus
+    single = os.environ.get("CSTR_BENCH_SINGLE_DEVICE") == "1"  # rehearsal: N ranks on cuda:0 (gloo transport)
+    have = th.cuda.device_count()
+    if not single and have < n:
+        print(f"bench.py: --gpus {n} but this node exposes {have} GPU(s); refusing to report a {n}-GPU number", file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0",
+               OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "4"), CSTR_BENCH_SPAWNED="1")
+    procs = []
+    for r in range(n):
+        renv = dict(env, RANK=str(r), LOCAL_RANK=str(r), LOCAL_WORLD_SIZE=str(n))
+        out = subprocess.PIPE if r == 0 else sys.stderr  # stdout carries ONE line: rank 0's
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=renv, stdout=out))
+    out0, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    lines = [ln for ln in out0.decode().splitlines() if ln.strip().startswith("{")]
+    if any(codes) or len(lines) != 1:
+        print(f"bench.py: rank exit codes {codes}, {len(lines)} JSON line(s) from rank 0", file=sys.stderr)
+        return 1
+    rec = json.loads(lines[0])
+    if rec.get("n_gpus") != n or rec.get("rccl_world") != n:
+        print(f"bench.py: asked for {n} ranks, the job ran n_gpus={rec.get('n_gpus')} rccl_world={rec.get('rccl_world')}", file=sys.stderr)
+        return 1
+    sys.stdout.write(lines[0] + "\n")
+    sys.stdout.flush()
+    return 0
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args))
     # stdout carries exactly ONE line, the JSON result: libraries that print to fd 1 (RCCL's version banner on rank 0) go to stderr
     sys.stdout.flush()
     result_fd = os.dup(1)
@@ -324,8 +377,8 @@ def main():
     rank, local_rank, world = dist_util.init_from_env(os.environ.get("CSTR_DIST_BACKEND"))
     if os.environ.get("CSTR_BENCH_SINGLE_DEVICE") == "1":
         local_rank = 0
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: refusing to label a {world}-rank run as {args.gpus} GPUs")
     assert th.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
     th.cuda.set_device(local_rank)
     from core import _native as nv
@@ -363,6 +416,15 @@ def main():
     _, callback = model._setup_learn(total, NoopCallback(), True, "bench", False)
     use_graph = bool(args.graph)  # world > 1: graph segments with the RCCL all-reduces between them
     model.enable_graph_capture(use_graph, unroll=args.graph_unroll if world == 1 else 1)
+    if os.environ.get("CSTR_BENCH_BREAK_CAPTURE") == "1":  # test knob (tests/test_bench_contract.py): the recorded body raises
+        body = model._graph_body
+
+        def broken_body():
+            body()
+            if th.cuda.is_current_stream_capturing():
+                raise RuntimeError("injected capture failure (CSTR_BENCH_BREAK_CAPTURE)")
+
+        model._graph_body = broken_body
     if args.tunable:  # development: record / eager-tune every GEMM shape (input of tools/tune_gemms.py)
         th.cuda.tunable.enable(True)
         th.cuda.tunable.tuning_enable(True)
@@ -381,26 +443,81 @@ def main():
             th.distributed.barrier()
         th.cuda.synchronize()
 
+    def agreed_max(x: float) -> float:  # MAX over ranks (every rank takes the same decisions from it)
+        if world == 1:
+            return x
+        t = th.tensor([x], dtype=th.float64, device=model.device)
+        th.distributed.all_reduce(t, op=th.distributed.ReduceOp.MAX)
+        return float(t)
+
     run_steps(args.warmup)
+    # --warmup is honoured as given; if hipGraph replay was requested and the graphs of every phase are not recorded yet
+    # (3 side-stream iterations + the capture per phase; TD3 / MADDPG have two phases) keep warming up, untimed and reported
+    prewarm = 0
+    if use_graph:
+        want = 2 if args.algo in ("td3", "maddpg") else 1
+        while model._graph_enabled and len(model._graph or {}) < want and prewarm < 64:
+            run_steps(1)
+            prewarm += 1
+        for _ in range(2):
+            run_steps(want)
+            prewarm += want
+    st0 = model.graph_status()
     barrier()
     t0 = time.perf_counter()
     run_steps(args.steps)
     barrier()
-    dt = time.perf_counter() - t0
+    dt = agreed_max(time.perf_counter() - t0)
+    # a K-step region shorter than MIN_TIMED_S is repeated in whole multiples of K until the total reaches it (every rank sees
+    # the same MAX-reduced durations, so every rank takes the same decision)
+    repeats = 1
+    while dt < MIN_TIMED_S and repeats < 100000:
+        barrier()
+        t0 = time.perf_counter()
+        run_steps(args.steps)
+        barrier()
+        dt += agreed_max(time.perf_counter() - t0)
+        repeats += 1
+    timed_steps = args.steps * repeats
+    st1 = model.graph_status()
+    graph_replays = st1["replays"] - st0["replays"]
+    eager_in_timed = st1["eager_iterations"] - st0["eager_iterations"]
+    dt_steps = dt / repeats  # seconds per K steps
+    # proof of the rank count: a summing all-reduce on the job's backend, and the weights of every rank after training
+    checksum = dict(expected=world * (world + 1) // 2, got=rank + 1, backend="none")
+    weights_identical = None
     if world > 1:
-        t = th.tensor([dt], dtype=th.float64, device="cuda")
-        th.distributed.all_reduce(t, op=th.distributed.ReduceOp.MAX)
-        dt = float(t)
+        t = th.tensor([float(rank + 1)], dtype=th.float64, device=model.device)
+        th.distributed.all_reduce(t)
+        checksum.update(got=int(t), backend=th.distributed.get_backend())
+        flats = [p.detach().reshape(-1) for p in model.policy.parameters()]
+        if getattr(model, "log_ent_coef", None) is not None:
+            flats.append(model.log_ent_coef.detach().reshape(-1))
+        h = th.stack([f.double().sum() for f in flats] + [f.double().abs().sum() for f in flats])
+        hmax, hmin = h.clone(), h.clone()
+        th.distributed.all_reduce(hmax, op=th.distributed.ReduceOp.MAX)
+        th.distributed.all_reduce(hmin, op=th.distributed.ReduceOp.MIN)
+        weights_identical = bool(th.equal(hmax, hmin))
+    dt = dt_steps
     value = args.steps * N * world / dt
+    rccl_world = th.distributed.get_world_size() if th.distributed.is_initialized() else 1
     line = {
         "metric": "env-steps/sec (SAC, two-series CSTR, 4096 vec-envs) at 1/2/4/8 GPUs" if args.algo == "sac" else
                   f"env-steps/sec ({args.algo.upper()}, two-series CSTR, {N} vec-envs)",
         "value": round(value, 1), "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": "f32", "data": "synthetic", "rccl_world": rccl_world, "allreduce_checksum": checksum,
+        "weights_identical_across_ranks": weights_identical, "graph_collectives": st1["graph_collectives"],
+        "timed_steps_total": timed_steps, "timed_repeats": repeats, "timed_seconds_total": round(dt * repeats, 4),
+        "graph_prewarm_steps": prewarm, "hip_graph_active": st1["active"], "hip_graph_replays_in_timed_region": graph_replays,
+        "eager_iterations_in_timed_region": eager_in_timed, "hip_graph_error": st1["error"],
+        "reference_python_env_steps_per_s": {"value": REFERENCE_PYTHON_ENV_STEPS_PER_S, "provenance": "unmodified reference SAC.learn() on "
+                                             "DummyVecEnv(4096), survey container, 8 CPU cores, no GPU (SURVEY 6 / BASELINE.md 2); "
+                                             "not re-measurable on the GPU box (the reference cannot travel)",
+                                             "speedup": round(value / REFERENCE_PYTHON_ENV_STEPS_PER_S, 1)},
         "config": {"workload": f"{args.algo.upper()} MlpPolicy class defaults on {N} vectorised two-series CSTR envs per GPU "
                                f"(obs {args.obs_dim}/act 2, {args.integrator}, batch 256, ring 244x{N}, 1 gradient step per vec-step)",
-                   "n_envs_per_gpu": N, "global_batch": B * world, "parallelism": f"dp{world}", "hip_graph": use_graph, "graph_unroll": model.graph_unroll if use_graph else 0, "blas": args.blas,
+                   "n_envs_per_gpu": N, "global_batch": B * world, "parallelism": f"dp{world}", "hip_graph": bool(st1["active"]), "hip_graph_requested": use_graph, "hip_graph_segments": st1["segments_per_graph"], "graph_unroll": model.graph_unroll if use_graph else 0, "blas": args.blas,
                    "n_updates": model._n_updates},
     }
     if rank == 0:
@@ -434,6 +551,19 @@ def main():
         th.distributed.barrier()
     if th.distributed.is_initialized():
         th.distributed.destroy_process_group()
+    problems = []
+    if use_graph and (not st1["active"] or eager_in_timed or graph_replays != timed_steps):
+        problems.append(f"hipGraph replay requested but the timed region ran {eager_in_timed} eager / {graph_replays} replayed of {timed_steps} "
+                        f"iterations (capture error: {st1['error']})")
+    if checksum["got"] != checksum["expected"]:
+        problems.append(f"all-reduce checksum {checksum}")
+    if weights_identical is False:
+        problems.append("weights differ between ranks after training")
+    if world > 1 and os.environ.get("CSTR_DIST_BACKEND") is None and checksum["backend"] != "nccl":
+        problems.append(f"multi-GPU run on backend {checksum['backend']!r}, not RCCL")
+    if problems:
+        print("bench.py: INVALID RUN -- " + "; ".join(problems), file=sys.stderr)
+        raise SystemExit(3)
 
 
 if __name__ == "__main__":

@@ -65,10 +65,21 @@ def allreduce_sum_(flat: th.Tensor) -> th.Tensor:
 _GRAPH_COLLECTIVES_OK = None
 
 
+def _agree(ok: bool, device) -> bool:
+    """MIN over ranks of a local verdict. `th.full` is a fill kernel (no host-to-device copy), safe right after a capture."""
+    verdict = th.full((1,), 1.0 if ok else 0.0, dtype=th.float32, device=device)
+    dist.all_reduce(verdict, op=dist.ReduceOp.MIN)
+    return bool(verdict.item() == 1.0)
+
+
 def graph_collectives_ok(device) -> bool:
     """Start-up trial for recording collectives into hipGraphs: capture ONE all-reduce, replay it twice and check the sums on
-    every rank; all ranks agree on the verdict (MIN all-reduce). Only the RCCL backend on a GPU qualifies. Must be called by
-    every rank, outside any capture."""
+    every rank. Only the RCCL backend on a GPU qualifies. Must be called by every rank, outside any capture.
+
+    Every rank issues the SAME sequence of collectives whatever happens locally: [warm all-reduce] [captured all-reduce, not
+    executed] [MIN verdict "captured"] and, only if every rank captured, [replay, replay] [MIN verdict "sums right"]. A rank
+    whose capture raises leaves capture mode (capture_end) before anything else touches the stream or the graph object is
+    destroyed -- a graph destroyed mid-capture aborts the process (round 1, rc 134 in CUDAGraph::~CUDAGraph)."""
     global _GRAPH_COLLECTIVES_OK
     if _GRAPH_COLLECTIVES_OK is not None:
         return _GRAPH_COLLECTIVES_OK
@@ -76,31 +87,52 @@ def graph_collectives_ok(device) -> bool:
     if not is_distributed() or dist.get_backend() != "nccl" or device.type != "cuda":
         _GRAPH_COLLECTIVES_OK = False
         return False
+    import gc
+
     rank, world = dist.get_rank(), dist.get_world_size()
-    ok = True
-    try:
-        with th.cuda.device(device):
-            t = th.zeros(4096, dtype=th.float32, device=device)
-            dist.all_reduce(t)  # the communicator and its buffers exist before anything is recorded
-            th.cuda.synchronize(device)
-            side, g = th.cuda.Stream(device=device), th.cuda.CUDAGraph()
-            side.wait_stream(th.cuda.current_stream(device))
+    with th.cuda.device(device):
+        t = th.zeros(4096, dtype=th.float32, device=device)
+        dist.all_reduce(t)  # the communicator and its buffers exist before anything is recorded
+        th.cuda.synchronize(device)
+        side, g = th.cuda.Stream(device=device), th.cuda.CUDAGraph()
+        side.wait_stream(th.cuda.current_stream(device))
+        captured = False
+        gc.collect()  # like torch.cuda.graph(): a collection that frees device memory mid-capture invalidates the capture
+        gc_was_enabled = gc.isenabled()
+        gc.disable()
+        try:
             with th.cuda.stream(side):
                 g.capture_begin(capture_error_mode="thread_local")
-                dist.all_reduce(t)
-                g.capture_end()
-            th.cuda.current_stream(device).wait_stream(side)
+                try:
+                    dist.all_reduce(t)
+                    g.capture_end()
+                    captured = True
+                except Exception as exc:  # noqa: BLE001 -- any failure means "keep the collectives between graph segments"
+                    try:
+                        g.capture_end()  # leave capture mode FIRST
+                    except Exception:  # noqa: BLE001
+                        pass
+                    print(f"[distributed] collectives stay outside hipGraphs (capture failed): {exc!r}", file=sys.stderr)
+        finally:
+            if gc_was_enabled:
+                gc.enable()
+        th.cuda.current_stream(device).wait_stream(side)
+        th.cuda.synchronize(device)
+        if not _agree(captured, device):
+            del g
+            _GRAPH_COLLECTIVES_OK = False
+            return False
+        ok = True
+        try:
             for k in (1.0, 3.0):
                 t.fill_(k * (rank + 1))
                 g.replay()
                 th.cuda.synchronize(device)
                 ok = ok and bool((t == k * world * (world + 1) / 2).all())
-    except Exception as exc:  # noqa: BLE001 -- any failure means "keep the collectives between graph segments"
-        print(f"[distributed] collectives stay outside hipGraphs: {exc!r}", file=sys.stderr)
-        ok = False
-    verdict = th.tensor([1.0 if ok else 0.0], device=device)
-    dist.all_reduce(verdict, op=dist.ReduceOp.MIN)
-    _GRAPH_COLLECTIVES_OK = bool(verdict.item() == 1.0)
+        except Exception as exc:  # noqa: BLE001
+            print(f"[distributed] collectives stay outside hipGraphs (replay failed): {exc!r}", file=sys.stderr)
+            ok = False
+        _GRAPH_COLLECTIVES_OK = _agree(ok, device)
     return _GRAPH_COLLECTIVES_OK
 
 

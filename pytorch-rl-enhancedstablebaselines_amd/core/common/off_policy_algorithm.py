@@ -58,6 +58,9 @@ class OffPolicyAlgorithm(BaseAlgorithm):
         self.train_freq = train_freq
         self.use_sde_at_warmup = use_sde_at_warmup
         self._graph_enabled, self._graph, self._graph_key = False, None, None
+        self._graph_error: Optional[str] = None  # text of the exception that ended hipGraph replay (None = never failed)
+        self._graph_replays = 0                  # iterations served by a captured graph / by eager launches (bench.py reports both)
+        self._eager_iterations = 0
         self.stats_sync_interval = 100   # vec-steps between host reads of the device episode counters
         self._steps_since_sync = 0
         self._episodes_at_last_dump = 0
@@ -176,8 +179,9 @@ class OffPolicyAlgorithm(BaseAlgorithm):
         When the iteration is eligible it is replayed from a captured hipGraph instead (same launches, same
         order, one host call)."""
         if self._graph_enabled and self._graph_eligible(callback):
-            self._graph_iteration(log_interval)
+            self._graph_iteration(log_interval, callback)
             return True
+        self._eager_iterations += 1
         rollout = self.collect_rollouts(self.env, train_freq=self.train_freq, action_noise=self.action_noise,
                                         callback=callback, learning_starts=self.learning_starts,
                                         replay_buffer=self.replay_buffer, log_interval=log_interval)
@@ -201,7 +205,7 @@ class OffPolicyAlgorithm(BaseAlgorithm):
         idles between two graph launches is paid once per `unroll` iterations. Used on one GPU with a constant learning
         rate while at least `unroll` iterations remain; otherwise single-iteration graphs are replayed."""
         self._graph_enabled = enabled
-        self._graph = None
+        self._graph, self._graph_error = None, None
         self.graph_unroll = max(1, int(unroll if unroll is not None else os.environ.get("CSTR_GRAPH_UNROLL", "1")))
 
     def _graph_eligible(self, callback: BaseCallback) -> bool:
@@ -249,7 +253,7 @@ class OffPolicyAlgorithm(BaseAlgorithm):
         remaining = (self._total_timesteps - self.num_timesteps) // self.n_envs
         return u if remaining >= u else 1
 
-    def _graph_iteration(self, log_interval: Optional[int]) -> None:
+    def _graph_iteration(self, log_interval: Optional[int], callback: Optional[BaseCallback] = None) -> None:
         vn = self._vec_normalize_env
         opt = getattr(getattr(self.policy, "actor", None), "optimizer", None)
         if getattr(opt, "shadow", None) is not None:  # torch changed the actor's weights (a callback, load_state_dict): the
@@ -270,6 +274,7 @@ class OffPolicyAlgorithm(BaseAlgorithm):
                     self._graph_body()
                 th.cuda.current_stream(self.device).wait_stream(side)
                 self._graph_warm[key] = warm + 1
+                self._eager_iterations += 1
                 self._graph_host_bookkeeping(log_interval)
                 return
             self._train_host_pre()
@@ -278,15 +283,33 @@ class OffPolicyAlgorithm(BaseAlgorithm):
             except Exception as exc:  # something in the iteration is not capturable: run eagerly from now on
                 import warnings
 
-                warnings.warn(f"hipGraph capture failed ({type(exc).__name__}: {exc}); falling back to eager launches")
+                self._graph_error = f"{type(exc).__name__}: {exc}"
+                warnings.warn(f"hipGraph capture failed ({self._graph_error}); falling back to eager launches")
                 self._graph_enabled, self._graph = False, None
-                self._learn_iteration(to_callback(None), log_interval)
+                self._learn_iteration(callback if callback is not None else self._noop_callback(), log_interval)
                 return
         self._train_host_pre()
         for item in self._graph[key]:  # hipGraph segments interleaved with the eager collectives that separate them
             item.replay() if isinstance(item, th.cuda.CUDAGraph) else item()
+        self._graph_replays += unroll
         for _ in range(unroll):
             self._graph_host_bookkeeping(log_interval)
+
+    def _noop_callback(self) -> BaseCallback:
+        cb = to_callback(None)
+        cb.init_callback(self)
+        return cb
+
+    def graph_status(self) -> dict:
+        """What actually runs (not what was requested): bench.py refuses to report a run whose graphs fell back to eager."""
+        graphs = self._graph if isinstance(self._graph, dict) else {}
+        segs = [sum(isinstance(i, th.cuda.CUDAGraph) for i in items) for items in graphs.values()]
+        mode = "none"
+        if self.world_size > 1 or getattr(self, "_force_segment_boundaries", False):
+            mode = "in-graph" if getattr(self, "_graph_collectives", False) else "segmented"
+        return dict(requested=bool(self._graph_enabled or self._graph_error), active=bool(self._graph_enabled and len(graphs) > 0),
+                    graphs=len(graphs), segments_per_graph=segs, replays=self._graph_replays, eager_iterations=self._eager_iterations,
+                    error=self._graph_error, graph_collectives=mode)
 
     def _capture_segments(self, unroll: int = 1) -> list:
         """`_record_segments`, and if recording WITH the collectives inside the graph raises (every rank runs the same code,

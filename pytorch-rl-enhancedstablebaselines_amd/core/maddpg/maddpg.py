@@ -223,7 +223,10 @@ class MADDPG(OffPolicyAlgorithm):
             self.logger.record(f"train/agent_{i}_critic_loss", DeviceMean(self._loss_sums[f"critic{i}"], gradient_steps))
 
     def _train_device_only(self, gradient_steps: int, batch_size: int) -> None:
-        self._loss_sum_buf.zero_()
+        # a call without a policy update keeps the actors' last loss sums (slots [0, n_agents)), like maddpg.py:183-191 keeps
+        # the last recorded value until the next actor update; the critics' slots are zeroed every call
+        n_actor = (self._n_updates + gradient_steps) // self.policy_delay - self._n_updates // self.policy_delay
+        (self._loss_sum_buf if n_actor > 0 else self._loss_sum_buf[self.n_agents:]).zero_()
         n_updates = self._n_updates
         A, C = self.actor, self.critic
         for _ in range(gradient_steps):

@@ -106,7 +106,10 @@ class TD3(OffPolicyAlgorithm):
         self.logger.record("train/critic_loss", DeviceMean(self._loss_sums["critic"], gradient_steps))
 
     def _train_device_only(self, gradient_steps: int, batch_size: int) -> None:
-        self._loss_sum_buf.zero_()
+        # the reference keeps the last np.mean(actor_losses) until the next actor update (td3.py:207-211): a call without a
+        # policy update zeroes the critic slot only, so a log dump after it still resolves the lazily-read actor loss
+        n_actor = (self._n_updates + gradient_steps) // self.policy_delay - self._n_updates // self.policy_delay
+        (self._loss_sum_buf if n_actor > 0 else self._loss_sum_buf[1:2]).zero_()
         n_updates = self._n_updates  # host counter advances in _train_host_only
         for _ in range(gradient_steps):
             n_updates += 1

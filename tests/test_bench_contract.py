@@ -1,0 +1,79 @@
+"""bench.py's driver contract: `python bench.py --gpus N` starts N ranks by itself, proves the rank
+count on the JSON line, and refuses to report a run that is not what it says it is."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _run(args, env=None, timeout=900):
+    e = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    e.update(env or {})
+    return subprocess.run([sys.executable, BENCH] + args, env=e, capture_output=True, text=True, timeout=timeout)
+
+
+def test_gpus_n_without_enough_devices_is_refused_not_relabelled():
+    """No launcher, no GPUs (this container) or fewer than N: non-zero exit, no JSON line (round 1 silently ran 1 rank)."""
+    import torch as th
+
+    if th.cuda.device_count() >= 2:
+        pytest.skip("needs a node with < 2 GPUs")
+    r = _run(["--gpus", "2", "--steps", "2", "--warmup", "1"], timeout=120)
+    assert r.returncode != 0 and r.stdout.strip() == ""
+    assert "refusing" in r.stderr
+
+
+def test_world_size_mismatch_is_refused():
+    r = _run(["--gpus", "4", "--steps", "2", "--warmup", "1"], env=dict(WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), timeout=120)
+    assert r.returncode != 0 and r.stdout.strip() == ""
+    assert "refusing to label" in r.stderr
+
+
+@pytest.mark.gpu
+def test_bench_gpus_2_launches_two_ranks_by_itself():
+    """The plain command the driver's SCALE run issues, rehearsed on ONE MI355X: both ranks on cuda:0, gloo transport (RCCL
+    refuses two ranks on one device). Asserts the line's own proof of the rank count and the honesty keys."""
+    r = _run(["--gpus", "2", "--steps", "10", "--warmup", "5", "--no-cpu-baseline", "--no-roofline"],
+             env=dict(CSTR_DIST_BACKEND="gloo", CSTR_BENCH_SINGLE_DEVICE="1"))
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["rccl_world"] == 2 and rec["config"]["parallelism"] == "dp2"
+    assert rec["allreduce_checksum"] == dict(expected=3, got=3, backend="gloo")
+    assert rec["weights_identical_across_ranks"] is True
+    assert rec["graph_collectives"] == "segmented"  # gloo collectives are never recorded into a hipGraph
+    assert rec["hip_graph_active"] is True and rec["eager_iterations_in_timed_region"] == 0
+    assert rec["hip_graph_replays_in_timed_region"] == rec["timed_steps_total"] >= rec["steps"] == 10
+    assert rec["timed_seconds_total"] >= 0.25  # a 10-step region is ~2 ms: it must have been repeated
+    assert rec["config"]["global_batch"] == 512 and rec["scaling"] == "weak"
+
+
+@pytest.mark.gpu
+def test_bench_single_gpu_line_carries_roofline_baseline_and_guards():
+    r = _run(["--steps", "20", "--warmup", "5", "--cpu-seconds", "2", "--no-variant"])
+    assert r.returncode == 0, r.stderr[-3000:]
+    (line,) = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    rec = json.loads(line)
+    assert rec["n_gpus"] == 1 and rec["rccl_world"] == 1 and rec["steps"] == 20
+    assert rec["timed_steps_total"] % 20 == 0 and rec["timed_seconds_total"] >= 0.25
+    assert rec["hip_graph_active"] is True and rec["hip_graph_error"] is None
+    assert rec["roofline"]["bound"] == "hbm" and rec["roofline_mfma"]["bound"] == "mfma"
+    assert rec["cpu_baseline"]["kind"] == "port" and rec["cpu_baseline"]["cores"] >= 1
+    assert rec["reference_python_env_steps_per_s"]["value"] == 4200.0
+
+
+@pytest.mark.gpu
+def test_bench_fails_when_graph_capture_falls_back():
+    """A capture regression must not pass as `hip_graph: true`: CSTR_BENCH_BREAK_CAPTURE makes the captured body raise."""
+    r = _run(["--steps", "5", "--warmup", "5", "--no-cpu-baseline", "--no-roofline", "--no-variant"], env=dict(CSTR_BENCH_BREAK_CAPTURE="1"))
+    assert r.returncode == 3, (r.returncode, r.stderr[-2000:])
+    assert "INVALID RUN" in r.stderr
+    (line,) = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    rec = json.loads(line)
+    assert rec["hip_graph_active"] is False and "injected" in rec["hip_graph_error"]

@@ -114,3 +114,49 @@ def test_collectives_inside_the_graph_match_segmented_and_eager(tmp_path):
         assert out[mode]["n_updates"] == out["eager"]["n_updates"] == 13
         for k in ("actor", "critic", "alpha", "obs"):
             assert th.equal(out[mode][k], out["eager"][k]), (mode, k)
+
+
+def _capture_failure_worker(rank, port, out_dir):
+    import sys
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    root = os.path.dirname(here)
+    for p in (root, os.path.join(root, "pytorch-rl-enhancedstablebaselines_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    from core.common import distributed as du
+
+    th.cuda.set_device(0)
+    th.distributed.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                                      device_id=th.device("cuda", 0))
+    du.is_distributed = lambda: True
+    real, calls = du.dist.all_reduce, []
+
+    def flaky(tensor, *a, **kw):
+        calls.append(bool(th.cuda.is_current_stream_capturing()))
+        if calls[-1]:
+            raise RuntimeError("injected: collective refused under capture")
+        return real(tensor, *a, **kw)
+
+    du.dist.all_reduce = flaky
+    ok = du.graph_collectives_ok("cuda:0")
+    du.dist.all_reduce = real
+    # the process survived, the stream left capture mode, and ordinary work + collectives still run
+    x = th.arange(8, dtype=th.float32, device="cuda:0")
+    real(x)
+    th.cuda.synchronize()
+    th.save(dict(ok=ok, calls=calls, x=x.cpu(), capturing=bool(th.cuda.is_current_stream_capturing())),
+            os.path.join(out_dir, "capfail.pt"))
+    th.distributed.destroy_process_group()
+
+
+def test_graph_collectives_trial_survives_a_failed_capture(tmp_path):
+    """a collective that raises while being captured must not leave the stream capturing nor destroy the graph
+    mid-capture; the trial returns False after the SAME collective sequence as a healthy rank up to the first verdict
+    (warm all-reduce, captured attempt, MIN verdict)."""
+    mp.spawn(_capture_failure_worker, args=(_free_port(), str(tmp_path)), nprocs=1, join=True)
+    out = th.load(tmp_path / "capfail.pt")
+    assert out["ok"] is False and out["capturing"] is False
+    assert out["calls"] == [False, True, False]  # warm-up, the captured attempt, the "captured" verdict; no replay verdict
+    assert th.equal(out["x"], th.arange(8, dtype=th.float32))

@@ -20,9 +20,47 @@ from conftest import rel_err
 pytestmark = pytest.mark.gpu
 
 
-def q_err(got, want):
+STRICT_Q = {}  # label -> worst per-element relative Q error seen (written to gpurun_out/ at session end, quoted in DESIGN.md)
+
+
+def q_err(got, want, label=None):
+    """The asserted bound: |dq_i| <= 1e-5 * max(|q_i|, mean|q|). Beside it the STRICT per-element figure |dq_i| / |q_i| (no
+    batch-scale floor; only an absolute 1e-3 floor against division by ~0) is recorded per test and asserted < 1e-4: one f32
+    ulp of a Q-value of magnitude 4 is 4.8e-7, so an element whose |q| is 100x below the batch scale cannot meet 1e-5 of
+    ITSELF under any summation order -- that is what the floor is for."""
     want = np.asarray(want, np.float64)
+    strict = rel_err(got, want, 1e-3)
+    if label is not None:
+        STRICT_Q[label] = max(STRICT_Q.get(label, 0.0), strict)
+    assert strict < 1e-4, (label, strict)
     return rel_err(got, want, float(np.abs(want).mean()))
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _dump_strict_q():
+    yield
+    import json
+    import os
+
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if STRICT_Q and os.path.isdir(out):
+        with open(os.path.join(out, "q_strict_rel_err.json"), "w") as fh:
+            json.dump({k: float(f"{v:.3e}") for k, v in sorted(STRICT_Q.items())}, fh, indent=1)
+
+
+def _check_init(model, g, mods):
+    """Seeded initial weights == the reference's (construction order = RNG order): bit-exact, or via the digests of a
+    class-default fixture (first 64 values bit-exact + the f64 sum)."""
+    for nm in mods:
+        sd = getattr(model, nm).state_dict()
+        for k, v in sd.items():
+            a, key = v.cpu().numpy(), f"before/{nm}/{k}"
+            if key in g:
+                np.testing.assert_array_equal(a, g[key], err_msg=f"init {nm}/{k}")
+            else:
+                assert tuple(a.shape) == tuple(g[key + "#shape"]), key
+                np.testing.assert_array_equal(a.reshape(-1)[:64], g[key + "#head"], err_msg=key)
+                assert a.astype(np.float64).sum() == float(g[key + "#sum"]), key
 
 
 def _load_ring(model, g):
@@ -104,9 +142,10 @@ def test_sac_train_teacher_forced(golden, tag, fused_path, monkeypatch):
             np.testing.assert_array_equal(getattr(b, name).cpu().numpy(), g[f"step{k}/batch_{name}"], err_msg=f"step {k} batch {name}")
         t = model.last_train_tensors
         # Q-values and TD targets: 1e-5 relative (north_star)
-        assert q_err(t["target_q"].cpu().numpy(), g[f"step{k}/target_q"]) < 1e-5, f"target_q step {k}"
-        assert q_err(t["current_q"][0].cpu().numpy(), g[f"step{k}/current_q1"]) < 1e-5, f"q1 step {k}"
-        assert q_err(t["current_q"][1].cpu().numpy(), g[f"step{k}/current_q2"]) < 1e-5, f"q2 step {k}"
+        lab = f"sac_{tag}_{fused_path if fused_path is not True else ('rocblas' if not fused.USE_FUSED_LINEAR else 'fused')}"
+        assert q_err(t["target_q"].cpu().numpy(), g[f"step{k}/target_q"], lab) < 1e-5, f"target_q step {k}"
+        assert q_err(t["current_q"][0].cpu().numpy(), g[f"step{k}/current_q1"], lab) < 1e-5, f"q1 step {k}"
+        assert q_err(t["current_q"][1].cpu().numpy(), g[f"step{k}/current_q2"], lab) < 1e-5, f"q2 step {k}"
         lv = model.logger.name_to_value
         for key in ("critic_loss", "actor_loss", "ent_coef_loss", "ent_coef"):
             assert rel_err(float(lv[f"train/{key}"]), float(g[f"step{k}/{key}"]), 1e-3) < 1e-5, f"{key} step {k}"
@@ -117,7 +156,10 @@ def test_sac_train_teacher_forced(golden, tag, fused_path, monkeypatch):
 
 
 @pytest.mark.parametrize("fused_path", [True, "rocblas", False])
-def test_td3_train_teacher_forced(golden, fused_path, monkeypatch):
+@pytest.mark.parametrize("tag", ["small", "default"])
+def test_td3_train_teacher_forced(golden, tag, fused_path, monkeypatch):
+    """tag "default": the class-default nets [400, 300] (reference core/td3/policies.py:141-145) at batch 256 -- widths that are
+    not multiples of 16: MFMA tile edges, split-K and the packed-batch path of the fused learner end to end (VERDICT r1 missing-2)."""
     from core.common import fused, legacy_rng
     from core.td3 import TD3
 
@@ -125,18 +167,20 @@ def test_td3_train_teacher_forced(golden, fused_path, monkeypatch):
         monkeypatch.setattr(fused, "USE_FUSED_LINEAR", False)
         fused_path = True
 
-    g = golden("td3_train_kat.npz")
+    g = golden("td3_train_kat.npz" if tag == "small" else "td3_train_kat_default.npz")
     gamma, tau, tpn, tnc, delay, lr, B, n_steps = g["hyper"]
     B, n_steps = int(B), int(n_steps)
-    model = TD3("MlpPolicy", _make_env(4), seed=0, batch_size=B, buffer_size=64 * 4, policy_kwargs=dict(net_arch=[48, 32]))
+    kw = dict(policy_kwargs=dict(net_arch=[48, 32])) if tag == "small" else {}
+    model = TD3("MlpPolicy", _make_env(4), seed=0, batch_size=B, buffer_size=64 * 4, **kw)
+    if tag == "default":
+        assert B == 256 and tuple(model.actor.mu[0].weight.shape) == (400, 4) and tuple(model.actor.mu[2].weight.shape) == (300, 400)
+    lab = f"td3_{tag}_{fused_path if fused_path is not True else ('rocblas' if not fused.USE_FUSED_LINEAR else 'fused')}"
     assert model.fused_learner
     model.fused_learner = fused_path
     assert (model.gamma, model.tau, model.target_policy_noise, model.target_noise_clip, model.policy_delay) == (gamma, tau, tpn, tnc, int(delay))
     assert model.lr_schedule(1) == lr
     mods = ["actor", "actor_target", "critic", "critic_target"]
-    for nm in mods:
-        for k, v in getattr(model, nm).state_dict().items():
-            np.testing.assert_array_equal(v.cpu().numpy(), g[f"before/{nm}/{k}"], err_msg=f"init {nm}/{k}")
+    _check_init(model, g, mods)
     _load_ring(model, g)
     legacy_rng.seed(int(g["np_seed"]), model.device)
     model.debug_capture = True
@@ -147,9 +191,9 @@ def test_td3_train_teacher_forced(golden, fused_path, monkeypatch):
         for name in ("observations", "actions", "next_observations", "dones", "rewards"):
             np.testing.assert_array_equal(getattr(b, name).cpu().numpy(), g[f"step{k}/batch_{name}"])
         t = model.last_train_tensors
-        assert q_err(t["target_q"].cpu().numpy(), g[f"step{k}/target_q"]) < 1e-5
-        assert q_err(t["current_q"][0].cpu().numpy(), g[f"step{k}/current_q1"]) < 1e-5
-        assert q_err(t["current_q"][1].cpu().numpy(), g[f"step{k}/current_q2"]) < 1e-5
+        assert q_err(t["target_q"].cpu().numpy(), g[f"step{k}/target_q"], lab) < 1e-5
+        assert q_err(t["current_q"][0].cpu().numpy(), g[f"step{k}/current_q1"], lab) < 1e-5
+        assert q_err(t["current_q"][1].cpu().numpy(), g[f"step{k}/current_q2"], lab) < 1e-5
         lv = model.logger.name_to_value
         assert rel_err(float(lv["train/critic_loss"]), float(g[f"step{k}/critic_loss"]), 1e-3) < 1e-5
         if f"step{k}/actor_loss" in g:  # delayed policy update: every 2nd step
@@ -157,7 +201,7 @@ def test_td3_train_teacher_forced(golden, fused_path, monkeypatch):
             assert t["actor_loss"] is not None
         else:
             assert t["actor_loss"] is None
-    _check_weights(model, g, "after", mods)
+    _check_weights(model, g, "after", mods, digest=(tag == "default"))
     assert model.critic.optimizer.step_count == n_steps and model.actor.optimizer.step_count == n_steps // 2
 
 
@@ -303,30 +347,37 @@ def test_hipgraph_iteration_equals_eager():
         assert abs(e["alpha"] - g["alpha"]) < 1e-5
 
 
-@pytest.mark.parametrize("fused_path", [True, False])
-@pytest.mark.parametrize("algo", ["maddpg", "iddpg"])
-def test_maddpg_train_teacher_forced(golden, algo, fused_path):
+@pytest.mark.parametrize("fused_path", [True, "rocblas", False])
+@pytest.mark.parametrize("algo", ["maddpg", "iddpg", "maddpg_default"])
+def test_maddpg_train_teacher_forced(golden, algo, fused_path, monkeypatch):
     """MADDPG / IDDPG on the natural 2-agent split of the CSTR env vs the unmodified reference (core/maddpg/maddpg.py:117-191,
-    core/iddpg/iddpg.py), quirks Q1-Q4 included: per-agent Q-values / TD targets / losses at 1e-5, weights after 4 steps."""
-    from core.common import legacy_rng
+    core/iddpg/iddpg.py), quirks Q1-Q4 included: per-agent Q-values / TD targets / losses at 1e-5, weights after 4 steps.
+    "maddpg_default": the class-default per-agent nets [400, 300] (core/maddpg/policies.py:344-353), batch 256."""
+    from core.common import fused, legacy_rng
     from core.iddpg import IDDPG
     from core.maddpg import MADDPG as _MADDPG
 
+    if fused_path == "rocblas":  # the fused glue with every GEMM left to PyTorch-ROCm / rocBLAS (CSTR_FUSED_LINEAR=0)
+        monkeypatch.setattr(fused, "USE_FUSED_LINEAR", False)
+        fused_path = True
+    tag = "default" if algo.endswith("_default") else "small"
+    algo = algo.split("_")[0]
+    lab = f"{algo}_{tag}_{fused_path if fused_path is not True else ('rocblas' if not fused.USE_FUSED_LINEAR else 'fused')}"
     MADDPG = _MADDPG if algo == "maddpg" else IDDPG
-    g = golden(f"{algo}_train_kat.npz")
+    g = golden(f"{algo}_train_kat.npz" if tag == "small" else f"{algo}_train_kat_default.npz")
     gamma, tau, tpn, tnc, delay, lr, B, n_steps, n_agents = g["hyper"]
     B, n_steps, n_agents = int(B), int(n_steps), int(n_agents)
+    kw = dict(policy_kwargs=dict(net_arch=[[32, 24], [32, 24]])) if tag == "small" else {}
     model = MADDPG(n_agents, "MlpPolicy", _make_env(4), [[0, 1], [2, 3]], [[0], [1]], learning_rate_list=[lr, lr], seed=0,
-                   batch_size=B, buffer_size=64 * 4, policy_kwargs=dict(net_arch=[[32, 24], [32, 24]]))
+                   batch_size=B, buffer_size=64 * 4, **kw)
     assert (model.gamma, model.tau, model.target_policy_noise, model.target_noise_clip, model.policy_delay) == (gamma, tau, tpn, tnc, int(delay))
     assert model.fused_learner
     model.fused_learner = fused_path
     mods = ["actor", "actor_target", "critic", "critic_target"]
     for nm in mods:  # seeded init == reference (construction order = RNG order)
         sd = getattr(model, nm).state_dict()
-        assert set(sd) == {k.split("/", 2)[2] for k in g.files if k.startswith(f"before/{nm}/")}
-        for k, v in sd.items():
-            np.testing.assert_array_equal(v.cpu().numpy(), g[f"before/{nm}/{k}"], err_msg=f"init {nm}/{k}")
+        assert set(sd) == {k.split("/", 2)[2].split("#")[0] for k in g.files if k.startswith(f"before/{nm}/")}
+    _check_init(model, g, mods)
     # quirk Q1: predict() output goes to the env and the buffer unchanged
     model._last_obs = g["sa_obs"]
     model.num_timesteps = 10**6
@@ -346,13 +397,13 @@ def test_maddpg_train_teacher_forced(golden, algo, fused_path):
         lv = model.logger.name_to_value
         for a in range(n_agents):
             t = model.last_train_tensors["agents"][a]
-            assert q_err(t["target_q"].cpu().numpy(), g[f"step{k}/agent{a}_target_q"]) < 1e-5, (k, a)
-            assert q_err(t["current_q"][0].cpu().numpy(), g[f"step{k}/agent{a}_current_q1"]) < 1e-5, (k, a)
-            assert q_err(t["current_q"][1].cpu().numpy(), g[f"step{k}/agent{a}_current_q2"]) < 1e-5, (k, a)
+            assert q_err(t["target_q"].cpu().numpy(), g[f"step{k}/agent{a}_target_q"], lab) < 1e-5, (k, a)
+            assert q_err(t["current_q"][0].cpu().numpy(), g[f"step{k}/agent{a}_current_q1"], lab) < 1e-5, (k, a)
+            assert q_err(t["current_q"][1].cpu().numpy(), g[f"step{k}/agent{a}_current_q2"], lab) < 1e-5, (k, a)
             assert rel_err(float(lv[f"train/agent_{a}_critic_loss"]), float(g[f"step{k}/agent{a}_critic_loss"]), 1e-3) < 1e-5
             if f"step{k}/agent{a}_actor_loss" in g:
                 assert rel_err(float(lv[f"train/agent_{a}_actor_loss"]), float(g[f"step{k}/agent{a}_actor_loss"]), 1e-3) < 1e-5
-    _check_weights(model, g, "after", mods)
+    _check_weights(model, g, "after", mods, digest=(tag == "default"))
     assert model._n_updates == n_steps
     pred, _ = model.predict(g["sa_obs"], deterministic=False)  # the fixture's predict() ran on the trained weights
     np.testing.assert_allclose(pred, g["sa_predict"], rtol=2e-4, atol=2e-5)
@@ -833,3 +884,136 @@ def test_reference_td3_cstr_recipe_runs_and_keeps_the_numpy_stream():
     assert int(vec_env.step_count[0]) == steps - 400 and float(vec_env.static_init.abs().sum()) > 0  # one reset at step 400
     for p in model.policy.parameters():
         assert th.isfinite(p).all()
+
+
+def test_full_size_td3_run_index_stream_ring_and_delayed_policy_updates():
+    """BASELINE config 3 at full size (TD3 class defaults [400, 300], lr 1e-3, 4096 envs, ring 244 x 4096, batch 256), 500
+    iterations from the TWO captured hipGraphs of the delayed policy update (reference core/td3/td3.py:154-211): the sampler's
+    MT19937 stream ends where numpy's would, actor steps == updates // policy_delay, ring / counters / episode statistics as in
+    the SAC full-size run."""
+    from core.common import legacy_rng
+    from core.common.vec_env import CSTRVecEnv
+    from core.td3 import TD3
+
+    N, B, seed, iters = 4096, 256, 13, 500
+    env = CSTRVecEnv(N)
+    model = TD3("MlpPolicy", env, seed=seed)
+    assert tuple(model.actor.mu[2].weight.shape) == (300, 400) and model.lr_schedule(1) == 1e-3 and model.policy_delay == 2
+    model.enable_graph_capture()
+    model.learn(N * iters)
+    st = model.graph_status()
+    assert st["active"] and st["graphs"] == 2 and st["error"] is None and st["replays"] >= iters - 12
+    rb = model.replay_buffer
+    R = rb.buffer_size
+    assert R == 244 and model.num_timesteps == N * iters and model._n_updates == iters
+    assert model.critic.optimizer.step_count == iters and model.actor.optimizer.step_count == iters // 2
+    rs = np.random.RandomState(seed + N - 1)
+    for k in range(1, iters + 1):
+        rs.randint(0, min(k, R), size=B)
+        rs.randint(0, N, size=B)
+    stt, w = rs.get_state(), legacy_rng.global_stream(model.device).cpu().numpy().view(np.uint32)
+    np.testing.assert_array_equal(w[:624], stt[1])
+    assert int(w[624]) == stt[2]
+    ctl = rb.ring.ctl.cpu().numpy()
+    assert (ctl[0], ctl[1], ctl[3]) == (iters % R, 1, iters) and rb.pos == iters % R and rb.full
+    assert int(env.step_count.min()) == int(env.step_count.max()) == iters - 400
+    n_ep, ret_sum, len_sum, _ = model._ep_stats.cpu().tolist()
+    assert n_ep == N and len_sum == 400 * N and ret_sum < 0
+    d, t = rb.dones.cpu().numpy(), rb.timeouts.cpu().numpy()
+    assert d.sum() == N and t.sum() == N and d[(400 - 1) % R].all()
+    for p in model.policy.parameters():
+        assert th.isfinite(p).all()
+    # target networks moved (polyak every 2nd step) but are not the online networks
+    assert not th.equal(model.policy.actor_target_arena.flat, model.policy.actor_arena.flat)
+    assert float(model.replay_buffer.actions.abs().max()) <= 1.0
+
+
+def test_config1_sac_single_env_10k_steps_matches_reference_counters_and_stream(golden):
+    """BASELINE config 1 ("SAC MlpPolicy on single two-series CSTR env, 10k steps", plumbing): the same learn() call on the
+    device stack. The fixture holds what the UNMODIFIED reference left behind after SAC("MlpPolicy", DummyVecEnv([CSTR]),
+    seed=0).learn(10_000) on the CPU: counters and the global legacy numpy stream. With n_envs = 1 the env-index draw
+    randint(0, 1) consumes nothing (core/common/buffers.py:309): the stream is a function of the row draws alone."""
+    from core import SAC
+    from core.common import legacy_rng
+    from core.common.vec_env import DummyVecEnv
+    from twoseriescstr import TwoSeriesCSTREnv
+
+    g = golden("config1_sac_single_env_kat.npz")
+    total, seed = int(g["total_timesteps"]), int(g["seed"])
+    venv = DummyVecEnv([lambda: TwoSeriesCSTREnv()])
+    model = SAC("MlpPolicy", venv, seed=seed)
+    assert (model.batch_size, model.learning_starts, model.replay_buffer.buffer_size) == (int(g["batch_size"]), int(g["learning_starts"]), int(g["ring_rows"]))
+    model.learn(total)
+    assert model.num_timesteps == int(g["num_timesteps"]) == total and model._n_updates == int(g["n_updates"]) == total - 100
+    rb = model.replay_buffer
+    assert rb.pos == int(g["ring_pos"]) and bool(rb.full) == bool(g["ring_full"]) and model._episode_num == int(g["episode_num"]) == total // 400
+    assert model.actor.optimizer.step_count == int(g["actor_adam_step"])
+    w = legacy_rng.global_stream(model.device).cpu().numpy().view(np.uint32)
+    np.testing.assert_array_equal(w[:624], g["mt_key"])
+    assert int(w[624]) == int(g["mt_pos"]) and int(w[625]) == int(g["mt_has_gauss"]) == 0
+    assert float(rb.dones[:rb.pos].sum()) == float(g["dones_sum"]) and float(rb.timeouts[:rb.pos].sum()) == float(g["timeouts_sum"])
+    for p in model.policy.parameters():
+        assert th.isfinite(p).all()
+
+
+def test_maddpg_four_agents_default_nets_fused_equals_stock_aten():
+    """BASELINE config 5 at its real shapes: 4 agents on the twin-train env (8 obs / 4 act), 1024 envs, class-default nets
+    [400, 300] per agent (reference core/maddpg/policies.py:344-353), batch 256. No 4-agent reference env exists,
+    so the fused path is checked against the stock-ATen evaluation of the same statements -- which IS golden-pinned to the
+    reference for 2 agents at these widths (maddpg_train_kat_default) -- on the same ring, index stream and smoothing noise."""
+    from core.common import legacy_rng
+    from core.common.vec_env import CSTRVecEnv
+    from core.maddpg import MADDPG
+
+    N, B, n_calls = 1024, 256, 4
+    models = []
+    for fused_path in (True, False):
+        env = CSTRVecEnv(N, obs_dim=8, twin=True)
+        model = MADDPG(4, "MlpPolicy", env, [[0, 1], [2, 3], [4, 5], [6, 7]], [[0], [1], [2], [3]], learning_rate_list=[1e-3] * 4, seed=3,
+                       learning_starts=10**9)
+        model.learn(N * 6)  # warm-up only: identical rings
+        assert model.fused_learner and model.replay_buffer.actions.shape == (976, N, 4)
+        assert tuple(model.actor.mu_list[0][2].weight.shape) == (300, 400)
+        model.fused_learner = fused_path
+        models.append(model)
+    a, b = models
+    for name in ("observations", "next_observations", "actions", "rewards", "dones"):
+        assert th.equal(getattr(a.replay_buffer, name), getattr(b.replay_buffer, name))
+    g = th.Generator().manual_seed(5)
+    for call in range(n_calls):
+        noise = [th.randn(B, 1, generator=g) * float(a.target_policy_noise) for _ in range(4)]
+        for m in (a, b):
+            m.noise_queue = [z.clone() for z in noise]
+            legacy_rng.seed(300 + call, m.device)
+            m.debug_capture = True
+            m.train(gradient_steps=1, batch_size=B)
+            assert not m.noise_queue
+        for ag in range(4):
+            ta, tb = a.last_train_tensors["agents"][ag], b.last_train_tensors["agents"][ag]
+            assert q_err(ta["target_q"].cpu().numpy(), tb["target_q"].cpu().numpy(), "maddpg4_default_fused_vs_aten") < 1e-5
+            assert q_err(ta["current_q"][0].cpu().numpy(), tb["current_q"][0].cpu().numpy(), "maddpg4_default_fused_vs_aten") < 1e-5
+    for (n1, p1), (_, p2) in zip(a.policy.named_parameters(), b.policy.named_parameters()):
+        scale = max(float(p2.detach().abs().max()), 1e-3)
+        assert float((p1 - p2).detach().abs().max()) < 2e-5 * scale + 1e-4 * float(p2.detach().abs().max()), n1
+    assert a._n_updates == b._n_updates == n_calls
+    assert all(o.step_count == n_calls for o in a.critic.optimizer_list) and all(o.step_count == n_calls // 2 for o in a.actor.optimizer_list)
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_td3_actor_loss_survives_a_log_read_after_a_critic_only_step(graph):
+    """`train/actor_loss` is read lazily from a device slot; a gradient step without a policy update must not
+    zero it (the reference keeps the last np.mean(actor_losses) until the next actor update, td3.py:207-211)."""
+    from core.common.vec_env import CSTRVecEnv
+    from core.td3 import TD3
+
+    N = 64
+    model = TD3("MlpPolicy", CSTRVecEnv(N), seed=1, batch_size=32, buffer_size=N * 16, policy_kwargs=dict(net_arch=[32, 32]))
+    if graph:
+        model.enable_graph_capture()
+    model.learn(N * 14)  # learning starts after the 2nd vec-step: 13 updates, the last one is critic-only
+    assert model._n_updates == 13 and model._n_updates % model.policy_delay == 1
+    lv = model.logger.name_to_value
+    a, c = float(lv["train/actor_loss"]), float(lv["train/critic_loss"])
+    assert a != 0.0 and np.isfinite(a) and c > 0.0
+    model.learn(N * 1, reset_num_timesteps=False)  # one more update: an actor step -> a fresh value
+    assert model._n_updates == 14 and float(model.logger.name_to_value["train/actor_loss"]) != a

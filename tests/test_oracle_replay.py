@@ -83,3 +83,27 @@ def test_sample_empty_ring_raises():
     ring = orc.ReplayRing(4, 2, 4, 2)
     with pytest.raises(ValueError):  # numpy: "high <= 0" (buffers.py:113 with pos == 0)
         ring.sample(orc.MT19937(0), 8)
+
+
+def test_config1_single_env_stream_matches_the_reference_run(golden):
+    """BASELINE config 1: the UNMODIFIED reference SAC("MlpPolicy", DummyVecEnv([CSTR]), seed=0).learn(10_000) on the CPU left
+    its global legacy stream in `mt_key / mt_pos` (tools/refharness/gen_golden.py:gen_config1). The oracle replays the sampler's
+    calls: seed + n_envs - 1 = 0; per gradient step randint(0, rows_written) for 256 rows, then randint(0, 1), which consumes
+    nothing (core/common/buffers.py:113-114, :309)."""
+    g = golden("config1_sac_single_env_kat.npz")
+    total, ls, B = int(g["total_timesteps"]), int(g["learning_starts"]), int(g["batch_size"])
+    assert int(g["n_updates"]) == total - ls and int(g["ring_pos"]) == total and not bool(g["ring_full"]) and int(g["episode_num"]) == total // 400
+    mt, rs = orc.MT19937(int(g["seed"]) + 1 - 1), np.random.RandomState(int(g["seed"]))
+    for k in range(ls + 1, total + 1):  # trains once num_timesteps > learning_starts; `upper` = pos = k rows written
+        a = mt.randint(k, B)
+        e = mt.randint(1, B)
+        assert not e.any() and a.max() < k
+        if k % 1237 == 0:
+            np.testing.assert_array_equal(a, rs.randint(0, k, size=B))
+        else:
+            rs.randint(0, k, size=B)
+    np.testing.assert_array_equal(mt.key, g["mt_key"])
+    assert mt.pos == int(g["mt_pos"]) and int(g["mt_has_gauss"]) == 0
+    st = rs.get_state()
+    np.testing.assert_array_equal(st[1], g["mt_key"])
+    assert st[2] == int(g["mt_pos"])

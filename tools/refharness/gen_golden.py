@@ -40,6 +40,22 @@ def save(name, **arrays):
     print(f"wrote {path}: {len(arrays)} arrays, {os.path.getsize(path)} bytes")
 
 
+def slim_weights(out, keep=4096, head=64, with_shape=True):
+    """Digest form for class-default nets: tensors above `keep` elements are stored as sum / abs-sum / first `head` values
+    (the initial weights are reproducible from the seed -- checked bit-exactly by the init KAT and by #head/#sum here)."""
+    slim = {}
+    for k, v in out.items():
+        if (k.startswith("before/") or k.startswith("after/")) and v.size > keep:
+            slim[k + "#sum"] = np.float64(v.astype(np.float64).sum())
+            slim[k + "#abs"] = np.float64(np.abs(v.astype(np.float64)).sum())
+            slim[k + "#head"] = v.reshape(-1)[:head].copy()
+            if with_shape:
+                slim[k + "#shape"] = np.array(v.shape, np.int64)
+        else:
+            slim[k] = v
+    return slim
+
+
 # --------------------------------------------------------------------------------------- env
 def gen_env():
     from twoseriescstr import TwoSeriesCSTREnv
@@ -354,19 +370,17 @@ def gen_sac():
         if tag == "default":
             # keep the committed fixture small: weights are reproducible from seed 0 (checked by the
             # init KAT), so store only digests of the big tensors for the default-size nets
-            slim = {}
-            for k, v in out.items():
-                if (k.startswith("before/") or k.startswith("after/")) and v.size > 4096:
-                    slim[k + "#sum"] = np.float64(v.astype(np.float64).sum())
-                    slim[k + "#abs"] = np.float64(np.abs(v.astype(np.float64)).sum())
-                    slim[k + "#head"] = v.reshape(-1)[:64].copy()
-                else:
-                    slim[k] = v
-            out = slim
+            out = slim_weights(out, with_shape=False)
         save(f"sac_train_kat_{tag}.npz", **out)
 
 
 def gen_td3():
+    _gen_td3("small")
+    _gen_td3("default")
+
+
+def _gen_td3(tag):
+    """tag "small": net_arch [48, 32], batch 64; "default": the class default [400, 300] (td3/policies.py:141-145), batch 256."""
     import torch.nn.functional as F_real
 
     import core.td3.td3 as td3mod
@@ -384,10 +398,11 @@ def gen_td3():
             rec.mse.append((a.detach().clone(), b.detach().clone()))
             return F_real.mse_loss(a, b, *args, **kw)
 
-    N, D, A, B, n_steps = 4, 4, 2, 64, 4
+    N, D, A, n_steps = 4, 4, 2, 4
+    B = 64 if tag == "small" else 256
     venv = _make_venv(N)
-    model = TD3("MlpPolicy", venv, seed=0, device="cpu", batch_size=B, buffer_size=64 * N,
-                policy_kwargs=dict(net_arch=[48, 32]))
+    pk = dict(policy_kwargs=dict(net_arch=[48, 32])) if tag == "small" else {}
+    model = TD3("MlpPolicy", venv, seed=0, device="cpu", batch_size=B, buffer_size=64 * N, **pk)
     model.set_logger(Logger(folder=None, output_formats=[]))
     rng = np.random.default_rng(314)
     _fill_buffer(model, rng, 40, N, D, A)
@@ -435,15 +450,24 @@ def gen_td3():
     out["hyper"] = np.array([model.gamma, model.tau, model.target_policy_noise, model.target_noise_clip,
                              model.policy_delay, model.lr_schedule(1), B, n_steps], np.float64)
     out["np_seed"] = np.int64(555)
-    save("td3_train_kat.npz", **out)
+    if tag == "default":
+        assert model.actor.mu[0].out_features == 400 and model.actor.mu[2].out_features == 300
+        save("td3_train_kat_default.npz", **slim_weights(out))
+    else:
+        save("td3_train_kat.npz", **out)
 
 
 def gen_iddpg():
     gen_maddpg(algo="iddpg")
 
 
-def gen_maddpg(algo="maddpg"):
-    """MADDPG / IDDPG on the natural 2-agent split of the CSTR env: agent 0 = reactor 1 ([C1,T1] -> F1), agent 1 = reactor 2."""
+def gen_maddpg_default():
+    gen_maddpg(tag="default")
+
+
+def gen_maddpg(algo="maddpg", tag="small"):
+    """MADDPG / IDDPG on the natural 2-agent split of the CSTR env: agent 0 = reactor 1 ([C1,T1] -> F1), agent 1 = reactor 2.
+    tag "default": the class-default per-agent nets [400, 300] (maddpg/policies.py:344-353), batch 256."""
     import torch.nn.functional as F_real
 
     from core.common.logger import Logger
@@ -465,10 +489,12 @@ def gen_maddpg(algo="maddpg"):
             rec.mse.append((a.detach().clone(), b.detach().clone()))
             return F_real.mse_loss(a, b, *args, **kw)
 
-    N, D, A, B, n_steps, n_agents = 4, 4, 2, 64, 4, 2
+    N, D, A, n_steps, n_agents = 4, 4, 2, 4, 2
+    B = 64 if tag == "small" else 256
     venv = _make_venv(N)
+    pk = dict(policy_kwargs=dict(net_arch=[[32, 24], [32, 24]])) if tag == "small" else {}
     model = MADDPG(n_agents, "MlpPolicy", venv, [[0, 1], [2, 3]], [[0], [1]], learning_rate_list=[1e-3, 1e-3], seed=0, device="cpu",
-                   batch_size=B, buffer_size=64 * N, policy_kwargs=dict(net_arch=[[32, 24], [32, 24]]))
+                   batch_size=B, buffer_size=64 * N, **pk)
     model.set_logger(Logger(folder=None, output_formats=[]))
     rng = np.random.default_rng(2718)
     _fill_buffer(model, rng, 40, N, D, A)
@@ -528,7 +554,38 @@ def gen_maddpg(algo="maddpg"):
     act, buf_act = model._sample_action(0, NormalActionNoise(np.zeros(1), np.ones(1)), N)
     pred, _ = model.predict(obs, deterministic=False)
     out.update(sa_obs=obs, sa_action=act, sa_buffer_action=buf_act, sa_predict=pred)
-    save(f"{algo}_train_kat.npz", **out)
+    if tag == "default":
+        shapes = sorted({tuple(v.shape) for k, v in out.items() if k.startswith("before/actor/") and v.ndim == 2})
+        assert (400, 2) in shapes and (300, 400) in shapes, shapes
+        save(f"{algo}_train_kat_default.npz", **slim_weights(out))
+    else:
+        save(f"{algo}_train_kat.npz", **out)
+
+
+def gen_config1():
+    """BASELINE config 1 (plumbing): the unmodified reference SAC("MlpPolicy") at the class defaults on ONE CSTR env, learn(10_000)
+    on the CPU. Recorded: the counters and the global legacy numpy stream afterwards. With n_envs = 1 the env-index draw
+    `randint(0, high=1)` consumes nothing (buffers.py:309), so the stream position is a function of the row-index draws only."""
+    import time
+
+    from core.common.logger import Logger
+    from core.sac.sac import SAC
+
+    seed, total = 0, 10_000
+    model = SAC("MlpPolicy", _make_venv(1), seed=seed, device="cpu")
+    model.set_logger(Logger(folder=None, output_formats=[]))
+    t0 = time.time()
+    model.learn(total)
+    dt = time.time() - t0
+    st = np.random.get_state()
+    rb = model.replay_buffer
+    save("config1_sac_single_env_kat.npz", seed=np.int64(seed), total_timesteps=np.int64(total), num_timesteps=np.int64(model.num_timesteps),
+         n_updates=np.int64(model._n_updates), episode_num=np.int64(model._episode_num), ring_pos=np.int64(rb.pos), ring_full=np.uint8(rb.full),
+         ring_rows=np.int64(rb.buffer_size), batch_size=np.int64(model.batch_size), learning_starts=np.int64(model.learning_starts),
+         mt_key=st[1].astype(np.uint32), mt_pos=np.int32(st[2]), mt_has_gauss=np.int32(st[3]),
+         reference_env_steps_per_s=np.float64(total / dt), actor_adam_step=np.float64(float(model.actor.optimizer.state_dict()["state"][0]["step"])),
+         dones_sum=np.float64(rb.dones[:rb.pos].sum()), timeouts_sum=np.float64(rb.timeouts[:rb.pos].sum()))
+    print(f"reference SAC, 1 env, {total} steps: {total / dt:.1f} env-steps/s on this container (1 torch thread)")
 
 
 def gen_checkpoint():
@@ -711,7 +768,7 @@ def gen_vecnorm():
     save("vecnormalize_kat.npz", **out)
 
 
-GENS = {"env": gen_env, "resets": gen_resets, "vecnorm": gen_vecnorm, "vecenv": gen_vecenv, "sampler": gen_sampler, "replay": gen_replay, "sac": gen_sac,
+GENS = {"maddpg_default": gen_maddpg_default, "config1": gen_config1, "env": gen_env, "resets": gen_resets, "vecnorm": gen_vecnorm, "vecenv": gen_vecenv, "sampler": gen_sampler, "replay": gen_replay, "sac": gen_sac,
         "td3": gen_td3, "init": gen_init, "maddpg": gen_maddpg, "iddpg": gen_iddpg, "checkpoint": gen_checkpoint}
 
 if __name__ == "__main__":
