@@ -237,10 +237,14 @@ def other_kernels(model, batch):
     w3, b3 = th.randn(2 * a, h, device=p.device) / 16, th.zeros(2 * a, device=p.device)
     act_out, ctl = th.empty(n_rows, a, device=p.device), hip_ops.new_rng_ctl(1, p.device)
     w_tiles = hip_ops.policy_swizzle(w)  # the product path reads the tile-major copy of the hidden layer (FlatAdam.add_weight_shadow)
-    us = event_time_us(lambda: hip_ops.policy_rows_fwd(xo, w1, b1, w, bias, w3, b3, 1, 0, 0, act_out, rng_ctl=ctl, w2_swz=w_tiles), 200, stream,
-                       in_graph=True)
+    # as the training loop launches it: tile-major W2 copy, Philox offset advanced by the collect launch that consumes the actions
+    # (cstr_collect_step_rng_f32) instead of a 256-workgroup ticket of its own; `launch_us_self_advancing` = the stand-alone form
+    us = event_time_us(lambda: hip_ops.policy_rows_fwd(xo, w1, b1, w, bias, w3, b3, 1, 0, 0, act_out, rng_ctl=ctl, w2_swz=w_tiles,
+                                                       defer_rng_advance=True), 200, stream, in_graph=True)
+    us_self = event_time_us(lambda: hip_ops.policy_rows_fwd(xo, w1, b1, w, bias, w3, b3, 1, 0, 0, act_out, rng_ctl=ctl, w2_swz=w_tiles), 200,
+                            stream, in_graph=True)
     flops = 2.0 * n_rows * (k0 * h + h * h + h * 2 * a)
-    out["policy_rows_fwd_kernel"] = dict(launch_us=round(us, 3), shape=[n_rows, k0, h, h, 2 * a], bound="mfma",
+    out["policy_rows_fwd_kernel"] = dict(launch_us=round(us, 3), launch_us_self_advancing=round(us_self, 3), shape=[n_rows, k0, h, h, 2 * a], bound="mfma",
                                          tflops=round(flops / us / 1e6, 2), frac=round(flops / us / 1e6 / F32_MFMA_PEAK_TFLOPS, 4))
     return out
 

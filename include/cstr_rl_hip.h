@@ -128,6 +128,15 @@ int cstr_collect_step_f32(const cstr_coef_t *coef, int integrator, const cstr_ri
                           const float *act_low, const float *act_high, const float *noise, const float *reset_obs,
                           uint64_t *pcg_state, double *static_init, float *reward_out, float *done_out, float *ep_return,
                           double *ep_stats, cstr_stream_t stream);
+/* The same launch additionally advancing a Philox stream offset: policy_rng_ctl (may be NULL) is the control block of the
+ * cstr_policy_rows_fwd_f32 launch that produced policy_out with cstr_policy_mlp_t.reserved bit 0 set ("the caller advances the
+ * offset"); this launch's last workgroup adds policy_rng_advance (= that launch's row count) to its offset word -- the rollout's
+ * _sample_action (core/common/off_policy_algorithm.py:364-411) and env step then share ONE control-word ticket. */
+int cstr_collect_step_rng_f32(const cstr_coef_t *coef, int integrator, const cstr_ring_t *ring, int64_t *ring_ctl,
+                              float *env_obs, int32_t *step_count, const float *policy_out, int squashed,
+                              const float *act_low, const float *act_high, const float *noise, const float *reset_obs,
+                              uint64_t *pcg_state, double *static_init, float *reward_out, float *done_out, float *ep_return,
+                              double *ep_stats, uint64_t *policy_rng_ctl, uint64_t policy_rng_advance, cstr_stream_t stream);
 
 /* np.random.seed(seed) for the device-resident legacy MT19937 state (core/common/utils.py:46;
  * twoseriescstr.py:164 reseeds the same global stream). */
@@ -347,7 +356,10 @@ int cstr_gaussian_head_bwd_input_f32(const float *g_action, int64_t ga_stride, c
  *         counter = offset + row; the offset advances by m); logp [m] optional.
  * head 1: deterministic actor (core/td3/policies.py:75-78): w3 [A][h2], b3 [A], action = out_act(h2 w3^T + b3); eps, rng_ctl
  *         and logp must be NULL.
- * h1, h2 multiples of 4, k0 <= 256, 16 * (h1 + h2 + 8) floats of LDS <= 64 KB. */
+ * h1, h2 multiples of 4, k0 <= 256, 16 * (h1 + h2 + 8) floats of LDS <= 64 KB.
+ * reserved: bit 0 set = the caller advances the Philox offset by m before the stream's next consumer
+ * (cstr_collect_step_rng_f32 does): the launch then ends without its 256-workgroup "last one out" ticket; other bits 0.
+ * With w2_swizzled and h1, h2 <= 512 the software-pipelined kernel runs. */
 typedef struct cstr_policy_mlp {
     int32_t k0, h1, h2, act_dim;
     int32_t act, head, out_act, reserved;

@@ -456,6 +456,7 @@ class FastSacActor:
         self.act_dim = actor.mu.weight.shape[0]
         self.head = head
         self.rng_ctl = None  # in-kernel Philox stream of the sampling head, seeded from torch's seed at first use
+        self.deferred_rng = None  # (rng_ctl, rows) of a whole-network launch that left the stream offset to its caller (`defer_rng`)
         if head is not None:
             w, wg, b, bg = head
             a2 = 2 * self.act_dim
@@ -492,9 +493,12 @@ class FastSacActor:
         return _MergedHeadFn.apply(h, self._hw, self._hb, self._hwg, self._hbg, train_params, self.mu.weight, self.log_std.weight)
 
     def action_log_prob(self, obs: th.Tensor, eps: Optional[th.Tensor] = None, train_params: bool = True, want_logp: bool = True,
-                        xbuf: Optional[th.Tensor] = None):
+                        xbuf: Optional[th.Tensor] = None, defer_rng: bool = False):
         """`xbuf`: a critic input buffer [B, D + A] (observation columns already filled): the action is written into its last
-        A columns and the BUFFER is returned in place of the action (torch.cat((obs, action)) without the launch)."""
+        A columns and the BUFFER is returned in place of the action (torch.cat((obs, action)) without the launch).
+        `defer_rng`: the rollout's caller advances the Philox offset itself (the fused collect launch that consumes the action
+        does it in its last-workgroup epilogue): when the whole-network launch runs it skips its own 256-workgroup ticket and
+        `self.deferred_rng` = (rng_ctl, rows) tells the caller what to pass on; otherwise `self.deferred_rng` stays None."""
         dist = self.actor.action_dist
         if eps is None and dist.eps_queue:  # teacher-forced draw (tests)
             eps = dist.draw_eps((obs.shape[0], self.act_dim), obs.device)
@@ -514,9 +518,12 @@ class FastSacActor:
             (l1, act), (l2, _) = self.latent.layers
             action = xbuf[:, xbuf.shape[1] - self.act_dim:] if xbuf is not None else th.empty(n, self.act_dim, dtype=obs.dtype, device=obs.device)
             logp = th.empty(n, dtype=obs.dtype, device=obs.device) if want_logp else None
+            defer = defer_rng and eps is None
             hip_ops.policy_rows_fwd(obs, l1.weight, l1.bias, l2.weight, l2.bias, self._hw, self._hb, act, 0, ACT_NONE, action,
                                     eps=eps, rng_ctl=None if eps is not None else self.rng_ctl, logp=logp,
-                                    w2_swz=_weight_shadow(getattr(self.actor, "optimizer", None), l2.weight))
+                                    w2_swz=_weight_shadow(getattr(self.actor, "optimizer", None), l2.weight), defer_rng_advance=defer)
+            if defer:
+                self.deferred_rng = (self.rng_ctl, n)
             return (xbuf if xbuf is not None else action), logp
         h = self.latent(obs, train_params, out_grad_is_dz=True)  # this head runs the latent net's last activation gradient
         grad = th.is_grad_enabled() and (h.requires_grad or train_params)

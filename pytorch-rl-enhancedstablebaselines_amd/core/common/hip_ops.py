@@ -89,7 +89,9 @@ def replay_add(ring: DeviceRing, obs, next_obs, act, rew, done, timeout):
 
 def collect_step(coef, integrator: str, ring: DeviceRing, env_obs, step_count, policy_out, squashed, act_low,
                  act_high, noise=None, reset_obs=None, pcg_state=None, reward_out=None, done_out=None, ep_return=None,
-                 ep_stats=None, static_init=None):
+                 ep_stats=None, static_init=None, rng_advance=None):
+    """`rng_advance` = (rng_ctl, count) or None: the Philox control block of the policy launch that produced `policy_out` with
+    `defer_rng_advance=True`; this launch's last workgroup advances its offset by `count` (cstr_collect_step_rng_f32)."""
     n, d, a = ring.n_envs, ring.obs_dim, ring.act_dim
     _chk(env_obs, "env_obs", (n, d), th.float32), _chk(step_count, "step_count", (n,), th.int32)
     _chk(policy_out, "policy_out", (n, a), th.float32)
@@ -108,10 +110,13 @@ def collect_step(coef, integrator: str, ring: DeviceRing, env_obs, step_count, p
         raise ValueError(f"act_low/act_high need {a} entries")
     lo = (C.c_float * a)(*[float(v) for v in act_low])
     hi = (C.c_float * a)(*[float(v) for v in act_high])
-    check(nv.lib().cstr_collect_step_f32(C.byref(coef), C.c_int(INTEGRATORS[integrator]), C.byref(ring.c), ptr(ring.ctl),
-                                         ptr(env_obs), ptr(step_count), ptr(policy_out), C.c_int(int(squashed)), lo, hi,
-                                         ptr(noise), ptr(reset_obs), ptr(pcg_state), ptr(static_init), ptr(reward_out), ptr(done_out),
-                                         ptr(ep_return), ptr(ep_stats), stream_ptr()), "cstr_collect_step_f32")
+    rng_ctl, rng_count = rng_advance if rng_advance is not None else (None, 0)
+    _opt(rng_ctl, "rng_ctl", (nv.RNG_CTL_WORDS,), th.int64)
+    check(nv.lib().cstr_collect_step_rng_f32(C.byref(coef), C.c_int(INTEGRATORS[integrator]), C.byref(ring.c), ptr(ring.ctl),
+                                             ptr(env_obs), ptr(step_count), ptr(policy_out), C.c_int(int(squashed)), lo, hi,
+                                             ptr(noise), ptr(reset_obs), ptr(pcg_state), ptr(static_init), ptr(reward_out), ptr(done_out),
+                                             ptr(ep_return), ptr(ep_stats), ptr(rng_ctl), C.c_uint64(int(rng_count)), stream_ptr()),
+          "cstr_collect_step_rng_f32")
 
 
 def mt19937_seed(mt_state, seed: int):
@@ -416,10 +421,13 @@ def policy_rows_supported(k0: int, h1: int, h2: int, n_out: int) -> bool:
             and n_out <= 2 * nv.MAX_HEAD_ACT)
 
 
-def policy_rows_fwd(x, w1, b1, w2, b2, w3, b3, act: int, head: int, out_act: int, action, eps=None, rng_ctl=None, logp=None, w2_swz=None):
+def policy_rows_fwd(x, w1, b1, w2, b2, w3, b3, act: int, head: int, out_act: int, action, eps=None, rng_ctl=None, logp=None, w2_swz=None,
+                    defer_rng_advance: bool = False):
     """A two-hidden-layer policy network + action head for all rows of x in ONE launch, inference only (cstr_policy_rows_fwd_f32).
     head 0: squashed-Gaussian sample (w3 [2A, H2]; noise from `eps` [M, A] or the Philox stream `rng_ctl`; optional `logp`);
-    head 1: deterministic out_act(h2 @ w3^T + b3). `action` [M, A] may be a column block of a wider row-major matrix."""
+    head 1: deterministic out_act(h2 @ w3^T + b3). `action` [M, A] may be a column block of a wider row-major matrix.
+    `defer_rng_advance`: the launch leaves the stream offset alone -- the caller advances it by M before the next consumer
+    (collect_step(..., rng_advance=(rng_ctl, M)) does it in the collect kernel's last-workgroup epilogue)."""
     m, k0 = x.shape
     h1, h2, n_out = w1.shape[0], w2.shape[0], w3.shape[0]
     a = n_out // 2 if head == 0 else n_out
@@ -431,7 +439,7 @@ def policy_rows_fwd(x, w1, b1, w2, b2, w3, b3, act: int, head: int, out_act: int
     stride = _rows(action, "action", m, a)
     if w2_swz is not None:
         _chk(w2_swz, "w2_swz", (swizzled_numel(h2, h1),), th.float32)
-    net = nv.PolicyMlp(k0, h1, h2, a, act, head, out_act, 0, w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), w3.data_ptr(),
+    net = nv.PolicyMlp(k0, h1, h2, a, act, head, out_act, 1 if (defer_rng_advance and rng_ctl is not None) else 0, w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), w3.data_ptr(),
                        b3.data_ptr(), None if w2_swz is None else w2_swz.data_ptr())
     check(nv.lib().cstr_policy_rows_fwd_f32(C.byref(net), ptr(x), C.c_int64(max(x.stride(0), k0)), ptr(eps), ptr(rng_ctl), ptr(action),
                                             C.c_int64(stride), ptr(logp), C.c_int64(m), stream_ptr()), "cstr_policy_rows_fwd_f32")

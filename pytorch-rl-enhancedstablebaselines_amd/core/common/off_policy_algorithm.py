@@ -58,6 +58,7 @@ class OffPolicyAlgorithm(BaseAlgorithm):
         self.train_freq = train_freq
         self.use_sde_at_warmup = use_sde_at_warmup
         self._graph_enabled, self._graph, self._graph_key = False, None, None
+        self._rng_advance = None  # (rng_ctl, rows) the next fused collect launch owes the rollout policy launch (SAC)
         self._graph_error: Optional[str] = None  # text of the exception that ended hipGraph replay (None = never failed)
         self._graph_replays = 0                  # iterations served by a captured graph / by eager launches (bench.py reports both)
         self._eager_iterations = 0
@@ -225,7 +226,7 @@ class OffPolicyAlgorithm(BaseAlgorithm):
         noise = None if self.action_noise is None else self.action_noise().contiguous()
         hip_ops.collect_step(env.coef, env.integrator, rb.ring, env.obs, env.step_count, pol, self._action_mode(False),
                              self.action_space.low, self.action_space.high, noise=noise, pcg_state=env.pcg_state, static_init=env.static_init, reward_out=env._rew, done_out=env._done,
-                             ep_return=self._ep_return, ep_stats=self._ep_stats)
+                             ep_return=self._ep_return, ep_stats=self._ep_stats, rng_advance=self._take_rng_advance())
         if hasattr(self.action_noise, "reset_done"):
             self.action_noise.reset_done(env._done)  # action_noise.reset(indices of finished envs), :596-599
         if vn is not None:
@@ -396,6 +397,10 @@ class OffPolicyAlgorithm(BaseAlgorithm):
         unscales it first); bit 1 = multi-agent behaviour (no scale/unscale round trip, no noise)."""
         return 0 if warmup else 1
 
+    def _take_rng_advance(self):
+        adv, self._rng_advance = self._rng_advance, None
+        return adv
+
     def _policy_out_device(self, obs: th.Tensor) -> th.Tensor:
         """Actor output for the fused collect kernel: squashed ([-1,1]) action, device tensor [N, A], no grad."""
         with th.no_grad():
@@ -529,7 +534,8 @@ class OffPolicyAlgorithm(BaseAlgorithm):
         with th.cuda.device(self.device):
             hip_ops.collect_step(env.coef, env.integrator, rb.ring, env.obs, env.step_count, pol, squashed,
                                  self.action_space.low, self.action_space.high, noise=noise, pcg_state=env.pcg_state, static_init=env.static_init,
-                                 reward_out=env._rew, done_out=env._done, ep_return=self._ep_return, ep_stats=self._ep_stats)
+                                 reward_out=env._rew, done_out=env._done, ep_return=self._ep_return, ep_stats=self._ep_stats,
+                                 rng_advance=self._take_rng_advance())
             if hasattr(action_noise, "reset_done"):
                 action_noise.reset_done(env._done)  # action_noise.reset(indices of finished envs), :596-599
             if vn is not None:

@@ -94,8 +94,11 @@ class SAC(OffPolicyAlgorithm):
     def _policy_out_device(self, obs: th.Tensor) -> th.Tensor:
         if not self.fused_learner:
             return super()._policy_out_device(obs)
+        fa = self._fast_actor
         with th.no_grad():
-            return self._fast_actor.action_log_prob(obs, train_params=False, want_logp=False)[0]
+            out = fa.action_log_prob(obs, train_params=False, want_logp=False, defer_rng=True)[0]
+        self._rng_advance, fa.deferred_rng = fa.deferred_rng, None  # the fused collect launch advances the Philox offset
+        return out
 
     def _create_aliases(self) -> None:
         self.actor = self.policy.actor

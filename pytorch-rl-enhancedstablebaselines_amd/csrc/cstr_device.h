@@ -64,13 +64,17 @@ __device__ __forceinline__ bool last_block_ticket(unsigned long long *ticket)
 }
 
 // ring_ctl = { pos, full, ticket, adds }: ReplayBuffer.add's epilogue (core/common/buffers.py:280-283)
-__device__ __forceinline__ void ring_advance_last_block(int64_t *ring_ctl, int64_t rows)
+// `rng_ctl` (may be NULL): a Philox stream control block whose offset this launch advances by `rng_advance` on behalf of the
+// policy launch in front of it (cstr_policy_mlp_t.reserved bit 0): one ticket for both control blocks.
+__device__ __forceinline__ void ring_advance_last_block(int64_t *ring_ctl, int64_t rows, uint64_t *rng_ctl = nullptr,
+                                                        uint64_t rng_advance = 0)
 {
     if (last_block_ticket(reinterpret_cast<unsigned long long *>(ring_ctl + 2)) && threadIdx.x == 0) {
         int64_t pos = ring_ctl[0] + 1;
         if (pos == rows) { ring_ctl[1] = 1; pos = 0; }
         ring_ctl[0] = pos;
         ring_ctl[3] += 1;
+        if (rng_ctl) rng_ctl[1] += rng_advance;
     }
 }
 #endif

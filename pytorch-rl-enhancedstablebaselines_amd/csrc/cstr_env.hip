@@ -379,7 +379,8 @@ __global__ void collect_step_kernel(const cstr_coef_t k, const cstr_ring_t ring,
                                     const float *__restrict__ policy_out, const int squashed, const ActBounds ab,
                                     const float *__restrict__ noise, const float *__restrict__ reset_obs,
                                     uint64_t *__restrict__ pcg, double *__restrict__ static_init, float *__restrict__ reward_out,
-                                    float *__restrict__ done_out, float *__restrict__ ep_return, double *__restrict__ ep_stats)
+                                    float *__restrict__ done_out, float *__restrict__ ep_return, double *__restrict__ ep_stats,
+                                    uint64_t *__restrict__ policy_rng_ctl, const uint64_t policy_rng_advance)
 {
     constexpr int A = Lay<L>::A;
     const int64_t n = ring.n_envs;
@@ -448,7 +449,7 @@ __global__ void collect_step_kernel(const cstr_coef_t k, const cstr_ring_t ring,
         }
         step_count[i] = st;
     }
-    ring_advance_last_block(ring_ctl, ring.rows);
+    ring_advance_last_block(ring_ctl, ring.rows, policy_rng_ctl, policy_rng_advance);
 }
 
 // ReplayBuffer.add: six row copies in one launch
@@ -565,6 +566,17 @@ extern "C" int cstr_collect_step_f32(const cstr_coef_t *coef, int integrator, co
                                      const float *reset_obs, uint64_t *pcg_state, double *static_init, float *reward_out,
                                      float *done_out, float *ep_return, double *ep_stats, cstr_stream_t stream)
 {
+    return cstr_collect_step_rng_f32(coef, integrator, ring, ring_ctl, env_obs, step_count, policy_out, squashed, act_low, act_high, noise,
+                                     reset_obs, pcg_state, static_init, reward_out, done_out, ep_return, ep_stats, nullptr, 0, stream);
+}
+
+extern "C" int cstr_collect_step_rng_f32(const cstr_coef_t *coef, int integrator, const cstr_ring_t *ring, int64_t *ring_ctl,
+                                         float *env_obs, int32_t *step_count, const float *policy_out, int squashed,
+                                         const float *act_low, const float *act_high, const float *noise,
+                                         const float *reset_obs, uint64_t *pcg_state, double *static_init, float *reward_out,
+                                         float *done_out, float *ep_return, double *ep_stats, uint64_t *policy_rng_ctl,
+                                         uint64_t policy_rng_advance, cstr_stream_t stream)
+{
     int rc = check_ring(ring);
     if (rc) return rc;
     if (!coef || !ring_ctl || !env_obs || !step_count || !policy_out || !act_low || !act_high) return CSTR_E_BADARG;
@@ -586,6 +598,6 @@ extern "C" int cstr_collect_step_f32(const cstr_coef_t *coef, int integrator, co
     int block, grid;
     env_launch_shape(ring->n_envs, block, grid);
     DISPATCH_L_INTEG(collect_step_kernel, *coef, *ring, ring_ctl, env_obs, step_count, policy_out, squashed, ab, noise, reset_obs,
-                     pcg_state, static_init, reward_out, done_out, ep_return, ep_stats);
+                     pcg_state, static_init, reward_out, done_out, ep_return, ep_stats, policy_rng_ctl, policy_rng_advance);
     return (int)hipGetLastError();
 }

@@ -9,6 +9,7 @@
 // All latency-bound at batch 256; 64-wide waves, LDS tree reductions, deterministic (no atomics).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/cstr_rl_hip.h"
 #include "cstr_device.h"
@@ -139,6 +140,18 @@ __device__ __forceinline__ float4 load_k4(const float *__restrict__ row, const i
     if (k + 1 < K) v.y = row[k + 1];
     if (k + 2 < K) v.z = row[k + 2];
     if (k + 3 < K) v.w = row[k + 3];
+    return v;
+}
+
+// The same values from an UNCONDITIONAL 16-byte load at a clamped address (VEC: K % 4 == 0, K >= 4), zeroed afterwards: hipcc
+// scalarises a float4 load under a condition into four branchy dword loads.
+template <bool VEC>
+__device__ __forceinline__ float4 load_k4_clamped(const float *__restrict__ row, const int k, const int K, const bool valid)
+{
+    if (!VEC) return load_k4<false>(row, k, K, valid);
+    float4 v = *reinterpret_cast<const float4 *>(row + min(k, K - 4));
+    const bool ok = valid && k < K;
+    v.x = ok ? v.x : 0.0f; v.y = ok ? v.y : 0.0f; v.z = ok ? v.z : 0.0f; v.w = ok ? v.w : 0.0f;
     return v;
 }
 
@@ -868,7 +881,7 @@ struct PolicyArgs {
     const float *w2, *b2; int h2;
     const float *w3, *b3; int act_dim, out_act;
     const float *eps_in; uint64_t *rng_ctl;
-    float *action; int64_t action_stride; float *logp; int64_t m; const float *w2s;
+    float *action; int64_t action_stride; float *logp; int64_t m; const float *w2s; int flags;
 };
 
 constexpr int POLICY_ROWS = 16, POLICY_WAVES = 8;
@@ -901,23 +914,23 @@ __device__ __forceinline__ bool last_block_ticket_tree(unsigned long long *top, 
 // 16-column tiles round robin, TWO per pass: every lane issues ALL of its loads for both tiles (up to 256 k values each) at
 // once (A = input rows, shared by the two tiles: global memory for the first layer, LDS after it; B = weight rows from L2), so
 // a layer of up to 16 x POLICY_WAVES columns costs one memory round trip.
-template <int ACT, bool A_GLOBAL, bool VEC, bool SWZ = false>
+template <int ACT, bool A_GLOBAL, bool VEC, bool SWZ = false, int UNROLL = 16>
 __device__ __forceinline__ void policy_layer(const float *__restrict__ in, const int64_t in_stride, const bool in_row_ok, const int K,
                                              const float *__restrict__ w, const float *__restrict__ bias, const int N,
-                                             float *__restrict__ out, const int so)
+                                             float *__restrict__ out, const int so, const int wave = threadIdx.x >> 6,
+                                             const int n_waves = POLICY_WAVES)
 {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, h = lane >> 4;
+    const int lane = threadIdx.x & 63, r = lane & 15, h = lane >> 4;
     const int tiles = (N + 15) >> 4;
     const float *ar = in + r * in_stride;
     const float4 *wsw = reinterpret_cast<const float4 *>(w);
     const int kc = (K + 15) >> 4;
-    for (int t = wave; t < tiles; t += 2 * POLICY_WAVES) {
-        const int n0 = t * 16, n1 = n0 + 16 * POLICY_WAVES;
+    for (int t = wave; t < tiles; t += 2 * n_waves) {
+        const int n0 = t * 16, n1 = n0 + 16 * n_waves;
         const bool ok0 = n0 + r < N, ok1 = n1 + r < N;
-        const bool second = t + POLICY_WAVES < tiles;  // wave-uniform
+        const bool second = t + n_waves < tiles;  // wave-uniform
         const float *wr0 = w + (int64_t)(n0 + r) * K, *wr1 = w + (int64_t)(n1 + r) * K;
         f32x4 c00 = {0.0f, 0.0f, 0.0f, 0.0f}, c01 = c00, c10 = c00, c11 = c00;
-        constexpr int UNROLL = 16;
         for (int c0 = 0; c0 < K; c0 += 16 * UNROLL) {
             float4 av[UNROLL], b0[UNROLL], b1[UNROLL];
 #pragma unroll
@@ -931,7 +944,7 @@ __device__ __forceinline__ void policy_layer(const float *__restrict__ in, const
             }
 #pragma unroll
             for (int u = 0; u < UNROLL; ++u)
-                b1[u] = SWZ ? ((second && c0 + 16 * u + 4 * h < K) ? wsw[((int64_t)(t + POLICY_WAVES) * kc + (c0 >> 4) + u) * 64 + lane]
+                b1[u] = SWZ ? ((second && c0 + 16 * u + 4 * h < K) ? wsw[((int64_t)(t + n_waves) * kc + (c0 >> 4) + u) * 64 + lane]
                                                                     : make_float4(0.0f, 0.0f, 0.0f, 0.0f))
                             : load_k4<VEC>(wr1, c0 + 16 * u + 4 * h, K, ok1 && second);
 #pragma unroll
@@ -1074,8 +1087,346 @@ __global__ __launch_bounds__(64 * POLICY_WAVES) void policy_rows_fwd_kernel(cons
             if (a.logp) a.logp[row] = lp - corr;
         }
     }
-    if (a.rng_ctl && last_block_ticket_tree(reinterpret_cast<unsigned long long *>(a.rng_ctl + 2),
-                                            reinterpret_cast<unsigned long long *>(a.rng_ctl + 4)) && tid == 0)
+    if (a.rng_ctl && !(a.flags & 1) && last_block_ticket_tree(reinterpret_cast<unsigned long long *>(a.rng_ctl + 2),
+                                                              reinterpret_cast<unsigned long long *>(a.rng_ctl + 4)) && tid == 0)
+        a.rng_ctl[1] = base + (uint64_t)a.m;
+}
+
+// ---- the same network, software-pipelined (needs the tile-major copy of W2; h1, h2 <= 512) ---------------------------------
+// What the first version leaves on the table at 4096 rows (r01: 17.8 us = 0.20 of the f32 matrix-core peak): per wave ALL of
+// layer 2's loads are issued, waited for, and only then do the 128 MFMAs run (no load / MFMA overlap); the head is 48 cross-lane
+// shuffles per wave followed by a ~1.5 k-instruction Philox / Box-Muller / tanh / log chain on 16 lanes of ONE wave while
+// the other seven idle; a 256-workgroup ticket closes the launch. Here:
+//   * layer 2 runs as a 2-stage register pipeline over K: stage s + 1's operands (4 k-chunks of 16: A from LDS, B = 1 KB full-
+//     line loads from the tile-major copy) are in flight while stage s's 32 MFMAs issue; stage 0 of B and the head's weights
+//     are requested BEFORE layer 1 (they do not depend on activations);
+//   * the Gaussian noise does not depend on the network either: wave 7 draws it (Philox + Box-Muller, a lane per row) while
+//     waves 0-6 compute layer 1, whose time is the latency of its observation / weight loads anyway;
+//   * the head is one 16 x 16 MFMA tile with K split over the 8 waves (2 k-chunks each at H2 = 256), partial sums combined in a
+//     fixed order from LDS, and the sampling tail runs on 16 x A lanes, a lane per (row, action);
+//   * bit 0 of cstr_policy_mlp_t.reserved: the caller advances the Philox offset (cstr_collect_step_f32 does it in its own
+//     last-workgroup epilogue), no 256-workgroup ticket at the end of this launch.
+// Layer 1 / layer 2 values are bit-identical to the first version (same k order, same accumulator assignment); the head's
+// summation order differs (split-K MFMA instead of per-lane partial dots + shuffle tree).
+constexpr int V2_CH = 4, V2_MAX_WIDTH = 512;
+
+#ifdef CSTR_POLICY_STAMPS  // diagnostic build only (make diag): s_memtime per wave at the phase boundaries, read by tools/policy_stamps.py
+__device__ unsigned long long policy_stamps[4096 * 16 * 8];
+#define V2_STAMP(i) do { if (lane == 0 && blockIdx.x < 4096) policy_stamps[(blockIdx.x * 16 + wave) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define V2_STAMP(i) do { } while (0)
+#endif
+
+// FULL: every chunk of the stage is inside K (all stages but the last): no checks between the MFMAs
+template <bool SECOND, bool FULL>
+__device__ __forceinline__ void v2_mfma_stage(const int c_begin, const int kc, const float4 (&av)[V2_CH], const float4 (&b0)[V2_CH],
+                                              const float4 (&b1)[V2_CH], f32x4 &c00, f32x4 &c01, f32x4 &c10, f32x4 &c11)
+{
+#pragma unroll
+    for (int u = 0; u < V2_CH; ++u) {
+        if (!FULL && c_begin + u >= kc) break;  // wave-uniform
+        c00 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u].x, b0[u].x, c00, 0, 0, 0);
+        if (SECOND) c10 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u].x, b1[u].x, c10, 0, 0, 0);
+        c01 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u].y, b0[u].y, c01, 0, 0, 0);
+        if (SECOND) c11 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u].y, b1[u].y, c11, 0, 0, 0);
+        c00 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u].z, b0[u].z, c00, 0, 0, 0);
+        if (SECOND) c10 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u].z, b1[u].z, c10, 0, 0, 0);
+        c01 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u].w, b0[u].w, c01, 0, 0, 0);
+        if (SECOND) c11 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u].w, b1[u].w, c11, 0, 0, 0);
+    }
+}
+
+template <int ACT, int HEAD, bool VEC0, bool K0_SMALL, bool SMALL>
+__global__ __launch_bounds__(64 * POLICY_WAVES) void policy_rows_v2_kernel(const PolicyArgs a)
+{
+    constexpr int WAVES = POLICY_WAVES, L1_WAVES = 4;
+    constexpr int MAXC = SMALL ? 16 : V2_MAX_WIDTH / 16;  // 16-wide k chunks / column tiles the instantiation is sized for (register budget)
+    constexpr int V2_HEAD_Q = MAXC / WAVES;     // head k chunks per wave
+    constexpr int L1_T = MAXC / L1_WAVES;       // layer-1 column tiles per layer-1 wave
+    constexpr int NB = SMALL ? 16 : V2_CH;      // B chunks per tile requested before the first barrier: ALL of K (SMALL) or stage 0
+    extern __shared__ float policy_lds[];
+    const int H1 = a.h1, H2 = a.h2, kc1 = (H1 + 15) >> 4, kc2 = (H2 + 15) >> 4, S1 = 16 * kc1 + 4, S2 = 16 * kc2 + 4;
+    float *h1s = policy_lds, *h2s = h1s + POLICY_ROWS * S1, *part = h2s + POLICY_ROWS * S2;  // part [8 waves][16 rows][8]
+    float *eps_s = part + WAVES * POLICY_ROWS * 8, *term = eps_s + POLICY_ROWS * 8;          // eps [16][8], terms [2][16][8]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, h = lane >> 4;
+    const int64_t m0 = (int64_t)blockIdx.x * POLICY_ROWS;
+    const bool draw = HEAD == 0 && a.rng_ctl != nullptr;
+    const uint64_t seed = a.rng_ctl ? a.rng_ctl[0] : 0ull, base = a.rng_ctl ? a.rng_ctl[1] : 0ull;
+    const int n_out = HEAD == 0 ? 2 * a.act_dim : a.act_dim;
+    const float4 *w2s = reinterpret_cast<const float4 *>(a.w2s);
+    const bool l1_wave = wave < L1_WAVES;
+    V2_STAMP(0);
+
+    // Roles before the first barrier. The CU's vector-memory path is ONE in-order queue that moves ~75 GB/s: layer 2's weights
+    // (256 KB per workgroup at 256 x 256) need ~3.4 us of it, as long as the layer's MFMAs, so the stream has to start at t = 0 and
+    // must not sit in front of layer 1's few small operand loads.
+    //   waves 4-7: request their layer-2 B operand at once -- ALL of it when it fits the register budget (SMALL: h1, h2 <= 256,
+    //              128 registers), else its first pipeline stage; wave 7 then draws the Gaussian noise (Philox + Box-Muller, a
+    //              lane per row, ~1.5 us of dependent VALU work that does not depend on the network).
+    //   waves 0-3: layer 1 first (operand loads at the head of the queue, one k chunk for k0 <= 16: lane (r, h) holds
+    //              x[row r][4h..4h+3] and W1[column tile row r][4h..4h+3]), THEN their own B requests.
+    // Every load is UNCONDITIONAL on a clamped (always valid) address: hipcc scalarises a float4 load under a condition into four
+    // branchy dword loads; out-of-range chunks are never fed to an MFMA, out-of-range head lanes are zeroed after the load.
+    float4 bq0[NB], bq1[NB], w3q[V2_HEAD_Q];
+    float b2q0, b2q1;
+    const int t0 = min(wave, kc2 - 1), t1 = min(wave + WAVES, kc2 - 1);
+    // L2 warm-up: a launch starts with its XCD's L2 cold, and every line of the weight copy is first touched by ONE of the XCD's
+    // 32 workgroups, whose wave then waits a fabric round trip in the middle of layer 2 (the slowest wave of a workgroup arrived
+    // ~1.3 us after the typical one). So each wave first touches one distinct 1 KB piece (8 lines, lanes 0-7; per XCD, under the
+    // observed round-robin placement, blocks b, b + 8, ... cover the whole copy; any other placement is only slower): the copy is
+    // in every L2 one fabric round trip after launch. The value is kept live to the end so that the load is not eliminated.
+    float warm = 0.0f;
+    {
+        const int pieces = kc2 * kc1, loader = (int)((blockIdx.x >> 3) & 31u) * WAVES + wave;
+        const float *wf = reinterpret_cast<const float *>(w2s);
+        for (int pc = loader; pc < pieces; pc += 32 * WAVES) warm += wf[(int64_t)pc * 256 + (lane & 7) * 32];
+    }
+#define V2_REQUEST_B(FROM, TO) do { _Pragma("unroll") for (int u = (FROM); u < (TO); ++u) { const int c = min(u, kc1 - 1); \
+        bq0[u] = w2s[((int64_t)t0 * kc1 + c) * 64 + lane]; bq1[u] = w2s[((int64_t)t1 * kc1 + c) * 64 + lane]; } } while (0)
+    // how many of the NB chunks are requested BEFORE the first barrier: a wave is held while it issues loads (~60 ns per 1 KB wave
+    // load), and everybody waits at the barrier for the last issuer -- the rest follows right after the barrier, before the MFMAs
+    constexpr int PRE_YOUNG = SMALL ? 12 : V2_CH, PRE_NOISE = SMALL ? 8 : V2_CH, PRE_OLD = V2_CH;
+    const bool noise_wave = draw && wave == WAVES - 1;
+    // zero the k padding of both activation images (widths that are not multiples of 16: the MFMA chunks read them)
+    {
+        const int p1 = 16 * kc1 - H1, p2 = 16 * kc2 - H2;
+        if (tid < POLICY_ROWS * p1) h1s[(tid / p1) * S1 + H1 + tid % p1] = 0.0f;
+        if (tid < POLICY_ROWS * p2) h2s[(tid / p2) * S2 + H2 + tid % p2] = 0.0f;
+    }
+    if (!l1_wave) {
+        V2_REQUEST_B(0, PRE_NOISE);
+        if (!noise_wave) V2_REQUEST_B(PRE_NOISE, PRE_YOUNG);
+        if (noise_wave) {
+            const int64_t row = m0 + lane;
+            if (lane < POLICY_ROWS && row < a.m) {
+                for (int j0 = 0; j0 < a.act_dim; j0 += 2) {
+                    const uint64_t ctr = base + (uint64_t)row;
+                    uint32_t rnd[4];
+                    float e0, e1;
+                    philox4x32_10((uint32_t)ctr, (uint32_t)(ctr >> 32), (uint32_t)(j0 >> 1), 0u, (uint32_t)seed, (uint32_t)(seed >> 32), rnd);
+                    box_muller(rnd[0], rnd[1], e0, e1);
+                    eps_s[lane * 8 + j0] = e0;
+                    if (j0 + 1 < a.act_dim) eps_s[lane * 8 + j0 + 1] = e1;
+                }
+            }
+            V2_STAMP(7);
+        }
+    } else if (K0_SMALL) {
+        float4 w1v[L1_T];
+        float b1v[L1_T];
+        const float4 xa = load_k4_clamped<VEC0>(a.x + min(m0 + r, a.m - 1) * a.ldx, 4 * h, a.k0, m0 + r < a.m);
+#pragma unroll
+        for (int i = 0; i < L1_T; ++i) {
+            const int n = 16 * (wave + L1_WAVES * i) + r;
+            w1v[i] = load_k4_clamped<VEC0>(a.w1 + (int64_t)min(n, H1 - 1) * a.k0, 4 * h, a.k0, n < H1);
+            b1v[i] = a.b1[min(n, H1 - 1)];
+        }
+        V2_REQUEST_B(0, PRE_OLD);
+#pragma unroll
+        for (int i = 0; i < L1_T; ++i) {
+            const int t = wave + L1_WAVES * i;
+            if (t >= kc1) break;  // wave-uniform
+            // the first version's accumulator assignment (elements x, z -> one chain, y, w -> the other): same bits
+            f32x4 c0 = {0.0f, 0.0f, 0.0f, 0.0f}, c1 = c0;
+            c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.x, w1v[i].x, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.y, w1v[i].y, c1, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.z, w1v[i].z, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.w, w1v[i].w, c1, 0, 0, 0);
+            const f32x4 acc = c0 + c1;
+            const int col = 16 * t + r;
+            if (col < H1) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = acc[e] + b1v[i];
+                    if (ACT == ACT_RELU) v = fmaxf(v, 0.0f);
+                    if (ACT == ACT_TANH) v = tanhf(v);
+                    h1s[(4 * h + e) * S1 + col] = v;
+                }
+            }
+        }
+    } else {
+        policy_layer<ACT, true, VEC0, false, 16>(a.x + m0 * a.ldx, a.ldx, m0 + r < a.m, a.k0, a.w1, a.b1, H1, h1s, S1, wave, L1_WAVES);
+        V2_REQUEST_B(0, PRE_OLD);
+    }
+    {   // needed last: the first tile pair's bias values and the head's rows
+        b2q0 = a.b2[min(16 * t0 + r, H2 - 1)];
+        b2q1 = a.b2[min(16 * t1 + r, H2 - 1)];
+        const float *w3r = a.w3 + (int64_t)min(r, n_out - 1) * H2;
+#pragma unroll
+        for (int q = 0; q < V2_HEAD_Q; ++q) w3q[q] = load_k4_clamped<true>(w3r, 16 * (wave + WAVES * q) + 4 * h, H2, r < n_out);
+    }
+    V2_STAMP(1);
+    __syncthreads();
+    V2_STAMP(2);
+    if (SMALL) {  // the rest of the wave's B operand
+        if (l1_wave) V2_REQUEST_B(PRE_OLD, NB);
+        else {
+            if (noise_wave) V2_REQUEST_B(PRE_NOISE, PRE_YOUNG);
+            V2_REQUEST_B(PRE_YOUNG, NB);
+        }
+    }
+#undef V2_REQUEST_B
+
+    // layer 2: tile pairs (t, t + 8); column = lane & 15, row = 4 * (lane >> 4) + register in the epilogue
+    const float *ar = h1s + r * S1 + 4 * h;
+#define V2_EPILOGUE(T, SECOND, FIRST) do { _Pragma("unroll") for (int half = 0; half < 2; ++half) { \
+            const int col = 16 * (half ? (T) + WAVES : (T)) + r; \
+            if ((half == 0 || (SECOND)) && col < H2) { \
+                const f32x4 acc = half ? c10 + c11 : c00 + c01; \
+                const float bb = (FIRST) ? (half ? b2q1 : b2q0) : a.b2[col]; \
+                _Pragma("unroll") for (int e = 0; e < 4; ++e) { \
+                    float v = acc[e] + bb; \
+                    if (ACT == ACT_RELU) v = fmaxf(v, 0.0f); \
+                    if (ACT == ACT_TANH) v = tanhf(v); \
+                    h2s[(4 * h + e) * S2 + col] = v; } } } } while (0)
+    if (SMALL) {
+        // the whole B operand of the wave's ONE tile pair is in registers or on its way; only the A operand (LDS) is staged, one
+        // stage ahead; the MFMAs of a stage wait (in-order vmcnt) for exactly the B chunks they consume
+        const int t = wave;
+        if (t < kc2) {
+            const bool second = t + WAVES < kc2;  // wave-uniform
+            f32x4 c00 = {0.0f, 0.0f, 0.0f, 0.0f}, c01 = c00, c10 = c00, c11 = c00;
+            float4 av[2][V2_CH];
+#pragma unroll
+            for (int u = 0; u < V2_CH; ++u) av[0][u] = *reinterpret_cast<const float4 *>(ar + 16 * min(u, kc1 - 1));
+#pragma unroll
+            for (int s = 0; s < 16 / V2_CH; ++s) {
+                if (s * V2_CH >= kc1) break;  // wave-uniform
+                if (s + 1 < 16 / V2_CH) {
+#pragma unroll
+                    for (int u = 0; u < V2_CH; ++u)
+                        av[(s + 1) & 1][u] = *reinterpret_cast<const float4 *>(ar + 16 * min((s + 1) * V2_CH + u, kc1 - 1));
+                }
+                float4 b0[V2_CH], b1[V2_CH];
+#pragma unroll
+                for (int u = 0; u < V2_CH; ++u) { b0[u] = bq0[(s * V2_CH + u) % NB]; b1[u] = bq1[(s * V2_CH + u) % NB]; }
+                if (second) v2_mfma_stage<true, false>(s * V2_CH, kc1, av[s & 1], b0, b1, c00, c01, c10, c11);
+                else v2_mfma_stage<false, false>(s * V2_CH, kc1, av[s & 1], b0, b1, c00, c01, c10, c11);
+            }
+            V2_EPILOGUE(t, second, true);
+        }
+    } else {
+        // K in stages of V2_CH chunks, two register sets: stage s + 1's operands in flight while stage s's MFMAs issue
+        const int nst = (kc1 + V2_CH - 1) / V2_CH;
+        for (int t = wave; t < kc2; t += 2 * WAVES) {
+            const bool second = t + WAVES < kc2;  // wave-uniform
+            const float4 *wb0 = w2s + (int64_t)t * kc1 * 64 + lane, *wb1 = w2s + (int64_t)(second ? t + WAVES : t) * kc1 * 64 + lane;
+            f32x4 c00 = {0.0f, 0.0f, 0.0f, 0.0f}, c01 = c00, c10 = c00, c11 = c00;
+            float4 aA[V2_CH], aB[V2_CH], b0A[V2_CH], b1A[V2_CH], b0B[V2_CH], b1B[V2_CH];
+#define V2_LOAD(S, AV, B0, B1) do { _Pragma("unroll") for (int u = 0; u < V2_CH; ++u) { const int c = min((S) * V2_CH + u, kc1 - 1); \
+                B0[u] = wb0[(int64_t)c * 64]; B1[u] = wb1[(int64_t)c * 64]; \
+                AV[u] = *reinterpret_cast<const float4 *>(ar + 16 * c); } } while (0)
+#define V2_MFMA(S, AV, B0, B1, FULL) do { if (second) v2_mfma_stage<true, FULL>((S) * V2_CH, kc1, AV, B0, B1, c00, c01, c10, c11); \
+                else v2_mfma_stage<false, FULL>((S) * V2_CH, kc1, AV, B0, B1, c00, c01, c10, c11); } while (0)
+            if (t == wave) {
+#pragma unroll
+                for (int u = 0; u < V2_CH; ++u) {
+                    b0A[u] = bq0[u % NB];
+                    b1A[u] = bq1[u % NB];
+                    aA[u] = *reinterpret_cast<const float4 *>(ar + 16 * min(u, kc1 - 1));
+                }
+            } else {
+                V2_LOAD(0, aA, b0A, b1A);
+            }
+            // Steady state WITHOUT a branch around any load: hipcc's s_waitcnt insertion merges the "loaded" and "not loaded" paths
+            // of a conditional prefetch and then waits for the NEW loads before the current stage's MFMAs (vmcnt(7), (5), (3), (1)
+            // in the first build of this loop: no overlap at all). Only the last stage can hold chunks beyond K.
+            int s = 0;
+            for (; s + 2 < nst; s += 2) {
+                V2_LOAD(s + 1, aB, b0B, b1B);
+                V2_MFMA(s, aA, b0A, b1A, true);
+                V2_LOAD(s + 2, aA, b0A, b1A);
+                V2_MFMA(s + 1, aB, b0B, b1B, true);
+            }
+            if (s + 1 < nst) {
+                V2_LOAD(s + 1, aB, b0B, b1B);
+                V2_MFMA(s, aA, b0A, b1A, true);
+                V2_MFMA(s + 1, aB, b0B, b1B, false);
+            } else {
+                V2_MFMA(s, aA, b0A, b1A, false);
+            }
+#undef V2_LOAD
+#undef V2_MFMA
+            V2_EPILOGUE(t, second, t == wave);
+        }
+    }
+#undef V2_EPILOGUE
+    V2_STAMP(3);
+    __syncthreads();
+    V2_STAMP(4);
+
+    // head: ONE 16 x 16 tile (rows x outputs, outputs >= n_out are zero columns), K split over the waves
+    {
+        f32x4 p0 = {0.0f, 0.0f, 0.0f, 0.0f}, p1 = p0;
+        const float *hr = h2s + r * S2 + 4 * h;
+#pragma unroll
+        for (int q = 0; q < V2_HEAD_Q; ++q) {
+            const int c = wave + WAVES * q;
+            if (c >= kc2) break;  // wave-uniform
+            const float4 av = *reinterpret_cast<const float4 *>(hr + 16 * c);
+            p0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, w3q[q].x, p0, 0, 0, 0);
+            p1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, w3q[q].y, p1, 0, 0, 0);
+            p0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, w3q[q].z, p0, 0, 0, 0);
+            p1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, w3q[q].w, p1, 0, 0, 0);
+        }
+        p0 += p1;
+        if (r < 8) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) part[(wave * POLICY_ROWS + 4 * h + e) * 8 + r] = p0[e];
+        }
+    }
+    __syncthreads();
+    V2_STAMP(5);
+
+    // tail: a lane per (row, output slot): thread = 8 * row + j
+    const int trow = tid >> 3, j = tid & 7;
+    const int64_t row = m0 + trow;
+    const bool live = tid < POLICY_ROWS * 8 && row < a.m;
+    auto head_out = [&](const int jj) {
+        float sum = 0.0f;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) sum += part[(w * POLICY_ROWS + trow) * 8 + jj];
+        return sum + a.b3[jj];
+    };
+    if (HEAD == 1) {
+        if (live && j < n_out) {
+            float v = head_out(j);
+            if (a.out_act == ACT_RELU) v = fmaxf(v, 0.0f);
+            if (a.out_act == ACT_TANH) v = tanhf(v);
+            a.action[row * a.action_stride + j] = v;
+        }
+    } else {
+        if (live && j < a.act_dim) {
+            const float half_log_2pi = 0.91893853320467274178f;
+            const float mu = head_out(j), raw = head_out(a.act_dim + j);
+            const float e = a.eps_in ? a.eps_in[row * a.act_dim + j] : eps_s[trow * 8 + j];
+            const float ls = fminf(fmaxf(raw, LOG_STD_MIN), LOG_STD_MAX);
+            const float sd = expf(ls);
+            const float u = mu + sd * e;
+            const float act = tanhf(u);
+            const float d = u - mu, var = sd * sd;
+            a.action[row * a.action_stride + j] = act;
+            if (a.logp) {
+                term[trow * 8 + j] = -(d * d) / (2.0f * var) - logf(sd) - half_log_2pi;
+                term[POLICY_ROWS * 8 + trow * 8 + j] = logf(1.0f - act * act + 1e-6f);
+            }
+        }
+        if (a.logp) {  // kernel-uniform
+            __syncthreads();
+            if (live && j == 0) {
+                float lp = 0.0f, corr = 0.0f;
+                for (int jj = 0; jj < a.act_dim; ++jj) {  // the reference's summation order over the action dimension
+                    lp += term[trow * 8 + jj];
+                    corr += term[POLICY_ROWS * 8 + trow * 8 + jj];
+                }
+                a.logp[row] = lp - corr;
+            }
+        }
+    }
+    V2_STAMP(6);
+    if (__builtin_isnan(warm) && a.m < 0) a.action[0] = warm;  // never true; keeps the warm-up load alive
+    if (a.rng_ctl && !(a.flags & 1) && last_block_ticket_tree(reinterpret_cast<unsigned long long *>(a.rng_ctl + 2),
+                                                              reinterpret_cast<unsigned long long *>(a.rng_ctl + 4)) && tid == 0)
         a.rng_ctl[1] = base + (uint64_t)a.m;
 }
 
@@ -1418,6 +1769,13 @@ extern "C" int cstr_gaussian_head_bwd_input_f32(const float *g_action, int64_t g
     return (int)hipGetLastError();
 }
 
+#ifdef CSTR_POLICY_STAMPS
+extern "C" int cstr_diag_policy_stamps(unsigned long long *host_out, int64_t words)
+{
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(policy_stamps), (size_t)words * 8);
+}
+#endif
+
 extern "C" int cstr_policy_swizzle_f32(const float *w, int64_t n, int64_t k, float *out, cstr_stream_t stream)
 {
     if (!w || !out || n <= 0 || k <= 0) return CSTR_E_BADARG;
@@ -1443,12 +1801,29 @@ extern "C" int cstr_policy_rows_fwd_f32(const cstr_policy_mlp_t *net, const floa
         lds > 64 * 1024 || !aligned16(n.w2) || !aligned16(n.w3) || (n.head == 0 ? 2 : 1) * n.act_dim > 2 * CSTR_MAX_HEAD_ACT ||
         (n.head == 0 && n.act_dim > CSTR_MAX_HEAD_ACT) || (m + POLICY_ROWS - 1) / POLICY_ROWS > 0x7fffffff)
         return CSTR_E_UNSUPPORTED;
+    if (n.reserved & ~1) return CSTR_E_BADARG;  // bit 0: the caller advances the Philox offset (no ticket in this launch)
     PolicyArgs a = {x, ldx, n.k0, n.w1, n.b1, n.h1, n.w2, n.b2, n.h2, n.w3, n.b3, n.act_dim, n.out_act, eps, rng_ctl,
-                    action, action_stride, logp, m, n.w2_swizzled};
+                    action, action_stride, logp, m, n.w2_swizzled, n.reserved};
     if (n.w2_swizzled && !aligned16(n.w2_swizzled)) return CSTR_E_BADARG;
     const unsigned grid = (unsigned)((m + POLICY_ROWS - 1) / POLICY_ROWS);
     const bool vec0 = (n.k0 & 3) == 0 && (ldx & 3) == 0 && aligned16(x) && aligned16(n.w1);
     hipStream_t s = (hipStream_t)stream;
+    static const bool force_v1 = getenv("CSTR_POLICY_V1") != nullptr;  // development A/B knob (tools/policy_ab.py)
+    if (n.w2_swizzled && n.h1 <= V2_MAX_WIDTH && n.h2 <= V2_MAX_WIDTH && !force_v1) {
+        // the software-pipelined kernel (tile-major W2 required)
+        const int kc1 = (n.h1 + 15) / 16, kc2 = (n.h2 + 15) / 16;
+        const size_t lds2 = (size_t)(POLICY_ROWS * (16 * kc1 + 4 + 16 * kc2 + 4) + POLICY_WAVES * POLICY_ROWS * 8 + 3 * POLICY_ROWS * 8) * sizeof(float);
+        const bool k0s = n.k0 <= 16, small = kc1 <= 16 && kc2 <= 16;
+#define POLV4(A, H, V, K) do { if (small) policy_rows_v2_kernel<A, H, V, K, true><<<grid, 64 * POLICY_WAVES, lds2, s>>>(a); \
+                               else policy_rows_v2_kernel<A, H, V, K, false><<<grid, 64 * POLICY_WAVES, lds2, s>>>(a); } while (0)
+#define POLV2(A, H) do { if (vec0) { if (k0s) POLV4(A, H, true, true); else POLV4(A, H, true, false); } \
+                         else { if (k0s) POLV4(A, H, false, true); else POLV4(A, H, false, false); } } while (0)
+        if (n.head == 0) { if (n.act == 0) POLV2(0, 0); else if (n.act == 1) POLV2(1, 0); else POLV2(2, 0); }
+        else { if (n.act == 0) POLV2(0, 1); else if (n.act == 1) POLV2(1, 1); else POLV2(2, 1); }
+#undef POLV2
+#undef POLV4
+        return (int)hipGetLastError();
+    }
 #define POL2(A, H) do { if (vec0) policy_rows_fwd_kernel<A, H, true><<<grid, 64 * POLICY_WAVES, lds, s>>>(a); \
                         else policy_rows_fwd_kernel<A, H, false><<<grid, 64 * POLICY_WAVES, lds, s>>>(a); } while (0)
 #define POL(A, H) POL2(A, H)
