@@ -222,7 +222,11 @@ class PackedBatch:
         e = lambda *s: th.zeros(*s, dtype=th.float32, device=device)  # noqa: E731
         w = obs_dim + act_dim
         self.obs_dim, self.act_dim = obs_dim, act_dim
-        self.x_data, self.x_next = e(batch_size, w), e(batch_size, w)
-        self.x_pi = e(batch_size, w) if with_pi else None
+        self.x_data = e(batch_size, w)
+        # x_pi and x_next are the two halves of ONE [2B, W] buffer: SAC evaluates pi(obs) and pi(next_obs) in one 2B-row actor
+        # pass (fused._ActorPairFn) that reads the observation columns and writes the action columns with one row stride
+        self.x_pn = e(2 * batch_size, w) if with_pi else None
+        self.x_next = self.x_pn[batch_size:] if with_pi else e(batch_size, w)
+        self.x_pi = self.x_pn[:batch_size] if with_pi else None
         self.samples = ReplayBufferSamples(self.x_data[:, :obs_dim], self.x_data[:, obs_dim:], self.x_next[:, :obs_dim],
                                            e(batch_size, 1), e(batch_size, 1))

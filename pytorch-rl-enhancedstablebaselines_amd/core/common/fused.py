@@ -482,6 +482,31 @@ class FastSacActor:
                 and l1.weight.is_contiguous() and l2.weight.is_contiguous() and l2.weight.data_ptr() % 16 == 0
                 and self._hw.is_contiguous() and self._hw.data_ptr() % 16 == 0)
 
+    def pair_supported(self, pb) -> bool:
+        """`action_log_prob_pair` applies: fused Linear kernels, two hidden layers with one activation, merged head, a packed
+        batch whose x_pi / x_next are the halves of one buffer, and zero or two teacher-forced noise tensors queued."""
+        layers = self.latent.layers
+        q = self.actor.action_dist.eps_queue
+        return (USE_FUSED_LINEAR and self.head is not None and self.act_dim <= hip_ops.nv.MAX_HEAD_ACT and len(layers) == 2
+                and layers[0][1] == layers[1][1] and getattr(pb, "x_pn", None) is not None and 2 * pb.x_pi.shape[0] <= 1024
+                and layers[1][0].out_features % 4 == 0 and len(q) in (0, 2) and self._hw.is_contiguous()
+                and all(lin.weight.grad is not None and lin.bias.grad is not None for lin, _ in layers))
+
+    def action_log_prob_pair(self, pb):
+        """(x_pi, log pi(a|obs)) with gradients and (x_next, log pi(a'|next_obs)) without, from ONE 2B-row pass (_ActorPairFn)."""
+        dist = self.actor.action_dist
+        b, a = pb.x_pi.shape[0], self.act_dim
+        eps2 = None
+        if dist.eps_queue:  # teacher-forced draws (tests): the pi(obs) tensor was queued first
+            eps2 = th.cat((dist.draw_eps((b, a), pb.x_pn.device), dist.draw_eps((b, a), pb.x_pn.device)), dim=0).contiguous()
+        elif self.rng_ctl is None:
+            self.rng_ctl = hip_ops.new_rng_ctl(th.initial_seed(), pb.x_pn.device)
+        (l1, act), (l2, _) = self.latent.layers
+        grads = (l1.weight.grad, l1.bias.grad, l2.weight.grad, l2.bias.grad, self._hwg, self._hbg)
+        x2 = pb.x_pn[:, :pb.obs_dim]
+        return _ActorPairFn.apply(x2, l1.weight, l1.bias, l2.weight, l2.bias, self._hw, self._hb, grads, act, eps2, self.rng_ctl,
+                                  pb.x_pi.detach(), pb.x_next.detach(), True, l1.weight, l2.weight, self.mu.weight, self.log_std.weight)
+
     def dist_params(self, obs: th.Tensor, train_params: bool = True) -> th.Tensor:
         """[B, 2A] = [mean | log_std_raw]"""
         h = self.latent(obs, train_params)
@@ -614,6 +639,59 @@ class _GaussianHeadFn(th.autograd.Function):
             th.mm(g_params.t(), h, out=ctx.wg)
         dx = _input_grad(g_params, w, h, ctx.below) if ctx.needs_input_grad[0] else None
         return (dx,) + (None,) * (10 + ctx.n_owners)
+
+
+class _ActorPairFn(th.autograd.Function):
+    """SAC's two actor passes of a gradient step -- pi(obs) with gradients (core/sac/sac.py:222) and pi(next_obs) without (:247) --
+    as ONE pass over 2B rows: rows [0, B) = obs, rows [B, 2B) = next_obs of one row-strided input, three forward launches instead
+    of six. Only the first B rows are kept for the backward, which is the chain's usual three launches on B rows (head backward
+    carried through its Linear, layer 2's input gradient, the deferred dW / db launch). The Philox stream positions are those
+    of the two separate launches (counter = offset + row, obs rows first). Two hidden layers + the merged head only."""
+
+    @staticmethod
+    def forward(ctx, x2, w1, b1, w2, b2, hw, hb, grads, act: int, eps2, rng_ctl, xbuf_pi, xbuf_next, train_params: bool, *owners):
+        n2, a = x2.shape[0], hw.shape[0] // 2
+        n = n2 // 2
+        h1 = hip_ops.linear_act_fwd(x2, w1, b1, act)
+        h2 = hip_ops.linear_act_fwd(h1, w2, b2, act)
+        params = th.empty(n2, 2 * a, dtype=h2.dtype, device=h2.device)
+        logp = th.empty(n2, dtype=h2.dtype, device=h2.device)
+        if eps2 is None:
+            eps2 = th.empty(n2, a, dtype=h2.dtype, device=h2.device)
+        else:
+            rng_ctl = None
+        d = xbuf_pi.shape[1] - a
+        # xbuf_pi / xbuf_next are the two halves of ONE [2B, D + A] buffer (PackedBatch.x_pn): one action pointer, one row stride
+        action2 = th.as_strided(xbuf_pi, (n2, a), (xbuf_pi.stride(0), 1), xbuf_pi.storage_offset() + d)
+        hip_ops.gaussian_head_gemm_fwd(h2, hw, hb, params, eps2, rng_ctl, action2, logp)
+        ctx.train_params, ctx.grads, ctx.act, ctx.a, ctx.n_owners = train_params, grads, act, a, len(owners)
+        ctx.save_for_backward(x2[:n], h1[:n], h2[:n], params[:n], eps2[:n], w2, hw)
+        ctx.action = xbuf_pi.detach()[:, d:]
+        ctx.set_materialize_grads(False)
+        ctx.mark_dirty(xbuf_pi, xbuf_next)
+        lp_pi, lp_next = logp[:n], logp[n:]
+        ctx.mark_non_differentiable(xbuf_next, lp_next)
+        return xbuf_pi, lp_pi, xbuf_next, lp_next
+
+    @staticmethod
+    def backward(ctx, g_x, g_logp, _gxn=None, _glpn=None):
+        x, h1, h2, params, eps, w2, hw = ctx.saved_tensors
+        g_action = None
+        if g_x is not None:
+            if g_x.stride(1) != 1:
+                g_x = g_x.contiguous()
+            g_action = g_x[:, g_x.shape[1] - ctx.a:]
+        g_logp = None if g_logp is None else g_logp.contiguous()
+        g_params = th.empty_like(params)
+        dz2 = th.empty(h2.shape[0], hw.shape[1], dtype=h2.dtype, device=h2.device)
+        hip_ops.gaussian_head_bwd_input(g_action, g_logp, ctx.action, params, eps, hw, h2, ctx.act, g_params, dz2)
+        dz1 = hip_ops.linear_bwd_input(dz2, w2, h1, ctx.act)
+        if ctx.train_params:
+            w1g, b1g, w2g, b2g, hwg, hbg = ctx.grads
+            _weight_grad(g_params, h2, hwg, hbg)
+            _weight_grad(dz2, h1, w2g, b2g)
+            _weight_grad(dz1, x, w1g, b1g)
+        return (None,) * (14 + ctx.n_owners)
 
 
 class QOut(tuple):
