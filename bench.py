@@ -62,8 +62,9 @@ def parse():
     ap.add_argument("--obs-dim", type=int, default=4, choices=[4, 8])
     ap.add_argument("--integrator", default="euler", choices=["euler", "rk4"])
     ap.add_argument("--graph", type=int, default=int(os.environ.get("CSTR_BENCH_GRAPH", "1")))
-    ap.add_argument("--graph-unroll", type=int, default=int(os.environ.get("CSTR_GRAPH_UNROLL", "1")),
-                    help="iterations recorded per hipGraph (the inter-graph launch gap is paid once per replay)")
+    ap.add_argument("--graph-unroll", type=int, default=int(os.environ.get("CSTR_GRAPH_UNROLL", "4")),
+                    help="iterations recorded per hipGraph on one GPU: the ~9 us the GPU idles between two graph launches "
+                         "(tools/graph_timeline.sh) is paid once per replay; the same launches in the same order")
     ap.add_argument("--blas", default=os.environ.get("CSTR_BLAS", "rocblas"), choices=["rocblas", "hipblaslt", "default"])
     ap.add_argument("--tunable", type=int, default=int(os.environ.get("CSTR_BENCH_TUNABLE", "0")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -459,17 +460,21 @@ def main():
     # (3 side-stream iterations + the capture per phase; TD3 / MADDPG have two phases) keep warming up, untimed and reported
     prewarm = 0
     if use_graph:
-        want = 2 if args.algo in ("td3", "maddpg") else 1
-        while model._graph_enabled and len(model._graph or {}) < want and prewarm < 64:
-            run_steps(1)
-            prewarm += 1
-        for _ in range(2):
-            run_steps(want)
-            prewarm += want
+        # every graph the timed region can need: `unroll`-iteration graphs (one per policy-delay phase) and, when K is not a multiple
+        # of the unroll factor, the single-iteration ones for the tail -- run both call shapes until a whole call replays
+        u = model.graph_unroll if world == 1 else 1
+        for k in ([2 * u] if args.steps % u == 0 else [2 * u, 2 * u + args.steps % u]):
+            for _ in range(40):
+                before = model.graph_status()["eager_iterations"]
+                run_steps(k)
+                prewarm += k
+                if not model._graph_enabled or model.graph_status()["eager_iterations"] == before:
+                    break
     st0 = model.graph_status()
     barrier()
     t0 = time.perf_counter()
     run_steps(args.steps)
+    host_dt = time.perf_counter() - t0  # host time to ENQUEUE the K steps (before the closing synchronize): ~ ms_per_step means host-bound
     barrier()
     dt = agreed_max(time.perf_counter() - t0)
     # a K-step region shorter than MIN_TIMED_S is repeated in whole multiples of K until the total reaches it (every rank sees
@@ -512,6 +517,7 @@ def main():
         "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic", "rccl_world": rccl_world, "allreduce_checksum": checksum,
         "weights_identical_across_ranks": weights_identical, "graph_collectives": st1["graph_collectives"],
+        "host_enqueue_ms_per_step": round(1e3 * host_dt / args.steps, 4),
         "timed_steps_total": timed_steps, "timed_repeats": repeats, "timed_seconds_total": round(dt * repeats, 4),
         "graph_prewarm_steps": prewarm, "hip_graph_active": st1["active"], "hip_graph_replays_in_timed_region": graph_replays,
         "eager_iterations_in_timed_region": eager_in_timed, "hip_graph_error": st1["error"],

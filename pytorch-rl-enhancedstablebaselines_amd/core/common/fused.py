@@ -34,6 +34,9 @@ WHOLE_NET_MIN_ROWS = 1024
 # + epilogue pair: measured on MI355X (tools/linear_probe.py) for every K at batch-sized M and for narrow inputs (K <= 32) at
 # any M; the 4096-row x 256 x 256 layers of the collect-time actor stay on rocBLAS. CSTR_FUSED_LINEAR=0 turns it off.
 USE_FUSED_LINEAR = os.environ.get("CSTR_FUSED_LINEAR", "1") != "0"
+# development A/B knobs: the 2B-row actor pass (_ActorPairFn) and the four-network critic / target chain (_TwinPairFn)
+USE_ACTOR_PAIR = os.environ.get("CSTR_ACTOR_PAIR", "1") != "0"
+USE_TWIN_PAIR = os.environ.get("CSTR_TWIN_PAIR", "1") != "0"
 
 
 def _fused_linear_ok(x: th.Tensor) -> bool:
@@ -389,6 +392,23 @@ def stacked_linear(x, weight, bias, wgrad, bgrad, act: int, train_params: bool, 
                                   *(owners if train_params else ()))
 
 
+_ZERO_BIAS: dict = {}
+
+
+def _hidden_gemm(x: th.Tensor, w1: th.Tensor) -> th.Tensor:
+    """z = x @ w1^T of a Q network's last hidden layer (its bias + activation ride in the head kernel): at batch size the f32-MFMA
+    Linear kernel with a zero bias (x . w + 0 is exact) instead of the rocBLAS batched GEMM -- same launch count, no Tensile
+    dispatch gap behind it (tools/graph_timeline.sh: 6.7 us start-to-next-start for the 4.6 us Cijk kernel)."""
+    if _fused_linear_ok(x):
+        n = w1.shape[-2]
+        key = (w1.shape[0] if w1.dim() == 3 else 0, n, x.device)
+        zb = _ZERO_BIAS.get(key)
+        if zb is None:
+            zb = _ZERO_BIAS[key] = th.zeros((key[0], n) if key[0] else (n,), dtype=x.dtype, device=x.device)
+        return hip_ops.linear_act_fwd(x, w1, zb, ACT_NONE)
+    return th.bmm(x, w1.transpose(1, 2)) if x.dim() == 3 else th.mm(x, w1.t())
+
+
 class _HiddenHeadFn(th.autograd.Function):
     """q = Linear_2(act(Linear_1(x))) with out_features(Linear_2) == 1, plain ([M, K]) or stacked ([G, M, K]) operands.
     w1 [.., N, K], b1 [.., N], w2 [.., 1, N], b2 [.., 1] and their gradient views (None when frozen)."""
@@ -396,7 +416,7 @@ class _HiddenHeadFn(th.autograd.Function):
     @staticmethod
     def forward(ctx, x, w1, b1, w2, b2, grads, act: int, train_params: bool, below, *owners):
         batched = x.dim() == 3
-        z = th.bmm(x, w1.transpose(1, 2)) if batched else th.mm(x, w1.t())
+        z = _hidden_gemm(x, w1)
         q = th.empty(*z.shape[:-1], 1, dtype=z.dtype, device=z.device)
         hip_ops.hidden_head_fwd_(z, b1, act, w2, b2, q)  # z now holds y = act(z + b1)
         ctx.act, ctx.train_params, ctx.batched, ctx.grads, ctx.n_owners = act, train_params, batched, grads, len(owners)
@@ -425,7 +445,7 @@ def hidden_head(x, w1, b1, w2, b2, grads, act: int, train_params: bool, owners=(
     if th.is_grad_enabled() and (x.requires_grad or train_params):
         return _HiddenHeadFn.apply(x, w1, b1, w2, b2, grads, act, train_params, below if x.requires_grad else None,
                                    *(owners if train_params else ()))
-    z = th.bmm(x, w1.transpose(1, 2)) if x.dim() == 3 else th.mm(x, w1.t())
+    z = _hidden_gemm(x, w1)
     q = th.empty(*z.shape[:-1], 1, dtype=z.dtype, device=z.device)
     return hip_ops.hidden_head_fwd_(z, b1, act, w2, b2, q)
 
@@ -487,7 +507,7 @@ class FastSacActor:
         batch whose x_pi / x_next are the halves of one buffer, and zero or two teacher-forced noise tensors queued."""
         layers = self.latent.layers
         q = self.actor.action_dist.eps_queue
-        return (USE_FUSED_LINEAR and self.head is not None and self.act_dim <= hip_ops.nv.MAX_HEAD_ACT and len(layers) == 2
+        return (USE_FUSED_LINEAR and USE_ACTOR_PAIR and self.head is not None and self.act_dim <= hip_ops.nv.MAX_HEAD_ACT and len(layers) == 2
                 and layers[0][1] == layers[1][1] and getattr(pb, "x_pn", None) is not None and 2 * pb.x_pi.shape[0] <= 1024
                 and layers[1][0].out_features % 4 == 0 and len(q) in (0, 2) and self._hw.is_contiguous()
                 and all(lin.weight.grad is not None and lin.bias.grad is not None for lin, _ in layers))
@@ -694,6 +714,43 @@ class _ActorPairFn(th.autograd.Function):
         return (None,) * (14 + ctx.n_owners)
 
 
+class _TwinPairFn(th.autograd.Function):
+    """The two critic passes in front of the critic loss -- Q_k(obs, act) with gradients (core/sac/sac.py:258, core/td3/td3.py:179)
+    and Q_k^target(next_obs, a') without (:250, :173) -- as ONE chain over four networks: they are independent until the loss, so
+    every layer is one pointer-table launch (cstr_linear_act_fwd_sets_f32: sets 0, 1 = the critic's networks on x_data, sets 2, 3 =
+    the target's on x_next) -- three launches instead of six. Only the critic's half is kept for the backward, which is the stacked
+    chain's usual launches. Networks = Linear-act-Linear-act-Linear(., 1), twin."""
+
+    @staticmethod
+    def forward(ctx, x_data, x_next, cs, ts, grads, act: int, *owners):
+        (w1, b1), (w2, b2), (w3, b3) = cs
+        (tw1, tb1), (tw2, tb2), (tw3, tb3) = ts
+        m, n1, n2 = x_data.shape[0], w1.shape[1], w2.shape[1]
+        e = lambda *sh: th.empty(*sh, dtype=x_data.dtype, device=x_data.device)  # noqa: E731
+        h1, y2, q = e(4, m, n1), e(4, m, n2), e(4, m, 1)
+        xs = (x_data, x_data, x_next, x_next)
+        hip_ops.linear_act_fwd_sets([(xs[g], (w1, tw1)[g >> 1][g & 1], (b1, tb1)[g >> 1][g & 1], h1[g]) for g in range(4)], act)
+        hip_ops.linear_act_fwd_sets([(h1[g], (w2, tw2)[g >> 1][g & 1], (b2, tb2)[g >> 1][g & 1], y2[g]) for g in range(4)], act)
+        hip_ops.linear_act_fwd_sets([(y2[g], (w3, tw3)[g >> 1][g & 1], (b3, tb3)[g >> 1][g & 1], q[g]) for g in range(4)], ACT_NONE)
+        ctx.act, ctx.grads, ctx.n_owners = act, grads, len(owners)
+        ctx.save_for_backward(x_data, h1[:2], w2, y2[:2], w3)
+        ctx.set_materialize_grads(False)  # no zero-fill launch for the (undefined) gradient of the target's output
+        q_c, q_t = q[:2], q[2:]
+        ctx.mark_non_differentiable(q_t)
+        return q_c, q_t
+
+    @staticmethod
+    def backward(ctx, gq, _gt=None):
+        x, h1, w2, y2, w3 = ctx.saved_tensors
+        (gw1, gb1), (gw2, gb2), (gw3, gb3) = ctx.grads
+        dz2 = th.empty_like(y2)
+        hip_ops.hidden_head_bwd(gq.contiguous(), y2, ctx.act, w3, dz2, gb2, gw3, gb3)
+        _weight_grad(dz2, h1, gw2, None)  # gb2 came out of the head kernel
+        dz1 = hip_ops.linear_bwd_input(dz2, w2, h1, ctx.act)
+        _weight_grad(dz1, x, gw1, gb1)
+        return (None,) * (6 + ctx.n_owners)
+
+
 class QOut(tuple):
     """Tuple of per-network Q tensors; `.stacked` is the [G, B, 1] batched-GEMM output they are views of (or None):
     backward from the stacked tensor directly (one root) instead of through G select nodes."""
@@ -753,6 +810,26 @@ class FastTwinCritic:
         out = QOut(h[i] for i in range(g))
         out.stacked = h
         return out
+
+
+def twin_pair_supported(critic: "FastTwinCritic", target: "FastTwinCritic") -> bool:
+    """`twin_pair_forward` applies: fused Linear kernels, both stacks present, two Q networks of Linear-act-Linear-act-Linear(., 1)."""
+    cs, ts = critic.stack, target.stack
+    return (USE_FUSED_LINEAR and USE_TWIN_PAIR and cs is not None and ts is not None and len(cs) == 3 and len(ts) == 3 and cs[0][0].shape[0] == 2
+            and ts[0][0].shape[0] == 2 and cs[-1][0].shape[1] == 1 and critic.acts[-1] == ACT_NONE and critic.acts[0] == critic.acts[1]
+            and all(wg is not None and bg is not None for _, wg, _, bg in cs) and 4 <= hip_ops.nv.MAX_LINEAR_SETS)
+
+
+def twin_pair_forward(critic: "FastTwinCritic", target: "FastTwinCritic", x_data: th.Tensor, x_next: th.Tensor):
+    """(QOut of the critic on x_data, with gradients; (q1_target, q2_target) on x_next, without) from ONE four-network chain."""
+    cs = [(w, b) for w, _, b, _ in critic.stack]
+    ts = [(w.detach(), b.detach()) for w, _, b, _ in target.stack]
+    grads = [(wg, bg) for _, wg, _, bg in critic.stack]
+    owners = [p for layer in critic.owners for p in layer]
+    q_c, q_t = _TwinPairFn.apply(x_data, x_next.detach(), cs, ts, grads, critic.acts[0], *owners)
+    out = QOut(q_c[i] for i in range(2))
+    out.stacked = q_c
+    return out, (q_t[0], q_t[1])
 
 
 def twin_groups(q_networks) -> list:

@@ -195,16 +195,19 @@ class SAC(OffPolicyAlgorithm):
         # coefficient's loss (ent_coef = exp(log_ent_coef) BEFORE the update, :230; the updated value is first used by the
         # next gradient step, so its optimiser step may wait for the critic's all-reduce: one collective instead of two),
         # the TD target (:245-254) and the critic loss (:258-261)
+        twin_pair = pb is not None and fused.twin_pair_supported(self._fast_critic, self._fast_critic_target)
         with th.no_grad():
-            if pair:
-                q1_t, q2_t = self._fast_critic_target.forward_input(x_next, train_params=False)
-            elif pb is not None:
+            if not pair and pb is not None:
                 x_next, next_log_prob = self._fast_actor.action_log_prob(rd.next_observations, train_params=False, xbuf=pb.x_next)
-                q1_t, q2_t = self._fast_critic_target.forward_input(x_next, train_params=False)
-            else:
+            if pb is None:
                 next_actions, next_log_prob = self._fast_actor.action_log_prob(rd.next_observations, train_params=False)
                 q1_t, q2_t = self._fast_critic_target(rd.next_observations, next_actions, train_params=False)
-        qs = self._fast_critic.forward_input(pb.x_data) if pb is not None else self._fast_critic(rd.observations, rd.actions)  # :258
+            elif not twin_pair:
+                q1_t, q2_t = self._fast_critic_target.forward_input(x_next, train_params=False)
+        if twin_pair:  # :258 and :250 as ONE four-network chain (three launches instead of six)
+            qs, (q1_t, q2_t) = fused.twin_pair_forward(self._fast_critic, self._fast_critic_target, pb.x_data, x_next)
+        else:
+            qs = self._fast_critic.forward_input(pb.x_data) if pb is not None else self._fast_critic(rd.observations, rd.actions)  # :258
         q1, q2 = qs
         if self.ent_coef_optimizer is not None:
             ent_coef = s["ent_coef"] if single else self._ent_coef_buf

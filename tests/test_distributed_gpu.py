@@ -160,3 +160,67 @@ def test_graph_collectives_trial_survives_a_failed_capture(tmp_path):
     assert out["ok"] is False and out["capturing"] is False
     assert out["calls"] == [False, True, False]  # warm-up, the captured attempt, the "captured" verdict; no replay verdict
     assert th.equal(out["x"], th.arange(8, dtype=th.float32))
+
+
+def _full_shape_worker(rank, world, port, out_dir, use_graph):
+    import sys
+
+    import numpy as np
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    root = os.path.dirname(here)
+    for p in (root, os.path.join(root, "pytorch-rl-enhancedstablebaselines_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from core.common import distributed as du
+    from core.common import legacy_rng
+    from core.common.vec_env import CSTRVecEnv
+    from core.sac import SAC
+
+    du.init_from_env(backend="gloo")
+    N, B, seed, iters = 4096, 256, 21, 50
+    env = CSTRVecEnv(N, device="cuda:0")
+    model = SAC("MlpPolicy", env, seed=seed, device="cuda:0")  # class defaults: nets [256, 256], ring 244 x 4096, batch 256
+    assert model.world_size == world and env.seed_offset == rank * N and model.replay_buffer.buffer_size == 244
+    model.enable_graph_capture(use_graph)
+    model.learn(N * iters)
+    th.cuda.synchronize()
+    pcg0 = env.pcg_state.cpu().clone()  # per-env reset generators after the seeded first reset (no auto-reset yet at 50 steps)
+    st = model.graph_status()
+    if use_graph:
+        assert st["active"] and st["graph_collectives"] == "segmented" and st["segments_per_graph"] == [3] and st["error"] is None
+    # this rank's sampler stream against numpy's: seed_r + N - 1 with seed_r = seed + rank * N, one randint pair per step
+    rs = np.random.RandomState(seed + rank * N + N - 1)
+    for k in range(1, iters + 1):
+        rs.randint(0, min(k, 244), size=B)
+        rs.randint(0, N, size=B)
+    want, got = rs.get_state(), legacy_rng.global_stream(model.device).cpu().numpy().view(np.uint32)
+    assert np.array_equal(got[:624], want[1]) and int(got[624]) == want[2], "sampler stream differs from numpy's"
+    th.save(dict(actor=model.policy.actor_arena.flat.cpu(), critic=model.policy.critic_arena.flat.cpu(),
+                 target=model.policy.critic_target_arena.flat.cpu(), alpha=model.log_ent_coef.detach().cpu(), obs=env.obs.cpu(),
+                 n_updates=model._n_updates, ring_obs0=model.replay_buffer.observations[0].cpu(), pcg0=pcg0,
+                 sampler_seed=legacy_rng.last_seed(model.device)), os.path.join(out_dir, f"full_r{rank}_{int(use_graph)}.pt"))
+    th.distributed.barrier()
+    th.distributed.destroy_process_group()
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_two_ranks_at_config4_per_rank_shape(tmp_path, use_graph):
+    """BASELINE config 4's PER-RANK shape (SAC class defaults, 4096 envs, ring 244 x 4096, batch 256) on two data-parallel ranks
+    sharing this box's one MI355X (gloo transport; RCCL refuses two ranks on one device), 50 iterations, eager and captured
+    (graph | all-reduce | graph | all-reduce | graph): weights bit-identical across ranks, every rank's MT19937 stream equal to
+    numpy's for seed + r N + N - 1 (checked inside the rank), env shards and reset streams disjoint. This is as far as the 8-GPU
+    path can be verified without the 8-GPU node: the 1 -> 8 scaling curve itself is the driver's measurement."""
+    world, port = 2, _free_port()
+    mp.spawn(_full_shape_worker, args=(world, port, str(tmp_path), use_graph), nprocs=world, join=True)
+    r0, r1 = (th.load(tmp_path / f"full_r{r}_{int(use_graph)}.pt") for r in range(world))
+    assert r0["n_updates"] == r1["n_updates"] == 50
+    for k in ("actor", "critic", "target", "alpha"):
+        assert th.equal(r0[k], r1[k]), k
+    assert not th.equal(r0["obs"], r1["obs"]) and not th.equal(r0["ring_obs0"], r1["ring_obs0"])
+    assert r0["sampler_seed"] == 21 + 4096 - 1 and r1["sampler_seed"] == 21 + 4096 + 4096 - 1
+    import numpy as np
+
+    both = np.concatenate([r0["pcg0"].numpy(), r1["pcg0"].numpy()])  # per-env reset generators seeded seed_r + i: all 8192 streams distinct
+    assert len({tuple(row) for row in both.tolist()}) == 2 * 4096
