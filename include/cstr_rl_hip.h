@@ -414,6 +414,28 @@ int cstr_td_twin_q_loss_f32(const float *q1_t, const float *q2_t, const float *n
                             float *gq1, float *gq2, float *loss_out, float *loss_sum, const cstr_alpha_part_t *alpha,
                             int64_t batch, cstr_stream_t stream);
 
+/* cstr_hidden_head_bwd_f32 with the loss root INSIDE: d(loss)/dq of the twin Q networks (groups = 2) is computed per row in
+ * the kernel instead of being read from gq, and one extra workgroup performs the batch reductions of the separate loss
+ * launch (logged loss, entropy-coefficient part, g_logp) with that launch's arithmetic and reduction order -- the critic
+ * backward's / the actor backward's first launch and its loss launch become ONE.
+ *   mode 1 (critic loss, core/sac/sac.py:245-261, core/td3/td3.py:174-182) = cstr_td_twin_q_loss_f32's fields;
+ *   mode 2 (SAC actor loss, core/sac/sac.py:273-275)                       = cstr_sac_actor_loss_f32's fields (q1/q2 = Q(s, pi(s))).
+ * Unused pointers NULL; gq1 / gq2 of the separate launches are not produced (nothing else reads them). m <= 1024 rows. */
+typedef struct cstr_head_root {
+    int32_t mode, batch;
+    float gamma, scale;
+    const float *q1_t, *q2_t, *next_logp, *rew, *done; /* mode 1 */
+    const float *ent_coef;                             /* [1]: mode 1 without alpha part, mode 2 */
+    const float *q1, *q2;                              /* [batch] each */
+    float *target_out;                                 /* mode 1, [batch] or NULL */
+    const float *logp;                                 /* mode 2 */
+    float *g_logp;                                     /* mode 2 out [batch] */
+    float *loss_out, *loss_sum;                        /* [1] or NULL */
+    cstr_alpha_part_t alpha;                           /* mode 1: log_alpha NULL = absent */
+} cstr_head_root_t;
+int cstr_hidden_head_bwd_root_f32(const cstr_head_root_t *root, const float *y, int act, const float *w2, float *dz, float *gb1,
+                                  float *gw2, float *gb2, int64_t m, int64_t k, cstr_stream_t stream);
+
 /* SAC actor loss as a backward root (core/sac/sac.py:273-275): loss = mean(ent_coef * logp - min(q1, q2)). */
 int cstr_sac_actor_loss_f32(const float *logp, const float *q1, const float *q2, const float *ent_coef, float *g_logp, float *gq1,
                             float *gq2, float *loss_out, float *loss_sum, int64_t batch, cstr_stream_t stream);

@@ -37,6 +37,7 @@ USE_FUSED_LINEAR = os.environ.get("CSTR_FUSED_LINEAR", "1") != "0"
 # development A/B knobs: the 2B-row actor pass (_ActorPairFn) and the four-network critic / target chain (_TwinPairFn)
 USE_ACTOR_PAIR = os.environ.get("CSTR_ACTOR_PAIR", "1") != "0"
 USE_TWIN_PAIR = os.environ.get("CSTR_TWIN_PAIR", "1") != "0"
+USE_LOSS_ROOT = os.environ.get("CSTR_LOSS_ROOT", "1") != "0"  # the loss launches ride in the backward's first launch
 
 
 def _fused_linear_ok(x: th.Tensor) -> bool:
@@ -394,6 +395,47 @@ def stacked_linear(x, weight, bias, wgrad, bgrad, act: int, train_params: bool, 
 
 _ZERO_BIAS: dict = {}
 
+# A loss whose gradient w.r.t. the twin Q values is a per-row function of the batch (the TD critic loss, SAC's actor loss) can ride
+# in the FIRST launch of the backward it roots (cstr_hidden_head_bwd_root_f32) instead of being a launch of its own:
+# `set_loss_root(root)` right before the backward call; the twin hidden-head backward that runs next consumes it and ignores the
+# values of the gradient tensor it is handed.
+_pending_root: Optional[dict] = None
+
+
+def set_loss_root(root: Optional[dict]) -> None:
+    global _pending_root
+    _pending_root = root
+
+
+def loss_root_pending() -> bool:
+    return _pending_root is not None
+
+
+LOSS_ROOT_MAX_ROWS = 1024  # cstr_hidden_head_bwd_root_f32 keeps the per-row gradients in LDS
+
+
+def _take_root(groups: int) -> Optional[dict]:
+    global _pending_root
+    if _pending_root is None or groups != 2:
+        return None
+    root, _pending_root = _pending_root, None
+    return root
+
+
+def loss_root_supported(critic: "FastTwinCritic") -> bool:
+    """The critic's backward starts with the twin hidden-head launch: stacked, two Q networks, scalar head."""
+    st = critic.stack
+    return (USE_FUSED_LINEAR and USE_LOSS_ROOT and st is not None and len(st) >= 2 and st[0][0].shape[0] == 2 and st[-1][0].shape[1] == 1
+            and critic.acts[-1] == ACT_NONE)
+
+
+def _head_bwd(gq, y, act, w2, dz, gb1, gw2, gb2) -> None:
+    root = _take_root(y.shape[0] if y.dim() == 3 else 1)
+    if root is not None:
+        hip_ops.hidden_head_bwd_root(root, y, act, w2, dz, gb1, gw2, gb2)
+    else:
+        hip_ops.hidden_head_bwd(gq.contiguous(), y, act, w2, dz, gb1, gw2, gb2)
+
 
 def _hidden_gemm(x: th.Tensor, w1: th.Tensor) -> th.Tensor:
     """z = x @ w1^T of a Q network's last hidden layer (its bias + activation ride in the head kernel): at batch size the f32-MFMA
@@ -429,7 +471,7 @@ class _HiddenHeadFn(th.autograd.Function):
         x, w1, y, w2 = ctx.saved_tensors
         gw1, gb1, gw2, gb2 = ctx.grads if ctx.train_params else (None, None, None, None)
         dz = th.empty_like(y)
-        hip_ops.hidden_head_bwd(gq.contiguous(), y, ctx.act, w2, dz, gb1, gw2, gb2)
+        _head_bwd(gq, y, ctx.act, w2, dz, gb1, gw2, gb2)
         if ctx.train_params:
             if USE_FUSED_LINEAR:
                 _weight_grad(dz, x, gw1, None)  # gb1 came out of the head kernel
@@ -744,7 +786,7 @@ class _TwinPairFn(th.autograd.Function):
         x, h1, w2, y2, w3 = ctx.saved_tensors
         (gw1, gb1), (gw2, gb2), (gw3, gb3) = ctx.grads
         dz2 = th.empty_like(y2)
-        hip_ops.hidden_head_bwd(gq.contiguous(), y2, ctx.act, w3, dz2, gb2, gw3, gb3)
+        _head_bwd(gq, y2, ctx.act, w3, dz2, gb2, gw3, gb3)
         _weight_grad(dz2, h1, gw2, None)  # gb2 came out of the head kernel
         dz1 = hip_ops.linear_bwd_input(dz2, w2, h1, ctx.act)
         _weight_grad(dz1, x, gw1, gb1)

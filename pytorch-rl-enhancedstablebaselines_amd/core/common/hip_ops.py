@@ -596,6 +596,48 @@ def hidden_head_bwd(gq, y, act: int, w2, dz, gb1=None, gw2=None, gb2=None):
                                             C.c_int64(g), C.c_int64(m), C.c_int64(k), stream_ptr()), "cstr_hidden_head_bwd_f32")
 
 
+def hidden_head_bwd_root(root: dict, y, act: int, w2, dz, gb1=None, gw2=None, gb2=None):
+    """`hidden_head_bwd` for the twin Q networks with the loss root inside (cstr_hidden_head_bwd_root_f32): `root` =
+    dict(mode="td", q1_t, q2_t, next_logp | None, rew, done, ent_coef | None, gamma, scale, q1, q2, target_out | None, loss_out | None,
+    loss_sum | None, alpha | None) -- the arguments of `td_twin_q_loss` -- or dict(mode="sac_actor", logp, q1, q2, ent_coef, g_logp,
+    loss_out | None, loss_sum | None) -- those of `sac_actor_loss`."""
+    g, m, k = _gmn(y)
+    if g != 2:
+        raise ValueError("the loss-root form is built for the twin Q networks (2 groups)")
+    _chk(dz, "dz", y.shape, th.float32)
+    for t, nm, numel in ((y, "y", g * m * k), (w2, "w2", g * k)):
+        if _f32c(t, nm).numel() != numel:
+            raise ValueError(f"{nm} has {t.numel()} elements, expected {numel}")
+    grads = (gb1, gw2, gb2)
+    if any(t is None for t in grads) != all(t is None for t in grads):
+        raise ValueError("gb1, gw2 and gb2 go together")
+    if gb1 is not None:
+        for t, nm, numel in ((gb1, "gb1", g * k), (gw2, "gw2", g * k), (gb2, "gb2", g)):
+            if _f32c(t, nm).numel() != numel:
+                raise ValueError(f"{nm} has {t.numel()} elements, expected {numel}")
+    p = lambda key, n=m: None if root.get(key) is None else _vec(root[key], key, n).data_ptr()  # noqa: E731
+    part = nv.AlphaPart()
+    if root["mode"] == "td":
+        alpha = root.get("alpha")
+        if alpha is not None:
+            _vec(alpha["logp_pi"], "logp_pi", m)
+            for nm in ("log_alpha", "grad_out", "ent_coef_out"):
+                _vec(alpha[nm], nm, 1)
+            part = nv.AlphaPart(alpha["log_alpha"].data_ptr(), alpha["logp_pi"].data_ptr(), float(alpha["target_entropy"]),
+                                alpha["grad_out"].data_ptr(), alpha["ent_coef_out"].data_ptr(),
+                                *(None if alpha.get(kk) is None else alpha[kk].data_ptr() for kk in ("loss_out", "loss_sum", "ent_coef_sum")))
+        rt = nv.HeadRoot(1, m, float(root["gamma"]), float(root["scale"]), p("q1_t"), p("q2_t"), p("next_logp"), p("rew"), p("done"),
+                         None if alpha is not None else p("ent_coef", 1), p("q1"), p("q2"), p("target_out"), None, None,
+                         p("loss_out", 1), p("loss_sum", 1), part)
+    elif root["mode"] == "sac_actor":
+        rt = nv.HeadRoot(2, m, 0.0, 0.0, None, None, None, None, None, p("ent_coef", 1), p("q1"), p("q2"), None, p("logp"), p("g_logp"),
+                         p("loss_out", 1), p("loss_sum", 1), part)
+    else:
+        raise ValueError(f"unknown loss root {root['mode']!r}")
+    check(nv.lib().cstr_hidden_head_bwd_root_f32(C.byref(rt), ptr(y), C.c_int(act), ptr(w2), ptr(dz), ptr(gb1), ptr(gw2), ptr(gb2),
+                                                 C.c_int64(m), C.c_int64(k), stream_ptr()), "cstr_hidden_head_bwd_root_f32")
+
+
 def _rows(t, name, b, a):
     """A [b, a] float32 device matrix whose rows may be strided (a column slice of a wider row-major matrix)."""
     if not (isinstance(t, th.Tensor) and t.is_cuda and t.dtype == th.float32 and tuple(t.shape) == (b, a) and t.stride(1) == 1

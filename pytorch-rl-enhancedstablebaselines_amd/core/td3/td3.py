@@ -172,14 +172,20 @@ class TD3(OffPolicyAlgorithm):
                 queued = self.noise_queue.pop(0).to(self.device, th.float32).contiguous() if self.noise_queue else None
                 hip_ops.target_smooth(a_t, queued, None if queued is not None else self._device_rng(), self.target_policy_noise,
                                       self.target_noise_clip, pb.x_next[:, pb.obs_dim:])
-                qs = self._fast_critic_target.forward_input(pb.x_next, train_params=False)
+                twin_pair = fused.twin_pair_supported(self._fast_critic, self._fast_critic_target)
+                if not twin_pair:
+                    qs = self._fast_critic_target.forward_input(pb.x_next, train_params=False)
             else:
                 noise = self.noise_queue.pop(0).to(self.device) if self.noise_queue else rd.actions.clone().normal_(0, self.target_policy_noise)
                 noise = noise.clamp(-self.target_noise_clip, self.target_noise_clip)
                 next_actions = (self._fast_actor_target(rd.next_observations, train_params=False) + noise).clamp(-1, 1)
                 qs = self._fast_critic_target(rd.next_observations, next_actions, train_params=False)
-            q1_t, q2_t = qs[0], qs[-1]
-        qs = self._fast_critic.forward_input(pb.x_data) if pb is not None else self._fast_critic(rd.observations, rd.actions)  # :179
+            if pb is None or not twin_pair:
+                q1_t, q2_t = qs[0], qs[-1]
+        if pb is not None and twin_pair:  # :179 and :173 as ONE four-network chain (three launches instead of six)
+            qs, (q1_t, q2_t) = fused.twin_pair_forward(self._fast_critic, self._fast_critic_target, pb.x_data, pb.x_next)
+        else:
+            qs = self._fast_critic.forward_input(pb.x_data) if pb is not None else self._fast_critic(rd.observations, rd.actions)  # :179
         q1, q2 = qs[0], qs[-1]
         # TD target (:174-176) + critic loss (:182) in one launch; n_critics == 1 (DDPG): loss = mse(q1, t) -> scale 0.5 of
         # the doubled term

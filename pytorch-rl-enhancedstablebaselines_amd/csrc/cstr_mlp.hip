@@ -1554,6 +1554,150 @@ __global__ __launch_bounds__(256) void sac_actor_loss_kernel(const float *__rest
     }
 }
 
+constexpr int HEAD_ROOT_MAX_ROWS = 1024;  // batch rows of the loss-root form (its per-row gradients sit in LDS)
+
+// block_sum_256 inside a larger workgroup: every thread calls it, waves 0-3 contribute (the same tree, the same bits)
+__device__ __forceinline__ float block_sum_first4(float v, float *sm)
+{
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0 && wave < 4) sm[wave] = v;
+    __syncthreads();
+    const float r = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+    __syncthreads();
+    return r;
+}
+
+// hidden_head_bwd_kernel with the loss root inside (cstr_hidden_head_bwd_root_f32): d(loss)/dq is a per-row function of the
+// batch's Q values, so every workgroup recomputes it for the rows it walks (the same expressions as td_twin_q_loss_kernel /
+// sac_actor_loss_kernel: the same bits), and ONE extra workgroup (blockIdx.x == gridDim.x - 1, group 0) does what only the
+// separate loss launch did: target_out / g_logp, the logged loss and the entropy-coefficient part, with that launch's 256-thread
+// accumulation pattern and reduction tree. Two groups (the twin Q networks).
+template <int ACT, int WAVES, int MODE>
+__global__ __launch_bounds__(WAVES * 64) void hidden_head_bwd_root_kernel(const cstr_head_root_t rt, const float *__restrict__ y,
+                                                                          const float *__restrict__ w2, float *__restrict__ dz,
+                                                                          float *__restrict__ gb1, float *__restrict__ gw2,
+                                                                          float *__restrict__ gb2, const int m, const int k)
+{
+    __shared__ float part[3][WAVES][64];
+    __shared__ float sm[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t g = blockIdx.y;
+    const bool with_alpha = MODE == 1 && rt.alpha.log_alpha != nullptr;
+    const float la = with_alpha ? rt.alpha.log_alpha[0] : 0.0f;
+    const float ec = with_alpha ? expf(la) : (rt.ent_coef ? rt.ent_coef[0] : 0.0f);
+    const float kq = rt.scale * 2.0f / (float)rt.batch, inv = 1.0f / (float)rt.batch;
+    if (blockIdx.x == gridDim.x - 1) {  // the loss workgroup
+        if (g != 0) return;
+        const int tid = threadIdx.x;
+        if (MODE == 1) {
+            float a1 = 0.0f, a2 = 0.0f, aa = 0.0f;
+            if (tid < 256) {
+                for (int b = tid; b < rt.batch; b += 256) {
+                    float q = fminf(rt.q1_t[b], rt.q2_t[b]);
+                    if (rt.next_logp) q = q - ec * rt.next_logp[b];
+                    const float t = rt.rew[b] + (1.0f - rt.done[b]) * rt.gamma * q;
+                    if (rt.target_out) rt.target_out[b] = t;
+                    const float d1 = rt.q1[b] - t, d2 = rt.q2[b] - t;
+                    a1 += d1 * d1;
+                    a2 += d2 * d2;
+                    if (with_alpha) aa += rt.alpha.logp_pi[b] + rt.alpha.target_entropy;
+                }
+            }
+            const float s1 = block_sum_first4(a1, sm), s2 = block_sum_first4(a2, sm);
+            const float mean = with_alpha ? block_sum_first4(aa, sm) / (float)rt.batch : 0.0f;
+            if (tid == 0) {
+                const float loss = rt.scale * (s1 / (float)rt.batch + s2 / (float)rt.batch);
+                if (rt.loss_out) rt.loss_out[0] = loss;
+                if (rt.loss_sum) rt.loss_sum[0] += loss;
+                if (with_alpha) {
+                    rt.alpha.grad_out[0] = -mean;
+                    rt.alpha.ent_coef_out[0] = ec;
+                    if (rt.alpha.loss_out) rt.alpha.loss_out[0] = -(la * mean);
+                    if (rt.alpha.loss_sum) rt.alpha.loss_sum[0] += -(la * mean);
+                    if (rt.alpha.ent_coef_sum) rt.alpha.ent_coef_sum[0] += ec;
+                }
+            }
+        } else {
+            float acc = 0.0f;
+            if (tid < 256) {
+                for (int b = tid; b < rt.batch; b += 256) {
+                    const float a = rt.q1[b], c = rt.q2[b];
+                    acc += ec * rt.logp[b] - (a <= c ? a : c);
+                    rt.g_logp[b] = ec * inv;
+                }
+            }
+            const float sum = block_sum_first4(acc, sm);
+            if (tid == 0) {
+                const float loss = sum * inv;
+                if (rt.loss_out) rt.loss_out[0] = loss;
+                if (rt.loss_sum) rt.loss_sum[0] += loss;
+            }
+        }
+        return;
+    }
+    const int col = blockIdx.x * 64 + lane;
+    const int64_t goff = g * (int64_t)m * k;
+    y += goff;
+    dz += goff;
+    // this group's d(loss)/dq for every row, ONCE per workgroup (a thread per row, coalesced loads), then read from LDS
+    __shared__ float gq_s[HEAD_ROOT_MAX_ROWS];
+    {
+        const float *qg = g == 0 ? rt.q1 : rt.q2;
+        for (int r = threadIdx.x; r < m; r += WAVES * 64) {
+            float gqv;
+            if (MODE == 1) {
+                float q = fminf(rt.q1_t[r], rt.q2_t[r]);
+                if (rt.next_logp) q = q - ec * rt.next_logp[r];
+                const float tq = rt.rew[r] + (1.0f - rt.done[r]) * rt.gamma * q;
+                gqv = kq * (qg[r] - tq);
+            } else {
+                const bool first = rt.q1[r] <= rt.q2[r];
+                gqv = (first == (g == 0)) ? -inv : 0.0f;
+            }
+            gq_s[r] = gqv;
+        }
+    }
+    __syncthreads();
+    const float w = col < k ? w2[g * k + col] : 0.0f;
+    float s_b1 = 0.0f, s_w2 = 0.0f, s_b2 = 0.0f;
+    constexpr int FLY = 8;
+    for (int r0 = wave; r0 < m; r0 += FLY * WAVES) {
+        float t[FLY], u[FLY];
+#pragma unroll
+        for (int j = 0; j < FLY; ++j) {
+            const int r = r0 + j * WAVES;
+            t[j] = (r < m && col < k) ? y[(int64_t)r * k + col] : 0.0f;
+            u[j] = r < m ? gq_s[r] : 0.0f;
+        }
+#pragma unroll
+        for (int j = 0; j < FLY; ++j) {
+            const int r = r0 + j * WAVES;
+            float d = u[j] * w;
+            if (ACT == ACT_RELU) d = t[j] > 0.0f ? d : 0.0f;
+            if (ACT == ACT_TANH) d = d * (1.0f - t[j] * t[j]);
+            if (r < m && col < k) dz[(int64_t)r * k + col] = d;
+            s_b1 += d;
+            s_w2 += u[j] * t[j];
+            s_b2 += u[j];
+        }
+    }
+    part[0][wave][lane] = s_b1;
+    part[1][wave][lane] = s_w2;
+    part[2][wave][lane] = s_b2;
+    __syncthreads();
+    if (wave == 0 && gw2) {
+        float a = 0.0f, b = 0.0f, c = 0.0f;
+#pragma unroll
+        for (int v = 0; v < WAVES; ++v) { a += part[0][v][lane]; b += part[1][v][lane]; c += part[2][v][lane]; }
+        if (col < k) {
+            gb1[g * k + col] = a;
+            gw2[g * k + col] = b;
+        }
+        if (blockIdx.x == 0 && lane == 0) gb2[g] = c;
+    }
+}
+
 // Deterministic-policy actor loss (core/td3/td3.py:194, core/maddpg/maddpg.py:174): loss = -mean(q1); dq = -1/B
 __global__ __launch_bounds__(256) void neg_mean_loss_kernel(const float *__restrict__ q, float *__restrict__ gq,
                                                             float *__restrict__ loss_out, float *__restrict__ loss_sum, const int batch)
@@ -1726,6 +1870,27 @@ extern "C" int cstr_hidden_head_bwd_f32(const float *gq, const float *y, int act
     if (m >= 64) { if (act == 0) HH_BWD(0, 16); else if (act == 1) HH_BWD(1, 16); else HH_BWD(2, 16); }
     else { if (act == 0) HH_BWD(0, 4); else if (act == 1) HH_BWD(1, 4); else HH_BWD(2, 4); }
 #undef HH_BWD
+    return (int)hipGetLastError();
+}
+
+extern "C" int cstr_hidden_head_bwd_root_f32(const cstr_head_root_t *root, const float *y, int act, const float *w2, float *dz,
+                                             float *gb1, float *gw2, float *gb2, int64_t m, int64_t k, cstr_stream_t stream)
+{
+    if (!root || !y || !w2 || !dz || m <= 0 || k <= 0) return CSTR_E_BADARG;
+    const cstr_head_root_t &r = *root;
+    if ((gb1 == nullptr) != (gw2 == nullptr) || (gw2 == nullptr) != (gb2 == nullptr)) return CSTR_E_BADARG;  // all three or none
+    if ((r.mode != 1 && r.mode != 2) || r.batch != m || !r.q1 || !r.q2) return CSTR_E_BADARG;
+    if (r.mode == 1 && (!r.q1_t || !r.q2_t || !r.rew || !r.done || (r.next_logp && !r.alpha.log_alpha && !r.ent_coef))) return CSTR_E_BADARG;
+    if (r.mode == 1 && r.alpha.log_alpha && (!r.alpha.logp_pi || !r.alpha.grad_out || !r.alpha.ent_coef_out)) return CSTR_E_BADARG;
+    if (r.mode == 2 && (!r.logp || !r.g_logp || !r.ent_coef)) return CSTR_E_BADARG;
+    if (act < 0 || act > 2 || m > HEAD_ROOT_MAX_ROWS || k > 0x7fffffff) return CSTR_E_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid((unsigned)((k + 63) / 64) + 1u, 2u);  // + the loss workgroup
+#define HH_ROOT(A, W) do { if (r.mode == 1) hidden_head_bwd_root_kernel<A, W, 1><<<grid, W * 64, 0, s>>>(r, y, w2, dz, gb1, gw2, gb2, (int)m, (int)k); \
+                           else hidden_head_bwd_root_kernel<A, W, 2><<<grid, W * 64, 0, s>>>(r, y, w2, dz, gb1, gw2, gb2, (int)m, (int)k); } while (0)
+    if (m >= 64) { if (act == 0) HH_ROOT(0, 16); else if (act == 1) HH_ROOT(1, 16); else HH_ROOT(2, 16); }
+    else { if (act == 0) HH_ROOT(0, 4); else if (act == 1) HH_ROOT(1, 4); else HH_ROOT(2, 4); }
+#undef HH_ROOT
     return (int)hipGetLastError();
 }
 
