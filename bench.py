@@ -542,7 +542,7 @@ def main():
             traffic = None  # HBM bytes per launch from the committed PMC passes (tools/pmc_policy.sh), bench shape only
             if pk["shape"] == [4096, 4, 256, 256, 4]:
                 try:
-                    with open(os.path.join(ROOT, "profiles", "r01_policy_pmc.json")) as fh:
+                    with open(os.path.join(ROOT, "profiles", "r02_policy_pmc.json")) as fh:
                         traffic = json.load(fh)["policy_rows_fwd_kernel"]["4096"]["traffic_bytes"]
                 except (OSError, KeyError, ValueError):
                     pass

@@ -612,9 +612,13 @@ __device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float &z0, fl
 {
     const float u1 = ((float)(a >> 8) + 0.5f) * (1.0f / 16777216.0f);  // (0, 1): 24 random bits, never 0
     const float u2 = ((float)(b >> 8) + 0.5f) * (1.0f / 16777216.0f);
-    const float r = sqrtf(-2.0f * logf(u1)), t = 6.28318530717958647692f * u2;
-    z0 = r * cosf(t);
-    z1 = r * sinf(t);
+    // cos / sin(2 pi u2) through sincospif: one shared, exact argument reduction (the angle is given in half-turns) instead of two
+    // full-range reductions of 2 pi u2 -- the same distribution, a shorter dependent chain (the rollout's noise is drawn by ONE wave)
+    const float r = sqrtf(-2.0f * logf(u1));
+    float sn, cs;
+    sincospif(2.0f * u2, &sn, &cs);
+    z0 = r * cs;
+    z1 = r * sn;
 }
 
 __global__ __launch_bounds__(64) void gaussian_head_fwd_kernel(float *__restrict__ params, const float *__restrict__ bias,
@@ -1185,7 +1189,8 @@ __global__ __launch_bounds__(64 * POLICY_WAVES) void policy_rows_v2_kernel(const
         bq0[u] = w2s[((int64_t)t0 * kc1 + c) * 64 + lane]; bq1[u] = w2s[((int64_t)t1 * kc1 + c) * 64 + lane]; } } while (0)
     // how many of the NB chunks are requested BEFORE the first barrier: a wave is held while it issues loads (~60 ns per 1 KB wave
     // load), and everybody waits at the barrier for the last issuer -- the rest follows right after the barrier, before the MFMAs
-    constexpr int PRE_YOUNG = SMALL ? 12 : V2_CH, PRE_NOISE = SMALL ? 8 : V2_CH, PRE_OLD = V2_CH;
+    // (waves 0-3, SMALL: none before layer 1 -- A/B on MI355X: 0 / 2 / 4 chunks ahead of layer 1 = 10.60 / 10.61 / 10.73 us)
+    constexpr int PRE_YOUNG = SMALL ? 12 : V2_CH, PRE_NOISE = SMALL ? 8 : V2_CH, PRE_OLD = SMALL ? 0 : V2_CH;
     const bool noise_wave = draw && wave == WAVES - 1;
     // zero the k padding of both activation images (widths that are not multiples of 16: the MFMA chunks read them)
     {
@@ -1248,6 +1253,8 @@ __global__ __launch_bounds__(64 * POLICY_WAVES) void policy_rows_v2_kernel(const
         policy_layer<ACT, true, VEC0, false, 16>(a.x + m0 * a.ldx, a.ldx, m0 + r < a.m, a.k0, a.w1, a.b1, H1, h1s, S1, wave, L1_WAVES);
         V2_REQUEST_B(0, PRE_OLD);
     }
+    // the tail's head biases (thread = 8 * row + j reads slots j and act_dim + j): requested now, used ~8 us later
+    const float b3v0 = a.b3[min(tid & 7, n_out - 1)], b3v1 = a.b3[min((HEAD == 0 ? a.act_dim : 0) + (tid & 7), n_out - 1)];
     {   // needed last: the first tile pair's bias values and the head's rows
         b2q0 = a.b2[min(16 * t0 + r, H2 - 1)];
         b2q1 = a.b2[min(16 * t1 + r, H2 - 1)];
@@ -1382,15 +1389,15 @@ __global__ __launch_bounds__(64 * POLICY_WAVES) void policy_rows_v2_kernel(const
     const int trow = tid >> 3, j = tid & 7;
     const int64_t row = m0 + trow;
     const bool live = tid < POLICY_ROWS * 8 && row < a.m;
-    auto head_out = [&](const int jj) {
+    auto head_out = [&](const int jj, const float bias) {
         float sum = 0.0f;
 #pragma unroll
         for (int w = 0; w < WAVES; ++w) sum += part[(w * POLICY_ROWS + trow) * 8 + jj];
-        return sum + a.b3[jj];
+        return sum + bias;
     };
     if (HEAD == 1) {
         if (live && j < n_out) {
-            float v = head_out(j);
+            float v = head_out(j, b3v0);
             if (a.out_act == ACT_RELU) v = fmaxf(v, 0.0f);
             if (a.out_act == ACT_TANH) v = tanhf(v);
             a.action[row * a.action_stride + j] = v;
@@ -1398,7 +1405,7 @@ __global__ __launch_bounds__(64 * POLICY_WAVES) void policy_rows_v2_kernel(const
     } else {
         if (live && j < a.act_dim) {
             const float half_log_2pi = 0.91893853320467274178f;
-            const float mu = head_out(j), raw = head_out(a.act_dim + j);
+            const float mu = head_out(j, b3v0), raw = head_out(a.act_dim + j, b3v1);
             const float e = a.eps_in ? a.eps_in[row * a.act_dim + j] : eps_s[trow * 8 + j];
             const float ls = fminf(fmaxf(raw, LOG_STD_MIN), LOG_STD_MAX);
             const float sd = expf(ls);

@@ -17,5 +17,5 @@ if __name__ == "__main__":
     x, w1, b1, w2, b2, w3, b3 = r(m, k0), r(h, k0), r(h), r(h, h) / 16, r(h), r(2 * a, h) / 16, r(2 * a)
     ctl, act, tiles = hip_ops.new_rng_ctl(1, "cuda"), th.empty(m, a, device="cuda"), hip_ops.policy_swizzle(w2)
     for _ in range(200):
-        hip_ops.policy_rows_fwd(x, w1, b1, w2, b2, w3, b3, 1, 0, 0, act, rng_ctl=ctl, w2_swz=tiles)
+        hip_ops.policy_rows_fwd(x, w1, b1, w2, b2, w3, b3, 1, 0, 0, act, rng_ctl=ctl, w2_swz=tiles, defer_rng_advance=True)
     th.cuda.synchronize()

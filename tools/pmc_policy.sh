@@ -13,9 +13,11 @@ import csv, glob, json, statistics
 res = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     f = glob.glob("$OUT/pmc_%s/**/*counter_collection.csv" % c, recursive=True)[0]
-    v = [float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if "policy_rows_fwd" in r["Kernel_Name"] and r["Counter_Name"] == c]
+    v = [float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if "policy_rows" in r["Kernel_Name"] and r["Counter_Name"] == c]
     res[c + "_KiB"] = round(statistics.median(v), 2)
     res["dispatches"] = len(v)
+print(json.dumps(res))
+res["traffic_bytes"] = int((2 * res["FETCH_SIZE_KiB"] + res["WRITE_SIZE_KiB"]) * 1024)  # gfx950: FETCH_SIZE counts half the bytes
 print(json.dumps(res))
 json.dump(res, open("$OUT/policy_pmc.json", "w"))
 PY
