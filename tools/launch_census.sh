@@ -4,7 +4,7 @@ ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 rm -rf $OUT/prof_x
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_x -o sac -- python3 $ROOT/bench.py --algo ${ALGO:-sac} --steps 300 --warmup 50 --no-variant --no-cpu-baseline --no-roofline > $OUT/prof_x.json 2> $OUT/prof_x.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_x -o sac -- python3 $ROOT/bench.py --algo ${ALGO:-sac} ${EXTRA:-} --graph-unroll 1 --steps 300 --warmup 50 --no-variant --no-cpu-baseline --no-roofline > $OUT/prof_x.json 2> $OUT/prof_x.err
 f=$(find $OUT/prof_x -name "*kernel_stats.csv" | head -1)
 python3 - <<PY
 import csv, json
