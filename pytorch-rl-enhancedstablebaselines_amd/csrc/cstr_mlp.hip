@@ -1199,8 +1199,7 @@ __global__ __launch_bounds__(64 * POLICY_WAVES) void policy_rows_v2_kernel(const
         if (tid < POLICY_ROWS * p2) h2s[(tid / p2) * S2 + H2 + tid % p2] = 0.0f;
     }
     if (!l1_wave) {
-        V2_REQUEST_B(0, PRE_NOISE);
-        if (!noise_wave) V2_REQUEST_B(PRE_NOISE, PRE_YOUNG);
+        if (!noise_wave) V2_REQUEST_B(0, PRE_YOUNG);
         if (noise_wave) {
             const int64_t row = m0 + lane;
             if (lane < POLICY_ROWS && row < a.m) {
@@ -1215,6 +1214,7 @@ __global__ __launch_bounds__(64 * POLICY_WAVES) void policy_rows_v2_kernel(const
                 }
             }
             V2_STAMP(7);
+            V2_REQUEST_B(0, PRE_NOISE);  // the noise wave: its ~1 us chain first (it was the last arrival at the barrier), then its requests
         }
     } else if (K0_SMALL) {
         float4 w1v[L1_T];
@@ -1359,7 +1359,10 @@ __global__ __launch_bounds__(64 * POLICY_WAVES) void policy_rows_v2_kernel(const
     }
 #undef V2_EPILOGUE
     V2_STAMP(3);
-    __syncthreads();
+    // No workgroup barrier here: the head's k chunks of wave w are c = w + 8 q -- exactly the column tiles this wave has just
+    // written (t = w, w + 8, w + 16, w + 24), so it reads back only its OWN LDS stores; a wave's LDS operations complete in order,
+    // the fence keeps the compiler from moving the reads up and drains the stores.
+    __threadfence_block();
     V2_STAMP(4);
 
     // head: ONE 16 x 16 tile (rows x outputs, outputs >= n_out are zero columns), K split over the waves
