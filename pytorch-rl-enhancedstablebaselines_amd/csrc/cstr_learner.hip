@@ -86,22 +86,45 @@ __device__ __forceinline__ void adam_body(float *__restrict__ param, const float
     const int64_t tid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x, stride = (int64_t)gridDim.x * blockDim.x;
     float4 *p4 = reinterpret_cast<float4 *>(param), *m4 = reinterpret_cast<float4 *>(exp_avg), *v4 = reinterpret_cast<float4 *>(exp_avg_sq);
     const float4 *g4 = reinterpret_cast<const float4 *>(grad);
-    // arenas far beyond the caches (a microbenchmark regime, not the learners'): stream the updated state past L2
+    // arenas far beyond the caches (a microbenchmark regime, not the learners'): stream the state past L2 in BOTH directions
+    // (non-temporal loads as well as stores: every byte is touched once) and keep two 16-byte quads per stream in flight per lane
     const bool stream_out = n >= (int64_t)(16 << 20);
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    if (stream_out && !sh.out) {
+        int64_t i = tid;
+        for (; i + stride < nv; i += 2 * stride) {
+            const int64_t j = i + stride;
+            v4f p0 = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(p4 + i)), p1 = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(p4 + j));
+            v4f m0 = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(m4 + i)), m1 = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(m4 + j));
+            v4f v0 = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(v4 + i)), v1 = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(v4 + j));
+            const v4f g0 = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(g4 + i)), g1 = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(g4 + j));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float pp = p0[e], mm = m0[e], vv = v0[e];
+                adam1(pp, g0[e], mm, vv, a);
+                p0[e] = pp; m0[e] = mm; v0[e] = vv;
+                pp = p1[e]; mm = m1[e]; vv = v1[e];
+                adam1(pp, g1[e], mm, vv, a);
+                p1[e] = pp; m1[e] = mm; v1[e] = vv;
+            }
+            __builtin_nontemporal_store(p0, reinterpret_cast<v4f *>(p4 + i)); __builtin_nontemporal_store(p1, reinterpret_cast<v4f *>(p4 + j));
+            __builtin_nontemporal_store(m0, reinterpret_cast<v4f *>(m4 + i)); __builtin_nontemporal_store(m1, reinterpret_cast<v4f *>(m4 + j));
+            __builtin_nontemporal_store(v0, reinterpret_cast<v4f *>(v4 + i)); __builtin_nontemporal_store(v1, reinterpret_cast<v4f *>(v4 + j));
+        }
+        for (; i < nv; i += stride) {
+            float4 p = p4[i], m = m4[i], v = v4[i];
+            const float4 g = g4[i];
+            adam1(p.x, g.x, m.x, v.x, a); adam1(p.y, g.y, m.y, v.y, a);
+            adam1(p.z, g.z, m.z, v.z, a); adam1(p.w, g.w, m.w, v.w, a);
+            p4[i] = p; m4[i] = m; v4[i] = v;
+        }
+    } else
     for (int64_t i = tid; i < nv; i += stride) {
         float4 p = p4[i], m = m4[i], v = v4[i];
         const float4 g = g4[i];
         adam1(p.x, g.x, m.x, v.x, a); adam1(p.y, g.y, m.y, v.y, a);
         adam1(p.z, g.z, m.z, v.z, a); adam1(p.w, g.w, m.w, v.w, a);
-        if (stream_out) {
-            typedef float v4f __attribute__((ext_vector_type(4)));
-            const v4f pv = {p.x, p.y, p.z, p.w}, mv = {m.x, m.y, m.z, m.w}, vv = {v.x, v.y, v.z, v.w};
-            __builtin_nontemporal_store(pv, reinterpret_cast<v4f *>(p4 + i));
-            __builtin_nontemporal_store(mv, reinterpret_cast<v4f *>(m4 + i));
-            __builtin_nontemporal_store(vv, reinterpret_cast<v4f *>(v4 + i));
-        } else {
-            p4[i] = p; m4[i] = m; v4[i] = v;
-        }
+        p4[i] = p; m4[i] = m; v4[i] = v;
         if (sh.out && i >= sh.begin4 && i < sh.end4) {  // this float4 is one lane's operand quad of the matrix
             const int64_t e = (i - sh.begin4) * 4;
             const int row = (int)(e / sh.k), col = (int)(e - (int64_t)row * sh.k);

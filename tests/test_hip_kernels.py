@@ -639,3 +639,25 @@ def test_multi_update_launch_equals_separate_calls(ops):
     for x, y in zip(a1 + b1 + [t1, ca1, cb1], a2 + b2 + [t2, ca2, cb2]):
         assert th.equal(x, y)
     assert int(ca2[0]) == 3 and int(cb2[0]) == 3
+
+
+def test_adam_streaming_regime_equals_cached_regime(ops):
+    """Arenas of >= 2^24 parameters take the streaming form of the Adam kernel (non-temporal loads and stores, two quads per
+    stream in flight): the same arithmetic, so the result equals the cached form's bit for bit -- checked by running the same data
+    as ONE 2^24 + 8-element arena and as two halves below the threshold (separate control words, same step)."""
+    n = (1 << 24) + 8
+    g = th.Generator(device="cuda").manual_seed(7)
+    p0, gr = th.randn(n, device="cuda", generator=g), th.randn(n, device="cuda", generator=g) * 0.01
+    lr = th.tensor([1e-3], dtype=th.float64, device="cuda")
+    pa, ma, va, ca = p0.clone(), th.zeros(n, device="cuda"), th.zeros(n, device="cuda"), ops.new_adam_ctl("cuda")
+    h = n // 2  # a multiple of 4: both halves stay 16-byte aligned
+    halves = []
+    for lo, hi in ((0, h), (h, n)):
+        halves.append((p0[lo:hi].clone(), th.zeros(hi - lo, device="cuda"), th.zeros(hi - lo, device="cuda"), ops.new_adam_ctl("cuda"), gr[lo:hi].clone()))
+    for _ in range(3):
+        ops.adam(pa, gr, ma, va, ca, lr)
+        for p, m, v, c, gg in halves:
+            ops.adam(p, gg, m, v, c, lr)
+    for name, whole, idx in (("param", pa, 0), ("exp_avg", ma, 1), ("exp_avg_sq", va, 2)):
+        assert th.equal(whole, th.cat([halves[0][idx], halves[1][idx]])), name
+    assert int(ca[0]) == 3 and int(ca[1]) == 0
