@@ -109,7 +109,11 @@ class TD3(OffPolicyAlgorithm):
         # the reference keeps the last np.mean(actor_losses) until the next actor update (td3.py:207-211): a call without a
         # policy update zeroes the critic slot only, so a log dump after it still resolves the lazily-read actor loss
         n_actor = (self._n_updates + gradient_steps) // self.policy_delay - self._n_updates // self.policy_delay
-        (self._loss_sum_buf if n_actor > 0 else self._loss_sum_buf[1:2]).zero_()
+        # one gradient step per train() call (the default) on the fused path: the loss kernels STORE the logged values into the
+        # sums (an actor-less call leaves the actor's slot alone), no zero-fill launch
+        self._single_step = gradient_steps == 1 and self.fused_learner
+        if not self._single_step:
+            (self._loss_sum_buf if n_actor > 0 else self._loss_sum_buf[1:2]).zero_()
         n_updates = self._n_updates  # host counter advances in _train_host_only
         for _ in range(gradient_steps):
             n_updates += 1
@@ -188,11 +192,20 @@ class TD3(OffPolicyAlgorithm):
             qs = self._fast_critic.forward_input(pb.x_data) if pb is not None else self._fast_critic(rd.observations, rd.actions)  # :179
         q1, q2 = qs[0], qs[-1]
         # TD target (:174-176) + critic loss (:182) in one launch; n_critics == 1 (DDPG): loss = mse(q1, t) -> scale 0.5 of
-        # the doubled term
-        hip_ops.td_twin_q_loss(q1_t, q2_t, None, rd.rewards, rd.dones, None, self.gamma, q1, q2, 1.0 if len(qs) == 2 else 0.5,
-                               self._target_q, gq1, gq2, self._loss_now["critic"], s["critic"])
+        # the doubled term. Twin critics: inside the critic backward's first launch (cstr_hidden_head_bwd_root_f32).
+        single = getattr(self, "_single_step", False)
+        c_out, c_sum = (s["critic"], None) if single else (self._loss_now["critic"], s["critic"])
+        root = len(qs) == 2 and qs.stacked is not None and B <= fused.LOSS_ROOT_MAX_ROWS and fused.loss_root_supported(self._fast_critic)
+        if root:
+            fused.set_loss_root(dict(mode="td", q1_t=q1_t, q2_t=q2_t, next_logp=None, rew=rd.rewards, done=rd.dones, ent_coef=None,
+                                     gamma=self.gamma, scale=1.0, q1=q1.detach(), q2=q2.detach(), target_out=self._target_q,
+                                     loss_out=c_out, loss_sum=c_sum, alpha=None))
+        else:
+            hip_ops.td_twin_q_loss(q1_t, q2_t, None, rd.rewards, rd.dones, None, self.gamma, q1, q2, 1.0 if len(qs) == 2 else 0.5,
+                                   self._target_q, gq1, gq2, c_out, c_sum)
         if len(qs) == 2:
             fused.backward_q(qs, gq)
+            assert not fused.loss_root_pending(), "the critic backward did not start with the twin hidden-head launch"
         else:
             with fused.deferred_weight_grads():
                 th.autograd.backward([q1], [gq1 + gq2])
@@ -202,7 +215,8 @@ class TD3(OffPolicyAlgorithm):
         if n_updates % self.policy_delay == 0:  # :192-206
             a = self._fast_actor(rd.observations)
             qs_pi = self._fast_critic(rd.observations, a, train_params=False, only_first=True)
-            hip_ops.neg_mean_loss(qs_pi[0], gq1, self._loss_now["actor"], s["actor"])
+            a_out, a_sum = (s["actor"], None) if single else (self._loss_now["actor"], s["actor"])
+            hip_ops.neg_mean_loss(qs_pi[0], gq1, a_out, a_sum)
             fused.backward_q(qs_pi, gq)
             self._allreduce_grads(pol.actor_arena)
             # the actor's step and the critics' soft update touch disjoint arenas: one launch (:199 and :204)
@@ -211,8 +225,8 @@ class TD3(OffPolicyAlgorithm):
             actor_done = True
         if self.debug_capture:
             self.last_train_tensors = dict(target_q=self._target_q.clone(), current_q=[q.detach().clone() for q in qs],
-                                           critic_loss=self._loss_now["critic"].clone(),
-                                           actor_loss=self._loss_now["actor"].clone() if actor_done else None)
+                                           critic_loss=c_out.clone(),
+                                           actor_loss=a_out.clone() if actor_done else None)
 
     def _get_torch_save_params(self) -> tuple:
         """reference: td3.py:234-240"""
