@@ -245,6 +245,11 @@ int cstr_bias_act_fwd_f32(float *y, const float *bias, int act, int64_t groups, 
  * bias gradient's batch sum). gbias may be NULL; with act == NONE and gz == gy nothing is copied. */
 int cstr_bias_act_bwd_f32(const float *gy, const float *y, int act, float *gz, float *gbias, int64_t groups, int64_t m, int64_t n,
                           cstr_stream_t stream);
+/* The same for ONE group whose gy / y are column blocks of wider row-major matrices (row strides ldg / ldy >= n): the action columns of
+ * d(loss)/d(critic input) and of the critic input itself in the deterministic actors' backward (core/td3/td3.py:194-200,
+ * core/maddpg/maddpg.py:167-185) -- no gather copies. gz is contiguous [m][n]. */
+int cstr_bias_act_bwd_rows_f32(const float *gy, int64_t ldg, const float *y, int64_t ldy, int act, float *gz, float *gbias, int64_t m,
+                               int64_t n, cstr_stream_t stream);
 
 /* nn.Linear + the activation create_mlp puts behind it (core/common/torch_layers.py:110-183), forward, in ONE launch for the
  * learners' small shapes: y[g][m][n] = act(sum_k x[g][m][k] * w[g][n][k] + bias[g][n]) on the f32 matrix cores (exact f32 fma

@@ -148,6 +148,38 @@ class _LinearFn(th.autograd.Function):
         return dx, None, None, None, None, None, None
 
 
+class _LinearXbufFn(th.autograd.Function):
+    """`_LinearFn` whose output lands in the LAST N columns of a wider row-major buffer (a critic input whose observation columns
+    are already filled: torch.cat((obs, action)) without the launch) and whose gradient is read from those columns of the buffer's
+    gradient in place (cstr_bias_act_bwd_rows_f32: no gather copy). The buffer is the output."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, act: int, train_params: bool, below, xbuf):
+        n = weight.shape[0]
+        y = xbuf[:, xbuf.shape[1] - n:]
+        hip_ops.linear_act_fwd_sets([(x, weight, bias, y)], act)
+        ctx.act, ctx.train_params, ctx.below, ctx.n = act, train_params, below, n
+        ctx.save_for_backward(x, weight)
+        ctx.y = y.detach()
+        ctx.wgrad, ctx.bgrad = (weight.grad, bias.grad) if train_params else (None, None)
+        ctx.mark_dirty(xbuf)
+        return xbuf
+
+    @staticmethod
+    def backward(ctx, g_buf):
+        x, weight = ctx.saved_tensors
+        if g_buf.stride(1) != 1:
+            g_buf = g_buf.contiguous()
+        gy = g_buf[:, g_buf.shape[1] - ctx.n:]
+        if ctx.act != ACT_NONE:
+            gz = hip_ops.bias_act_bwd_rows(gy, ctx.y, ctx.act, th.empty(gy.shape, dtype=gy.dtype, device=gy.device))
+        else:
+            gz = gy.contiguous()
+        _param_grads(ctx, gz, x)
+        dx = _input_grad(gz, weight, x, ctx.below) if ctx.needs_input_grad[0] else None
+        return dx, None, None, None, None, None, None
+
+
 def linear(x: th.Tensor, weight: th.Tensor, bias: th.Tensor, act: int, train_params: bool, below=None,
            grad_is_dz: bool = False) -> th.Tensor:
     """y = act(x @ W^T + b). With grad mode off this is just the forward launch(es)."""
@@ -206,9 +238,22 @@ class FastMLP:
         """what a fused consumer of this MLP's output needs to run the last layer's activation / bias gradient itself"""
         return (self.layers[-1][1], None)
 
-    def __call__(self, x: th.Tensor, train_params: bool = True, out_grad_is_dz: bool = False) -> th.Tensor:
-        """`out_grad_is_dz`: the consumer is a fused layer built with `below=self.tail_below(...)` (see _input_grad)."""
+    def __call__(self, x: th.Tensor, train_params: bool = True, out_grad_is_dz: bool = False, xbuf: Optional[th.Tensor] = None) -> th.Tensor:
+        """`out_grad_is_dz`: the consumer is a fused layer built with `below=self.tail_below(...)` (see _input_grad).
+        `xbuf` [M, W]: the output is written into its last out_features columns and the BUFFER is returned (a deterministic actor's
+        action straight into the critic input, differentiable)."""
         layers = self.layers
+        if xbuf is not None:
+            if not USE_FUSED_LINEAR or not th.is_grad_enabled() or layers[-1][0].out_features == 1 or x.stride(-1) != 1:
+                raise NotImplementedError("FastMLP xbuf: the fused, differentiated, non-scalar-head form only")
+            below = None
+            for i, (lin, act) in enumerate(layers[:-1]):
+                x = linear(x, lin.weight, lin.bias, act, train_params, below, grad_is_dz=True)
+                below = (act, None)
+            lin, act = layers[-1]
+            if train_params and (lin.weight.grad is None or lin.bias.grad is None):
+                raise RuntimeError("fused linear: parameter gradients must be views of a ParamArena gradient buffer")
+            return _LinearXbufFn.apply(x, lin.weight, lin.bias, act, train_params, below if x.requires_grad else None, xbuf)
         if self._whole_net_ok(x, train_params):  # a deterministic actor's rollout pass: ONE launch, nothing kept
             (l1, act), (l2, _), (l3, out_act) = layers
             out = th.empty(x.shape[0], l3.out_features, dtype=x.dtype, device=x.device)
@@ -237,23 +282,27 @@ class _ActorGroupFn(th.autograd.Function):
 
     @staticmethod
     def forward(ctx, out, group, inputs, col_ranges, agent: int, *owners):
-        acts_i = group._run(inputs, out, col_ranges, keep=agent)  # agent's per-layer outputs (contiguous), last one included
+        acts_i = group._run(inputs, out, col_ranges, keep=agent)  # agent's per-layer outputs; the last one is its column block of `out`
         ctx.group, ctx.agent, ctx.cols = group, agent, col_ranges[agent]
-        ctx.save_for_backward(inputs[agent], *acts_i)
+        ctx.save_for_backward(inputs[agent], *acts_i[:-1])
+        ctx.y_last = acts_i[-1]
         ctx.mark_dirty(out)
         return out
 
     @staticmethod
     def backward(ctx, g_out):
         x0, *ys = ctx.saved_tensors
+        ys.append(ctx.y_last)
         layers = ctx.group.mlps[ctx.agent].layers
         lo, hi = ctx.cols
-        gz = g_out[:, lo:hi].contiguous()
+        if g_out.stride(1) != 1:
+            g_out = g_out.contiguous()
+        gz = g_out[:, lo:hi]
         last_act = layers[-1][1]
         if last_act != ACT_NONE:
-            dz = th.empty_like(gz)
-            hip_ops.bias_act_bwd(gz, ys[-1], last_act, dz, None)
-            gz = dz
+            gz = hip_ops.bias_act_bwd_rows(gz, ys[-1], last_act, th.empty(gz.shape, dtype=gz.dtype, device=gz.device))
+        else:
+            gz = gz.contiguous()
         for li in range(len(layers) - 1, -1, -1):
             lin = layers[li][0]
             x = x0 if li == 0 else ys[li - 1]
@@ -286,20 +335,15 @@ class FastActorGroup:
             act = self.mlps[0].layers[li][1]
             n = self.mlps[0].layers[li][0].out_features
             last = li == n_layers - 1
-            if last:
+            if last:  # (the differentiated agent's backward reads its column block in place: cstr_bias_act_bwd_rows_f32)
                 ys = [out[:, lo:hi] for lo, hi in col_ranges]
-                if keep is not None:  # the differentiated agent's output is also needed contiguously by its backward
-                    ys[keep] = th.empty(m, n, dtype=out.dtype, device=out.device)
             else:
                 buf = th.empty(len(self.mlps), m, n, dtype=out.dtype, device=out.device)
                 ys = [buf[j] for j in range(len(self.mlps))]
             hip_ops.linear_act_fwd_sets([(hs[j], self.mlps[j].layers[li][0].weight, self.mlps[j].layers[li][0].bias, ys[j])
                                          for j in range(len(self.mlps))], act)
             if keep is not None:
-                kept.append(ys[keep])
-                if last:
-                    lo, hi = col_ranges[keep]
-                    out[:, lo:hi].copy_(ys[keep])
+                kept.append(ys[keep].detach() if last else ys[keep])
             hs = ys
         return kept
 

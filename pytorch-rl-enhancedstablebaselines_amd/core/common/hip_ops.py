@@ -331,6 +331,20 @@ def bias_act_bwd(gy, y, act: int, gz, gbias):
                                          stream_ptr()), "cstr_bias_act_bwd_f32")
 
 
+def bias_act_bwd_rows(gy, y, act: int, gz, gbias=None):
+    """`bias_act_bwd` for one group whose gy / y may be column blocks of wider row-major matrices (row-strided views); gz is a
+    contiguous [M, N] tensor."""
+    m, n = gz.shape
+    _chk(gz, "gz", (m, n), th.float32)
+    ldg = _rows(gy, "gy", m, n)
+    ldy = _rows(y, "y", m, n) if act != 0 else n
+    if gbias is not None and _f32c(gbias, "gbias").numel() != n:
+        raise ValueError(f"gbias has {gbias.numel()} elements, expected {n}")
+    check(nv.lib().cstr_bias_act_bwd_rows_f32(ptr(gy), C.c_int64(ldg), ptr(y if act != 0 else None), C.c_int64(ldy), C.c_int(act), ptr(gz),
+                                              ptr(gbias), C.c_int64(m), C.c_int64(n), stream_ptr()), "cstr_bias_act_bwd_rows_f32")
+    return gz
+
+
 def new_rng_ctl(seed: int, device) -> th.Tensor:
     """{seed, offset, ticket, -, sub-tickets[8], -} of the in-kernel Philox stream (cstr_gaussian_head_fwd_f32), int64 bit patterns"""
     return th.tensor([int(seed) & 0x7FFFFFFFFFFFFFFF] + [0] * (nv.RNG_CTL_WORDS - 1), dtype=th.int64).to(device)

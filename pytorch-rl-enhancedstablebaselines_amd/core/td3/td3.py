@@ -74,7 +74,7 @@ class TD3(OffPolicyAlgorithm):
 
     def _packed_batch(self, batch_size: int):
         if self._packed is None or self._packed.x_data.shape[0] != batch_size:
-            self._packed = self.replay_buffer.alloc_packed_batch(batch_size, with_pi=False)
+            self._packed = self.replay_buffer.alloc_packed_batch(batch_size)  # x_pi: the actor writes its action into the critic input
             self._static_batch = self._packed.samples
             self._target_q = th.empty(batch_size, 1, dtype=th.float32, device=self.device)
             self._act_t = th.empty(batch_size, self._packed.act_dim, dtype=th.float32, device=self.device)
@@ -213,8 +213,14 @@ class TD3(OffPolicyAlgorithm):
         self.critic.optimizer.step()
         actor_done = False
         if n_updates % self.policy_delay == 0:  # :192-206
-            a = self._fast_actor(rd.observations)
-            qs_pi = self._fast_critic(rd.observations, a, train_params=False, only_first=True)
+            if pb is not None and fused.USE_FUSED_LINEAR and self._fast_actor.layers[-1][0].out_features > 1:
+                # the actor's last layer writes into x_pi = (obs | .): no torch.cat, and its backward reads the action columns
+                # of the critic's input gradient in place
+                x_pi = self._fast_actor(rd.observations, xbuf=pb.x_pi.detach())
+                qs_pi = self._fast_critic.forward_input(x_pi, train_params=False, only_first=True)
+            else:
+                a = self._fast_actor(rd.observations)
+                qs_pi = self._fast_critic(rd.observations, a, train_params=False, only_first=True)
             a_out, a_sum = (s["actor"], None) if single else (self._loss_now["actor"], s["actor"])
             hip_ops.neg_mean_loss(qs_pi[0], gq1, a_out, a_sum)
             fused.backward_q(qs_pi, gq)

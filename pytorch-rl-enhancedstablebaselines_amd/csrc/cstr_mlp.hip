@@ -55,9 +55,11 @@ __global__ void bias_act_fwd_vec4_kernel(float4 *__restrict__ y, const float4 *_
 // gradient's sum over the batch). One workgroup owns 64 columns: lanes run along columns (coalesced 256-B row
 // segments), its WAVES waves stride over the rows with four rows of loads in flight per wave (the kernel is pure
 // latency at batch 256), LDS combines the waves; every gbias element is written exactly once -> deterministic.
+// `ldg` / `ldy`: row strides of gy / y (n for contiguous tensors; a column block of a wider row-major matrix otherwise, one group)
 template <int ACT, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void bias_act_bwd_kernel(const float *gy, const float *__restrict__ y, float *gz,
-                                                                  float *__restrict__ gbias, const int m, const int n)
+                                                                  float *__restrict__ gbias, const int m, const int n,
+                                                                  const int64_t ldg, const int64_t ldy)
 {
     __shared__ float part[WAVES][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -75,9 +77,8 @@ __global__ __launch_bounds__(WAVES * 64) void bias_act_bwd_kernel(const float *g
 #pragma unroll
             for (int k = 0; k < FLY; ++k) {
                 const int r = r0 + k * WAVES;
-                const int64_t i = (int64_t)r * n + col;
-                g[k] = r < m ? gy[i] : 0.0f;
-                t[k] = (ACT != ACT_NONE && r < m) ? y[i] : 0.0f;
+                g[k] = r < m ? gy[(int64_t)r * ldg + col] : 0.0f;
+                t[k] = (ACT != ACT_NONE && r < m) ? y[(int64_t)r * ldy + col] : 0.0f;
             }
 #pragma unroll
             for (int k = 0; k < FLY; ++k) {
@@ -1757,19 +1758,31 @@ extern "C" int cstr_bias_act_fwd_f32(float *y, const float *bias, int act, int64
 extern "C" int cstr_bias_act_bwd_f32(const float *gy, const float *y, int act, float *gz, float *gbias, int64_t groups, int64_t m,
                                      int64_t n, cstr_stream_t stream)
 {
-    if (!gy || !gz || groups <= 0 || m <= 0 || n <= 0 || (act != 0 && !y)) return CSTR_E_BADARG;
+    if (groups <= 0) return CSTR_E_BADARG;
+    if (groups == 1) return cstr_bias_act_bwd_rows_f32(gy, n, y, n, act, gz, gbias, m, n, stream);
+    if (!gy || !gz || m <= 0 || n <= 0 || (act != 0 && !y)) return CSTR_E_BADARG;
     if (act < 0 || act > 2 || m > 0x7fffffff || n > 0x7fffffff || groups > 65535) return CSTR_E_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid((unsigned)((n + 63) / 64), (unsigned)groups);
-    if (m >= 64) {  // 16 waves per workgroup: 16 rows per wave at batch 256
-        if (act == 0) bias_act_bwd_kernel<0, 16><<<grid, 1024, 0, s>>>(gy, y, gz, gbias, (int)m, (int)n);
-        else if (act == 1) bias_act_bwd_kernel<1, 16><<<grid, 1024, 0, s>>>(gy, y, gz, gbias, (int)m, (int)n);
-        else bias_act_bwd_kernel<2, 16><<<grid, 1024, 0, s>>>(gy, y, gz, gbias, (int)m, (int)n);
-    } else {
-        if (act == 0) bias_act_bwd_kernel<0, 4><<<grid, 256, 0, s>>>(gy, y, gz, gbias, (int)m, (int)n);
-        else if (act == 1) bias_act_bwd_kernel<1, 4><<<grid, 256, 0, s>>>(gy, y, gz, gbias, (int)m, (int)n);
-        else bias_act_bwd_kernel<2, 4><<<grid, 256, 0, s>>>(gy, y, gz, gbias, (int)m, (int)n);
-    }
+#define BAB(A, W) bias_act_bwd_kernel<A, W><<<grid, 64 * W, 0, s>>>(gy, y, gz, gbias, (int)m, (int)n, n, n)
+    if (m >= 64) { if (act == 0) BAB(0, 16); else if (act == 1) BAB(1, 16); else BAB(2, 16); }  // 16 rows per wave at batch 256
+    else { if (act == 0) BAB(0, 4); else if (act == 1) BAB(1, 4); else BAB(2, 4); }
+#undef BAB
+    return (int)hipGetLastError();
+}
+
+extern "C" int cstr_bias_act_bwd_rows_f32(const float *gy, int64_t ldg, const float *y, int64_t ldy, int act, float *gz, float *gbias,
+                                          int64_t m, int64_t n, cstr_stream_t stream)
+{
+    if (!gy || !gz || m <= 0 || n <= 0 || ldg < n || (act != 0 && (!y || ldy < n))) return CSTR_E_BADARG;
+    if (act < 0 || act > 2 || m > 0x7fffffff || n > 0x7fffffff) return CSTR_E_UNSUPPORTED;
+    if (gz == gy && ldg != n) return CSTR_E_BADARG;  // gz is contiguous [m][n]
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid((unsigned)((n + 63) / 64), 1u);
+#define BAB(A, W) bias_act_bwd_kernel<A, W><<<grid, 64 * W, 0, s>>>(gy, y, gz, gbias, (int)m, (int)n, ldg, ldy)
+    if (m >= 64) { if (act == 0) BAB(0, 16); else if (act == 1) BAB(1, 16); else BAB(2, 16); }
+    else { if (act == 0) BAB(0, 4); else if (act == 1) BAB(1, 4); else BAB(2, 4); }
+#undef BAB
     return (int)hipGetLastError();
 }
 
