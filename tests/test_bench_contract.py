@@ -35,23 +35,24 @@ def test_world_size_mismatch_is_refused():
 
 
 @pytest.mark.gpu
-def test_bench_gpus_2_launches_two_ranks_by_itself():
-    """The plain command the driver's SCALE run issues, rehearsed on ONE MI355X: both ranks on cuda:0, gloo transport (RCCL
+@pytest.mark.parametrize("n", [2, 4])
+def test_bench_gpus_n_launches_its_ranks_by_itself(n):
+    """The plain command the driver's SCALE run issues, rehearsed on ONE MI355X: all ranks on cuda:0, gloo transport (RCCL
     refuses two ranks on one device). Asserts the line's own proof of the rank count and the honesty keys."""
-    r = _run(["--gpus", "2", "--steps", "10", "--warmup", "5", "--no-cpu-baseline", "--no-roofline"],
+    r = _run(["--gpus", str(n), "--steps", "10", "--warmup", "5", "--no-cpu-baseline", "--no-roofline"],
              env=dict(CSTR_DIST_BACKEND="gloo", CSTR_BENCH_SINGLE_DEVICE="1"))
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, r.stdout
     rec = json.loads(lines[0])
-    assert rec["n_gpus"] == 2 and rec["rccl_world"] == 2 and rec["config"]["parallelism"] == "dp2"
-    assert rec["allreduce_checksum"] == dict(expected=3, got=3, backend="gloo")
+    assert rec["n_gpus"] == n and rec["rccl_world"] == n and rec["config"]["parallelism"] == f"dp{n}"
+    assert rec["allreduce_checksum"] == dict(expected=n * (n + 1) // 2, got=n * (n + 1) // 2, backend="gloo")
     assert rec["weights_identical_across_ranks"] is True
     assert rec["graph_collectives"] == "segmented"  # gloo collectives are never recorded into a hipGraph
     assert rec["hip_graph_active"] is True and rec["eager_iterations_in_timed_region"] == 0
     assert rec["hip_graph_replays_in_timed_region"] == rec["timed_steps_total"] >= rec["steps"] == 10
     assert rec["timed_seconds_total"] >= 0.25  # a 10-step region is ~2 ms: it must have been repeated
-    assert rec["config"]["global_batch"] == 512 and rec["scaling"] == "weak"
+    assert rec["config"]["global_batch"] == 256 * n and rec["scaling"] == "weak"
 
 
 @pytest.mark.gpu
