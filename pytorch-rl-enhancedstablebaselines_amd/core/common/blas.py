@@ -1,6 +1,9 @@
-"""GEMM back-end selection for the MLP forward/backward (which stay on PyTorch-ROCm, north_star).
+"""GEMM back-end selection for the GEMMs that PyTorch-ROCm still evaluates: every GEMM of the learners with CSTR_FUSED_LINEAR=0
+(the north_star-literal configuration, `mlp_on_pytorch_rocm_variant` in bench.py) and of the stock-ATen fallback, and the
+shapes outside the hand-written f32-MFMA Linear kernels' range (more than 1024 rows with a wide input) otherwise -- the default
+SAC / TD3 iteration issues no rocBLAS launch any more (profiles/r02_bench_sac_kernel_stats.csv).
 
-Measured on MI355X (profiles/r1_*): for this path's shapes -- batch 256..4096, width 256 -- hipBLASLt's
+Measured on MI355X (profiles/r01_bench_eager_hipblaslt_kernel_stats.csv): for this path's shapes -- batch 256..4096, width 256 -- hipBLASLt's
 heuristic picks a 256x256 macro-tile kernel: a [256,256]x[256,256] GEMM becomes ONE workgroup on a 256-CU chip
 (38-64 us per GEMM, 70 % of the iteration's GPU time). rocBLAS' Tensile kernels for the same shapes take a few
 microseconds. `configure()` therefore prefers rocBLAS and routes `addmm` (nn.Linear with bias) away from the

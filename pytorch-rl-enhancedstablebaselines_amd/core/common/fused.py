@@ -1,15 +1,17 @@
-"""Fused learner path: the MLPs' GEMMs stay in PyTorch-ROCm (`torch.mm` -> rocBLAS), everything around them is
-a hand-written HIP kernel, and gradients are written STRAIGHT into the flat arena:
+"""Fused learner path: every Linear layer of the learners at batch size is ONE hand-written f32-MFMA launch with its bias and
+activation (backward: the input gradient times the activation gradient of the layer below in one launch, dW + db of ALL layers of
+an MLP in one pointer-table launch), everything around them is a hand-written HIP kernel too, and gradients are written STRAIGHT
+into the flat arena (no AccumulateGrad adds, no zero_grad memsets: every parameter's gradient is (over)written exactly once per
+backward; frozen parameters -- the critic during the actor loss -- skip the weight / bias launches entirely). CSTR_FUSED_LINEAR=0
+leaves every GEMM to PyTorch-ROCm (`torch.mm` -> rocBLAS) with the HIP epilogues around it (the north_star-literal form).
 
-  * `linear(x, W, b, act)`   = 1 GEMM + 1 epilogue launch (bias + ReLU/Tanh);
-    backward                 = 1 epilogue-backward launch (activation gradient + bias gradient into the arena)
-                               + `torch.mm(gz^T, x, out=<arena view of W.grad>)` + `torch.mm(gz, W)`.
-    No AccumulateGrad adds, no zero_grad memsets: every parameter's gradient is (over)written exactly once per
-    backward; frozen parameters (critic during the actor loss) skip the weight/bias GEMMs entirely.
-  * twin critics = ONE chain of batched GEMMs over stacked arena views; the actor's mu / log_std heads = ONE GEMM;
-  * a Q network's last hidden layer + scalar head (`hidden_head`) = 1 GEMM + 1 launch: the n = 1 head is a matrix-vector
-    product folded into the hidden layer's epilogue (rocBLAS runs it as an 8 us degenerate GEMM); backward = 1 launch for
-    the head's three gradients and the activation gradient, + the hidden layer's two GEMMs;
+  * twin critics = ONE chain of grouped launches over stacked arena views; the critic and the TARGET critic of a gradient step =
+    ONE four-network pointer-table chain (`_TwinPairFn`); the actor's mu / log_std heads = one head kernel;
+  * SAC's pi(obs) and pi(next_obs) = ONE 2B-row actor pass, backward on the B differentiated rows (`_ActorPairFn`);
+  * a Q network's last hidden layer + scalar head (`hidden_head`) = 1 GEMM launch + 1 launch; its backward's first launch can
+    carry the loss that roots it (`set_loss_root`: TD critic loss, SAC actor loss);
+  * deterministic actors write their action into the critic input and read its gradient columns in place (`_LinearXbufFn`,
+    `_ActorGroupFn`): no torch.cat, no gather copies;
   * `squashed_gaussian([mean | log_std], eps)` = 1 launch forward, 1 launch backward (analytic).
 
 The nn.Modules keep owning the parameters (state_dict / API); `FastMLP` only reads their tensors. Arithmetic per

@@ -3,7 +3,7 @@
 
 Reference iteration (per vec-step): python loop over N envs, deepcopy of N info dicts, 5 H2D copies per
 sample, 4 `.item()` syncs per gradient step. Here, when the env is a `CSTRVecEnv` and the buffer is the HBM
-`ReplayBuffer`, one iteration is: actor forward (PyTorch-ROCm, no_grad) -> ONE fused HIP launch
+`ReplayBuffer`, one iteration is: actor forward (one whole-network HIP launch above 1024 envs) -> ONE fused HIP launch
 (action scaling chain + env step + auto-reset + ring row write + episode statistics) -> `train()`. Nothing
 returns to the host except, every `stats_sync_interval` vec-steps, four doubles of episode statistics.
 Any other VecEnv goes through the NumPy compatibility path with the reference's exact semantics.
