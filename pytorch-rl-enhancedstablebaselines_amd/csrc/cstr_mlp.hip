@@ -1,12 +1,16 @@
-// cstr_mlp.hip -- element-wise / reduction glue of the learner for gfx950. The dense contractions stay in
-// PyTorch-ROCm (rocBLAS GEMMs, north_star); everything around them that the reference leaves to dozens of tiny
-// ATen kernels per step is fused here:
-//   * Linear epilogues: bias + activation forward; activation-gradient + bias-gradient (column sum) backward
-//   * SAC's squashed-Gaussian head: rsample -> tanh -> log-prob forward, analytic backward
+// cstr_mlp.hip -- the learners' MLP kernels for gfx950 (f32 matrix cores: v_mfma_f32_16x16x4_f32, exact f32 fma chains):
+//   * Linear + bias + activation forward, input gradient x activation gradient of the layer below, dW + db: one launch each,
+//     grouped (stacked twin critics) and pointer-table ("sets") forms;
+//   * the rollout's WHOLE policy network + sampling in one launch (policy_rows_v2_kernel: role-split waves, register-resident
+//     or register-pipelined B operand from a tile-major weight copy, split-K MFMA head, per-(row, action) sampling tail);
+//   * SAC's squashed-Gaussian head (in-kernel Philox noise): rsample -> tanh -> log-prob forward, analytic backward, also carried
+//     through the head's Linear;
+//   * a Q network's last hidden layer epilogue + scalar head, forward and backward; the backward form with the LOSS ROOT inside
+//     (TD critic loss, SAC actor loss: the loss launch and the backward's first launch are one);
 //   * loss heads that are backward ROOTS (upstream gradient == 1): the kernels emit the loss value AND d(loss)/d(Q),
-//     d(loss)/d(logp) directly, so no autograd nodes exist for the losses
-//   * SAC's entropy-coefficient loss/gradient
-// All latency-bound at batch 256; 64-wide waves, LDS tree reductions, deterministic (no atomics).
+//     d(loss)/d(logp) directly, so no autograd nodes exist for the losses; SAC's entropy-coefficient loss / gradient;
+//   * epilogue kernels around rocBLAS GEMMs for the CSTR_FUSED_LINEAR=0 configuration.
+// All latency-bound at batch 256; 64-wide waves, LDS tree reductions, deterministic (no float atomics).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
