@@ -71,3 +71,40 @@ def test_hip_ops_refuse_cpu_tensors():
 
     with pytest.raises(ValueError, match="No CPU fallback"):
         hip_ops.polyak(th.zeros(8), th.zeros(8), 0.005)
+
+
+def test_round2_entry_points_reject_bad_arguments_on_the_host():
+    """cstr_hidden_head_bwd_root_f32, cstr_bias_act_bwd_rows_f32, cstr_collect_step_rng_f32 and the policy launch's flag word:
+    argument checks fail before anything is dereferenced or launched."""
+    lib = nv.lib()
+    null, fake = C.c_void_p(None), C.c_void_p(0x1000)
+    i64, f32 = C.c_int64, C.c_float
+    # loss root: NULL struct, unknown mode, batch != m, missing mode-1 / mode-2 pointers, too many rows
+    assert lib.cstr_hidden_head_bwd_root_f32(null, fake, 1, fake, fake, null, null, null, i64(256), i64(256), null) == -1
+    rt = nv.HeadRoot(3, 256, 0.99, 1.0, 0x1000, 0x1000, None, 0x1000, 0x1000, None, 0x1000, 0x1000, None, None, None, None, None, nv.AlphaPart())
+    assert lib.cstr_hidden_head_bwd_root_f32(C.byref(rt), fake, 1, fake, fake, null, null, null, i64(256), i64(256), null) == -1
+    rt.mode, rt.batch = 1, 128
+    assert lib.cstr_hidden_head_bwd_root_f32(C.byref(rt), fake, 1, fake, fake, null, null, null, i64(256), i64(256), null) == -1
+    rt.batch, rt.rew = 256, None
+    assert lib.cstr_hidden_head_bwd_root_f32(C.byref(rt), fake, 1, fake, fake, null, null, null, i64(256), i64(256), null) == -1
+    rt.rew, rt.mode = 0x1000, 2  # mode 2 needs logp, g_logp, ent_coef
+    assert lib.cstr_hidden_head_bwd_root_f32(C.byref(rt), fake, 1, fake, fake, null, null, null, i64(256), i64(256), null) == -1
+    rt.mode, rt.batch = 1, 2048
+    assert lib.cstr_hidden_head_bwd_root_f32(C.byref(rt), fake, 1, fake, fake, null, null, null, i64(2048), i64(256), null) == -2
+    rt.batch = 256  # gb1 / gw2 / gb2 go together
+    assert lib.cstr_hidden_head_bwd_root_f32(C.byref(rt), fake, 1, fake, fake, fake, null, null, i64(256), i64(256), null) == -1
+    # strided bias / activation backward: row stride below the width, missing y for an activation, in-place with a strided gy
+    assert lib.cstr_bias_act_bwd_rows_f32(fake, i64(3), fake, i64(4), 2, fake, null, i64(8), i64(4), null) == -1
+    assert lib.cstr_bias_act_bwd_rows_f32(fake, i64(6), null, i64(6), 2, fake, null, i64(8), i64(4), null) == -1
+    assert lib.cstr_bias_act_bwd_rows_f32(fake, i64(6), fake, i64(6), 0, fake, null, i64(8), i64(4), null) == -1
+    assert lib.cstr_bias_act_bwd_rows_f32(fake, i64(6), fake, i64(6), 5, C.c_void_p(0x2000), null, i64(8), i64(4), null) == -2
+    # the collect step's rng form shares the checks of the plain one
+    coef = nv.default_coef()
+    ring = nv.Ring(0x1000, 0x1000, 0x1000, 0x1000, 0x1000, 0x1000, 4, 8, 4, 2)
+    lo = (C.c_float * 2)(-1, -1)
+    hi = (C.c_float * 2)(1, 1)
+    assert lib.cstr_collect_step_rng_f32(C.byref(coef), 0, C.byref(ring), fake, fake, fake, fake, 1, lo, hi, null, null, null, null, null, null,
+                                         null, null, fake, C.c_uint64(8), null) == -1  # no reset source
+    # the policy launch's flag word: only bit 0 is defined
+    net = nv.PolicyMlp(4, 64, 64, 2, 1, 0, 0, 2, 0x1000, 0x1000, 0x1000, 0x1000, 0x1000, 0x1000, None)
+    assert lib.cstr_policy_rows_fwd_f32(C.byref(net), fake, i64(4), null, fake, fake, i64(2), null, i64(16), null) == -1
