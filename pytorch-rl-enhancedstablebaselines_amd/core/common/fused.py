@@ -457,6 +457,20 @@ def loss_root_pending() -> bool:
     return _pending_root is not None
 
 
+@contextlib.contextmanager
+def loss_root(root: Optional[dict]):
+    """`set_loss_root(root)` for the backward call inside the block; on leaving, the root must have been consumed by that backward
+    (else the graph did not start with the twin hidden-head launch: a programming error) and is cleared in any case, so an
+    exception inside the block cannot leave a stale root for an unrelated backward."""
+    set_loss_root(root)
+    try:
+        yield
+        if root is not None and _pending_root is not None:
+            raise RuntimeError("loss root not consumed: the backward did not pass through the twin hidden-head launch")
+    finally:
+        set_loss_root(None)
+
+
 LOSS_ROOT_MAX_ROWS = 1024  # cstr_hidden_head_bwd_root_f32 keeps the per-row gradients in LDS
 
 

@@ -350,16 +350,17 @@ class MADDPG(OffPolicyAlgorithm):
                 qs = self._fast_critics[i].forward_input(x_cur)  # :154
             scale = 1.0 if len(qs) == 2 else 0.5
             root = len(qs) == 2 and qs.stacked is not None and B <= fused.LOSS_ROOT_MAX_ROWS and fused.loss_root_supported(self._fast_critics[i])
+            td_root = None
             if root:  # TD target (:148-151) + critic loss (:157-159) inside the critic backward's first launch
-                fused.set_loss_root(dict(mode="td", q1_t=qs_t[0], q2_t=qs_t[-1], next_logp=None, rew=rd.rewards, done=rd.dones, ent_coef=None,
-                                         gamma=self.gamma, scale=scale, q1=qs[0].detach(), q2=qs[-1].detach(), target_out=self._target_q[i],
-                                         loss_out=self._loss_now, loss_sum=self._loss_sums[f"critic{i}"], alpha=None))
+                td_root = dict(mode="td", q1_t=qs_t[0], q2_t=qs_t[-1], next_logp=None, rew=rd.rewards, done=rd.dones, ent_coef=None,
+                               gamma=self.gamma, scale=scale, q1=qs[0].detach(), q2=qs[-1].detach(), target_out=self._target_q[i],
+                               loss_out=self._loss_now, loss_sum=self._loss_sums[f"critic{i}"], alpha=None)
             else:  # TD target + critic loss in one launch
                 hip_ops.td_twin_q_loss(qs_t[0], qs_t[-1], None, rd.rewards, rd.dones, None, self.gamma, qs[0], qs[-1], scale,
                                        self._target_q[i], gq[0], gq[1], self._loss_now, self._loss_sums[f"critic{i}"])
             if len(qs) == 2:
-                fused.backward_q(qs, gq)  # :162-164
-                assert not fused.loss_root_pending(), "the critic backward did not start with the twin hidden-head launch"
+                with fused.loss_root(td_root):
+                    fused.backward_q(qs, gq)  # :162-164
             else:
                 with fused.deferred_weight_grads():
                     th.autograd.backward([qs[0]], [gq[0] + gq[1]])

@@ -218,19 +218,20 @@ class SAC(OffPolicyAlgorithm):
             ent_coef, alpha = self.ent_coef_tensor.reshape(1), None
             s["ent_coef"] += ent_coef
         root = qs.stacked is not None and B <= fused.LOSS_ROOT_MAX_ROWS and fused.loss_root_supported(self._fast_critic)
+        td_root = None
         if root:  # the three reductions ride in the critic backward's first launch (cstr_hidden_head_bwd_root_f32)
-            fused.set_loss_root(dict(mode="td", q1_t=q1_t, q2_t=q2_t, next_logp=next_log_prob, rew=rd.rewards, done=rd.dones,
-                                     ent_coef=ent_coef, gamma=self.gamma, scale=0.5, q1=q1.detach(), q2=q2.detach(), target_out=self._target_q,
-                                     loss_out=sto("critic", self._loss_now["critic"]), loss_sum=acc("critic"), alpha=alpha))
+            td_root = dict(mode="td", q1_t=q1_t, q2_t=q2_t, next_logp=next_log_prob, rew=rd.rewards, done=rd.dones,
+                           ent_coef=ent_coef, gamma=self.gamma, scale=0.5, q1=q1.detach(), q2=q2.detach(), target_out=self._target_q,
+                           loss_out=sto("critic", self._loss_now["critic"]), loss_sum=acc("critic"), alpha=alpha)
         else:
             hip_ops.td_twin_q_loss(q1_t, q2_t, next_log_prob, rd.rewards, rd.dones, ent_coef, self.gamma, q1, q2, 0.5, self._target_q,
                                    gq1, gq2, sto("critic", self._loss_now["critic"]), acc("critic"), alpha=alpha)
             if self.ent_coef_optimizer is not None and not self._ent_rides_critic:
                 self._allreduce_grads(self._ent_arena)
                 self.ent_coef_optimizer.step()
-        fused.backward_q(qs, gq)  # :266-268
+        with fused.loss_root(td_root):
+            fused.backward_q(qs, gq)  # :266-268
         if root:
-            assert not fused.loss_root_pending(), "the critic backward did not start with the twin hidden-head launch"
             if self.ent_coef_optimizer is not None and not self._ent_rides_critic:
                 self._allreduce_grads(self._ent_arena)
                 self.ent_coef_optimizer.step()
@@ -246,18 +247,17 @@ class SAC(OffPolicyAlgorithm):
                  else self._fast_critic(rd.observations, actions_pi, train_params=False))
         q1_pi, q2_pi = qs_pi
         root = qs_pi.stacked is not None and B <= fused.LOSS_ROOT_MAX_ROWS and fused.loss_root_supported(self._fast_critic)
+        actor_root = None
         if root:  # the actor loss rides in the first launch of the backward through the (frozen) critic
-            fused.set_loss_root(dict(mode="sac_actor", logp=log_prob.detach(), q1=q1_pi.detach(), q2=q2_pi.detach(), ent_coef=ent_coef, g_logp=g_lp,
-                                     loss_out=sto("actor", self._loss_now["actor"]), loss_sum=acc("actor")))
+            actor_root = dict(mode="sac_actor", logp=log_prob.detach(), q1=q1_pi.detach(), q2=q2_pi.detach(), ent_coef=ent_coef, g_logp=g_lp,
+                              loss_out=sto("actor", self._loss_now["actor"]), loss_sum=acc("actor"))
         else:
             hip_ops.sac_actor_loss(log_prob, q1_pi, q2_pi, ent_coef, g_lp, gq1, gq2, sto("actor", self._loss_now["actor"]), acc("actor"))
-        with fused.deferred_weight_grads():  # :279-281; the actor's dW / db of all layers in one launch
+        with fused.loss_root(actor_root), fused.deferred_weight_grads():  # :279-281; the actor's dW / db of all layers in one launch
             if qs_pi.stacked is not None:
                 th.autograd.backward([log_prob, qs_pi.stacked], [g_lp, gq])
             else:
                 th.autograd.backward([log_prob, q1_pi, q2_pi], [g_lp, gq1, gq2])
-        if root:
-            assert not fused.loss_root_pending(), "the actor backward did not pass through the twin hidden-head launch"
         self._allreduce_grads(pol.actor_arena)
         if gradient_step % self.target_update_interval == 0:  # :281 and :284-287 (disjoint arenas) in one launch
             self.actor.optimizer.step_with(polyak=(pol.critic_arena, pol.critic_target_arena, self.tau))

@@ -196,16 +196,17 @@ class TD3(OffPolicyAlgorithm):
         single = getattr(self, "_single_step", False)
         c_out, c_sum = (s["critic"], None) if single else (self._loss_now["critic"], s["critic"])
         root = len(qs) == 2 and qs.stacked is not None and B <= fused.LOSS_ROOT_MAX_ROWS and fused.loss_root_supported(self._fast_critic)
+        td_root = None
         if root:
-            fused.set_loss_root(dict(mode="td", q1_t=q1_t, q2_t=q2_t, next_logp=None, rew=rd.rewards, done=rd.dones, ent_coef=None,
-                                     gamma=self.gamma, scale=1.0, q1=q1.detach(), q2=q2.detach(), target_out=self._target_q,
-                                     loss_out=c_out, loss_sum=c_sum, alpha=None))
+            td_root = dict(mode="td", q1_t=q1_t, q2_t=q2_t, next_logp=None, rew=rd.rewards, done=rd.dones, ent_coef=None,
+                           gamma=self.gamma, scale=1.0, q1=q1.detach(), q2=q2.detach(), target_out=self._target_q,
+                           loss_out=c_out, loss_sum=c_sum, alpha=None)
         else:
             hip_ops.td_twin_q_loss(q1_t, q2_t, None, rd.rewards, rd.dones, None, self.gamma, q1, q2, 1.0 if len(qs) == 2 else 0.5,
                                    self._target_q, gq1, gq2, c_out, c_sum)
         if len(qs) == 2:
-            fused.backward_q(qs, gq)
-            assert not fused.loss_root_pending(), "the critic backward did not start with the twin hidden-head launch"
+            with fused.loss_root(td_root):
+                fused.backward_q(qs, gq)
         else:
             with fused.deferred_weight_grads():
                 th.autograd.backward([q1], [gq1 + gq2])
