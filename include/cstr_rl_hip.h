@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define CSTR_ABI_VERSION 3
+#define CSTR_ABI_VERSION 4
 
 #define CSTR_OK 0
 #define CSTR_E_BADARG (-1)      /* null pointer / non-positive size / misaligned buffer */
@@ -198,6 +198,16 @@ int cstr_replay_sample_mt19937_f32(const cstr_ring_t *ring, const int64_t *ring_
 int cstr_replay_sample_packed_mt19937_f32(const cstr_ring_t *ring, const int64_t *ring_ctl, uint32_t *mt_state, int64_t batch,
                                           float *x_data, float *x_next, float *x_pi, float *out_done, float *out_rew,
                                           int64_t *out_row_idx, int64_t *out_env_idx, cstr_stream_t stream);
+
+/* The gather half of that call for index pairs drawn earlier in the iteration (cstr_rollout_step_f32): sample_idx int32
+ * [2][batch] = { batch_inds, env_indices } (core/common/buffers.py:113, :309). ONE workgroup, which also performs the
+ * control-word updates the rollout launch leaves to its successor: advance_ring != 0 = ReplayBuffer.add's epilogue on
+ * ring_ctl (pos, full, adds; core/common/buffers.py:280-283), rng_ctl (may be NULL) = the rollout policy's Philox control
+ * block, whose offset grows by rng_advance. Both happen after the gather, so the gather reads the ring by the given indices only. */
+int cstr_replay_gather_packed_f32(const cstr_ring_t *ring, int64_t *ring_ctl, int advance_ring, uint64_t *rng_ctl,
+                                  uint64_t rng_advance, const int32_t *sample_idx, int64_t batch, float *x_data, float *x_next,
+                                  float *x_pi, float *out_done, float *out_rew, int64_t *out_row_idx, int64_t *out_env_idx,
+                                  cstr_stream_t stream);
 
 /* Target-Q: SAC core/sac/sac.py:250-254 (logp, ent_coef non-NULL), TD3 core/td3/td3.py:174-176 (both NULL):
  * out = rew + (1 - done) * gamma * (min(q1, q2) - ent_coef[0] * logp). ent_coef is a DEVICE scalar. */
@@ -380,6 +390,25 @@ typedef struct cstr_policy_mlp {
 int cstr_policy_swizzle_f32(const float *w, int64_t n, int64_t k, float *out, cstr_stream_t stream);
 int cstr_policy_rows_fwd_f32(const cstr_policy_mlp_t *net, const float *x, int64_t ldx, const float *eps, uint64_t *rng_ctl,
                              float *action, int64_t action_stride, float *logp, int64_t m, cstr_stream_t stream);
+
+/* One vec-step of collect_rollouts in ONE launch (core/common/off_policy_algorithm.py:510-605 for a device-resident vec-env):
+ * the policy network + sampling of cstr_policy_rows_fwd_f32 on x [n_envs][k0] (the policy's view of the observations: env_obs
+ * itself, or its normalised image), then -- on the sampling tail's lanes, the action never leaving registers -- the fused
+ * collect step of cstr_collect_step_f32 for the workgroup's 16 envs (same operands, same arithmetic), and, when mt_state is
+ * given, ReplayBuffer.sample's two index draws for the gradient step behind it (core/common/buffers.py:112-113, :309; numpy
+ * legacy MT19937, masked rejection, bit-exact) on one otherwise idle wave: sample_idx int32 [2][batch] = { batch_inds,
+ * env_indices }, drawn against the ring AS THE ADD OF THIS LAUNCH LEAVES IT (upper = rows if full else pos + 1), mt_state
+ * advanced. No control word is written here: ring_ctl is only read (the row goes to position pos), the Philox offset of
+ * rng_ctl stays; the next launch must be cstr_replay_gather_packed_f32(advance_ring = 1, rng_ctl, rng_advance = n_envs), or
+ * the caller advances them another way. Needs the tile-major W2 copy (net->w2_swizzled), hidden widths <= 512, k0 <= 16 in
+ * 16-byte-aligned rows (CSTR_E_UNSUPPORTED otherwise: use the separate launches). head 0: rng_ctl required; head 1: NULL.
+ * action_out [n_envs][act_dim] or NULL: the policy output (what cstr_policy_rows_fwd_f32 would have written). */
+int cstr_rollout_step_f32(const cstr_policy_mlp_t *net, const float *x, int64_t ldx, uint64_t *rng_ctl, const cstr_coef_t *coef,
+                          int integrator, const cstr_ring_t *ring, const int64_t *ring_ctl, float *env_obs, int32_t *step_count,
+                          int squashed, const float *act_low, const float *act_high, const float *noise, const float *reset_obs,
+                          uint64_t *pcg_state, double *static_init, float *reward_out, float *done_out, float *ep_return,
+                          double *ep_stats, float *action_out, uint32_t *mt_state, int64_t batch, int32_t *sample_idx,
+                          cstr_stream_t stream);
 
 /* TD3 / MADDPG target policy smoothing (core/td3/td3.py:167-173; core/maddpg/maddpg.py:131-142) in one launch:
  * noise = clamp(N(0, sigma), -clip, clip); out = clamp(action + noise, -1, 1). action [B][A] contiguous (the target

@@ -85,6 +85,7 @@ class ReplayBuffer(BaseBuffer):
         self.rewards, self.dones, self.timeouts = r.rewards, r.dones, r.timeouts
         self._stream = sampler_stream
         self.normalizer = None  # a VecNormalize whose statistics normalise every sampled batch (buffers.py:143-155)
+        self._predrawn = None  # (sample_idx, rng_advance) of a rollout launch whose indices the next packed sample gathers
 
     # ---- pickling (save_replay_buffer / load_replay_buffer, off_policy_algorithm.py:214-254) -------------
     _FIELDS = ("observations", "next_observations", "actions", "rewards", "dones", "timeouts")
@@ -117,6 +118,7 @@ class ReplayBuffer(BaseBuffer):
         ss = st.get("sampler_stream")
         self._stream = None if ss is None else th.from_numpy(np.ascontiguousarray(ss)).to(self.device)
         self.normalizer = None
+        self._predrawn = None
 
     def to(self, device) -> "ReplayBuffer":
         """Move the ring to another GPU (load_replay_buffer: 'update saved replay buffer device', :252-253)."""
@@ -148,6 +150,7 @@ class ReplayBuffer(BaseBuffer):
         """reference: buffers.py:247-283. Accepts NumPy (compatibility) or device tensors. `infos` may be the
         reference's list of dicts or a device/NumPy vector of timeout flags."""
         n = self.n_envs
+        self._no_predrawn("ReplayBuffer.add")
         if infos is None or not self.handle_timeout_termination:
             timeout = th.zeros(n, dtype=th.float32, device=self.device)
         elif isinstance(infos, (th.Tensor, np.ndarray)):
@@ -164,6 +167,26 @@ class ReplayBuffer(BaseBuffer):
         """The fused collect kernel wrote a row and advanced the device position; keep the host mirror in step."""
         self._adds += 1
 
+    # ---- rollout launch that also draws the next sample's indices (hip_ops.rollout_step) -----------------------------
+    def predraw_indices(self, batch_size: int) -> th.Tensor:
+        """Static int32 [2, batch] buffer the rollout launch writes (batch_inds, env_indices) into."""
+        buf = getattr(self, "_predraw_buf", None)
+        if buf is None or buf.shape[1] != batch_size:
+            buf = self._predraw_buf = th.zeros(2, batch_size, dtype=th.int32, device=self.device)
+        return buf
+
+    def note_predrawn(self, sample_idx: th.Tensor, rng_advance=None) -> None:
+        """A rollout launch wrote the ring row at the device position WITHOUT advancing it and drew `sample_idx` for the sample
+        behind it: the next `sample_packed_into` must gather by these indices and advance the control words. Anything else that
+        touches the ring first is a bug in the caller (raised, not papered over)."""
+        if self._predrawn is not None:
+            raise RuntimeError("a pre-drawn sample is already pending")
+        self._predrawn = (sample_idx, rng_advance)
+
+    def _no_predrawn(self, what: str) -> None:
+        if self._predrawn is not None:
+            raise RuntimeError(f"{what}: a rollout launch left its ring advance to the next packed sample, which has not run yet")
+
     def reset(self) -> None:
         self._adds = 0
         self.ring.ctl.zero_()
@@ -178,6 +201,7 @@ class ReplayBuffer(BaseBuffer):
         """`sample` into caller-owned (static, graph-capturable) tensors."""
         if self.size() == 0:
             raise ValueError("high <= 0")  # what np.random.randint(0, 0) raises in the reference (:113)
+        self._no_predrawn("ReplayBuffer.sample")
         with th.cuda.device(self.device):
             hip_ops.replay_sample(self.ring, self.sampler_stream, out.observations.shape[0], out.observations, out.actions,
                                   out.next_observations, out.dones, out.rewards, row_idx, env_idx)
@@ -197,6 +221,14 @@ class ReplayBuffer(BaseBuffer):
             raise ValueError("high <= 0")
         if self.normalizer is not None:
             raise ValueError("packed batches do not go through VecNormalize; use sample_into")
+        if self._predrawn is not None:  # indices drawn by the rollout launch in front of this call: gather + control-word updates
+            (idx, rng_advance), self._predrawn = self._predrawn, None
+            if idx.shape[1] != pb.x_data.shape[0]:
+                raise RuntimeError(f"pre-drawn sample of {idx.shape[1]} rows, batch of {pb.x_data.shape[0]}")
+            with th.cuda.device(self.device):
+                hip_ops.replay_gather_packed(self.ring, idx, idx.shape[1], pb.x_data, pb.x_next, pb.x_pi, pb.samples.dones,
+                                             pb.samples.rewards, row_idx, env_idx, advance_ring=True, rng_advance=rng_advance)
+            return pb
         with th.cuda.device(self.device):
             hip_ops.replay_sample_packed(self.ring, self.sampler_stream, pb.x_data.shape[0], pb.x_data, pb.x_next, pb.x_pi,
                                          pb.samples.dones, pb.samples.rewards, row_idx, env_idx)

@@ -236,6 +236,20 @@ class FastMLP:
                 and hip_ops.policy_rows_supported(l1.in_features, l1.out_features, l2.out_features, l3.out_features)
                 and all(lin.weight.is_contiguous() and lin.weight.data_ptr() % 16 == 0 for lin in (l2, l3)) and l1.weight.is_contiguous())
 
+    def rollout_operands(self, obs: th.Tensor) -> Optional[dict]:
+        """This network (a deterministic actor) as operands of hip_ops.rollout_step, or None if that launch does not cover it."""
+        with th.no_grad():
+            if not self._whole_net_ok(obs, train_params=False):
+                return None
+        (l1, act), (l2, _), (l3, out_act) = self.layers
+        swz = _weight_shadow(self.optimizer, l2.weight)
+        if not hip_ops.rollout_step_supported(l1.in_features, l1.out_features, l2.out_features, l3.out_features, swz is not None):
+            return None
+        if obs.stride(0) % 4 or obs.data_ptr() % 16 or l1.weight.data_ptr() % 16 or not l3.weight.is_contiguous():
+            return None
+        return dict(weights=(l1.weight, l1.bias, l2.weight, l2.bias, l3.weight, l3.bias), act=act, head=1, out_act=out_act, w2_swz=swz,
+                    rng_ctl=None)
+
     def tail_below(self, train_params: bool):
         """what a fused consumer of this MLP's output needs to run the last layer's activation / bias gradient itself"""
         return (self.layers[-1][1], None)
@@ -603,6 +617,24 @@ class FastSacActor:
         return (hip_ops.policy_rows_supported(l1.in_features, l1.out_features, l2.out_features, 2 * self.act_dim)
                 and l1.weight.is_contiguous() and l2.weight.is_contiguous() and l2.weight.data_ptr() % 16 == 0
                 and self._hw.is_contiguous() and self._hw.data_ptr() % 16 == 0)
+
+    def rollout_operands(self, obs: th.Tensor) -> Optional[dict]:
+        """The sampling actor as operands of hip_ops.rollout_step (Philox noise from this actor's stream), or None."""
+        if self.head is None or self.act_dim > hip_ops.nv.MAX_HEAD_ACT or self.actor.action_dist.eps_queue:
+            return None
+        with th.no_grad():
+            if not self._whole_net_ok(obs, train_params=False):
+                return None
+        (l1, act), (l2, _) = self.latent.layers
+        swz = _weight_shadow(getattr(self.actor, "optimizer", None), l2.weight)
+        if not hip_ops.rollout_step_supported(l1.in_features, l1.out_features, l2.out_features, 2 * self.act_dim, swz is not None):
+            return None
+        if obs.stride(0) % 4 or obs.data_ptr() % 16 or l1.weight.data_ptr() % 16:
+            return None
+        if self.rng_ctl is None:
+            self.rng_ctl = hip_ops.new_rng_ctl(th.initial_seed(), obs.device)
+        return dict(weights=(l1.weight, l1.bias, l2.weight, l2.bias, self._hw, self._hb), act=act, head=0, out_act=ACT_NONE, w2_swz=swz,
+                    rng_ctl=self.rng_ctl)
 
     def pair_supported(self, pb) -> bool:
         """`action_log_prob_pair` applies: fused Linear kernels, two hidden layers with one activation, merged head, a packed

@@ -210,6 +210,25 @@ def replay_sample_packed(ring: DeviceRing, mt_state, batch: int, x_data, x_next,
                                                          ptr(out_env_idx), stream_ptr()), "cstr_replay_sample_packed_mt19937_f32")
 
 
+def replay_gather_packed(ring: DeviceRing, sample_idx, batch: int, x_data, x_next, x_pi, out_done, out_rew, out_row_idx=None,
+                         out_env_idx=None, advance_ring: bool = False, rng_advance=None):
+    """The gather of `replay_sample_packed` for index pairs drawn by `rollout_step` (sample_idx int32 [2, batch]), plus the control-word
+    updates that launch left to this one: ReplayBuffer.add's epilogue (`advance_ring`) and `rng_advance` = (rng_ctl, count)."""
+    w = ring.obs_dim + ring.act_dim
+    _chk(sample_idx, "sample_idx", (2, batch), th.int32)
+    _chk(x_data, "x_data", (batch, w), th.float32), _chk(x_next, "x_next", (batch, w), th.float32), _opt(x_pi, "x_pi", (batch, w), th.float32)
+    _chk(out_done, "out_done", (batch, 1), th.float32), _chk(out_rew, "out_rew", (batch, 1), th.float32)
+    _opt(out_row_idx, "out_row_idx", (batch,), th.int64), _opt(out_env_idx, "out_env_idx", (batch,), th.int64)
+    if not 0 < batch <= nv.MAX_SAMPLE_BATCH:
+        raise ValueError(f"batch_size must be in [1, {nv.MAX_SAMPLE_BATCH}], got {batch}")
+    rng_ctl, rng_count = rng_advance if rng_advance is not None else (None, 0)
+    _opt(rng_ctl, "rng_ctl", (nv.RNG_CTL_WORDS,), th.int64)
+    check(nv.lib().cstr_replay_gather_packed_f32(C.byref(ring.c), ptr(ring.ctl), C.c_int(1 if advance_ring else 0), ptr(rng_ctl),
+                                                 C.c_uint64(int(rng_count)), ptr(sample_idx), C.c_int64(batch), ptr(x_data), ptr(x_next),
+                                                 ptr(x_pi), ptr(out_done), ptr(out_rew), ptr(out_row_idx), ptr(out_env_idx), stream_ptr()),
+          "cstr_replay_gather_packed_f32")
+
+
 def td_target_min(q1, q2, logp, rew, done, ent_coef, gamma: float, out):
     n = q1.numel()
     for t, nm in ((q1, "q1"), (q2, "q2"), (rew, "rew"), (done, "done"), (out, "out")):
@@ -458,6 +477,60 @@ def policy_rows_fwd(x, w1, b1, w2, b2, w3, b3, act: int, head: int, out_act: int
     check(nv.lib().cstr_policy_rows_fwd_f32(C.byref(net), ptr(x), C.c_int64(max(x.stride(0), k0)), ptr(eps), ptr(rng_ctl), ptr(action),
                                             C.c_int64(stride), ptr(logp), C.c_int64(m), stream_ptr()), "cstr_policy_rows_fwd_f32")
     return action
+
+
+def rollout_step_supported(k0: int, h1: int, h2: int, n_out: int, has_swizzled_w2: bool) -> bool:
+    """cstr_rollout_step_f32 covers the pipelined policy kernel with a one-chunk first layer (see the header)."""
+    return has_swizzled_w2 and k0 <= 16 and k0 % 4 == 0 and h1 <= 512 and h2 <= 512 and policy_rows_supported(k0, h1, h2, n_out)
+
+
+def rollout_step(x, w1, b1, w2, b2, w3, b3, act: int, head: int, out_act: int, w2_swz, rng_ctl, coef, integrator: str, ring: DeviceRing,
+                 env_obs, step_count, squashed, act_low, act_high, noise=None, reset_obs=None, pcg_state=None, static_init=None,
+                 reward_out=None, done_out=None, ep_return=None, ep_stats=None, action_out=None, mt_state=None, sample_idx=None):
+    """One vec-step in ONE launch (cstr_rollout_step_f32): policy network + sampling on x [N, k0], the fused collect step of
+    `collect_step` with the action kept in registers, and -- when `mt_state` / `sample_idx` int32 [2, batch] are given -- the replay
+    index draw of the gradient step behind it. Writes NO control word: follow it with `replay_gather_packed(advance_ring=True,
+    rng_advance=(rng_ctl, N))`."""
+    n, d, a = ring.n_envs, ring.obs_dim, ring.act_dim
+    k0 = x.shape[1]
+    h1, h2, n_out = w1.shape[0], w2.shape[0], w3.shape[0]
+    if not (x.is_cuda and x.dtype == th.float32 and x.dim() == 2 and x.shape[0] == n and x.stride(1) == 1):
+        raise ValueError("x: needs a float32 device matrix [n_envs, k0] with unit column stride")
+    if (n_out // 2 if head == 0 else n_out) != a:
+        raise ValueError(f"policy head width {n_out} does not match the ring's act_dim {a}")
+    _chk(w1, "w1", (h1, k0), th.float32), _chk(b1, "b1", (h1,), th.float32), _chk(w2, "w2", (h2, h1), th.float32)
+    _chk(b2, "b2", (h2,), th.float32), _chk(w3, "w3", (n_out, h2), th.float32), _chk(b3, "b3", (n_out,), th.float32)
+    _chk(w2_swz, "w2_swz", (swizzled_numel(h2, h1),), th.float32)
+    _opt(rng_ctl, "rng_ctl", (nv.RNG_CTL_WORDS,), th.int64)
+    _chk(env_obs, "env_obs", (n, d), th.float32), _chk(step_count, "step_count", (n,), th.int32)
+    _opt(noise, "noise", (n, a), th.float32), _opt(reset_obs, "reset_obs", (n, d), th.float32)
+    _opt(pcg_state, "pcg_state", (n, nv.PCG_STATE_WORDS), th.int64)
+    _opt(static_init, "static_init", (n, 8 if a == 4 else 4), th.float64)
+    _opt(reward_out, "reward_out", (n,), th.float32), _opt(done_out, "done_out", (n,), th.float32)
+    _opt(ep_return, "ep_return", (n,), th.float32), _opt(ep_stats, "ep_stats", (4,), th.float64)
+    _opt(action_out, "action_out", (n, a), th.float32)
+    if (ep_return is None) != (ep_stats is None):
+        raise ValueError("ep_return and ep_stats go together")
+    if (reset_obs is None) == (pcg_state is None):
+        raise ValueError("rollout_step needs exactly one reset source: reset_obs or pcg_state")
+    if len(act_low) != a or len(act_high) != a:
+        raise ValueError(f"act_low/act_high need {a} entries")
+    if (mt_state is None) != (sample_idx is None):
+        raise ValueError("mt_state and sample_idx go together")
+    batch = 0
+    if mt_state is not None:
+        _chk(mt_state, "mt_state", (nv.MT_STATE_WORDS,), th.int32)
+        batch = sample_idx.shape[1] if sample_idx.dim() == 2 else -1
+        _chk(sample_idx, "sample_idx", (2, batch), th.int32)
+    lo = (C.c_float * a)(*[float(v) for v in act_low])
+    hi = (C.c_float * a)(*[float(v) for v in act_high])
+    net = nv.PolicyMlp(k0, h1, h2, a, act, head, out_act, 1, w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), w3.data_ptr(),
+                       b3.data_ptr(), w2_swz.data_ptr())
+    check(nv.lib().cstr_rollout_step_f32(C.byref(net), ptr(x), C.c_int64(max(x.stride(0), k0)), ptr(rng_ctl), C.byref(coef),
+                                         C.c_int(INTEGRATORS[integrator]), C.byref(ring.c), ptr(ring.ctl), ptr(env_obs), ptr(step_count),
+                                         C.c_int(int(squashed)), lo, hi, ptr(noise), ptr(reset_obs), ptr(pcg_state), ptr(static_init),
+                                         ptr(reward_out), ptr(done_out), ptr(ep_return), ptr(ep_stats), ptr(action_out), ptr(mt_state),
+                                         C.c_int64(batch), ptr(sample_idx), stream_ptr()), "cstr_rollout_step_f32")
 
 
 def linear_act_fwd(x, weight, bias, act: int, out=None):

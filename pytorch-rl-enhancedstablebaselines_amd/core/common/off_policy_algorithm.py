@@ -30,6 +30,9 @@ from core.common.vec_env import CSTRVecEnv, VecEnv
 # start-up trial (distributed.graph_collectives_ok: capture + replay of one all-reduce, result checked on every rank) passes,
 # else run them eagerly BETWEEN graph segments; "0": always between segments; "1": always inside (no trial).
 GRAPH_COLLECTIVES = os.environ.get("CSTR_GRAPH_COLLECTIVES", "auto")
+# the captured iteration's rollout as ONE launch (policy + collect step + replay index draw; hip_ops.rollout_step). "0": the
+# separate policy / collect / sampler launches (A/B knob; both forms are bit-identical, tests/test_rollout_step.py)
+FUSED_ROLLOUT = os.environ.get("CSTR_FUSED_ROLLOUT", "1") != "0"
 
 
 class OffPolicyAlgorithm(BaseAlgorithm):
@@ -222,8 +225,25 @@ class OffPolicyAlgorithm(BaseAlgorithm):
     def _graph_body(self) -> None:
         env, rb, vn = self._denv, self.replay_buffer, self._vec_normalize_env
         self.policy.set_training_mode(False)
-        pol = self._policy_out_device(env.obs if vn is None else vn.norm_obs_dev)
         noise = None if self.action_noise is None else self.action_noise().contiguous()
+        net = self._rollout_net() if (FUSED_ROLLOUT and vn is None and self._use_packed_batch()) else None
+        if net is not None:
+            # policy network + sampling + collect step + the first gradient step's replay index draw in ONE launch; the gather
+            # launch of that gradient step advances the ring position and the policy's Philox offset (hip_ops.rollout_step)
+            idx = rb.predraw_indices(self.batch_size)
+            hip_ops.rollout_step(env.obs, *net["weights"], net["act"], net["head"], net["out_act"], net["w2_swz"], net["rng_ctl"], env.coef,
+                                 env.integrator, rb.ring, env.obs, env.step_count, self._action_mode(False), self.action_space.low,
+                                 self.action_space.high, noise=noise, pcg_state=env.pcg_state, static_init=env.static_init,
+                                 reward_out=env._rew, done_out=env._done, ep_return=self._ep_return, ep_stats=self._ep_stats,
+                                 mt_state=rb.sampler_stream, sample_idx=idx)
+            rb.note_predrawn(idx, None if net["rng_ctl"] is None else (net["rng_ctl"], env.num_envs))
+            if hasattr(self.action_noise, "reset_done"):
+                self.action_noise.reset_done(env._done)
+            self.policy.set_training_mode(True)
+            self._train_device_only(self.gradient_steps, self.batch_size)
+            rb._no_predrawn("the iteration's first gradient step")
+            return
+        pol = self._policy_out_device(env.obs if vn is None else vn.norm_obs_dev)
         hip_ops.collect_step(env.coef, env.integrator, rb.ring, env.obs, env.step_count, pol, self._action_mode(False),
                              self.action_space.low, self.action_space.high, noise=noise, pcg_state=env.pcg_state, static_init=env.static_init, reward_out=env._rew, done_out=env._done,
                              ep_return=self._ep_return, ep_stats=self._ep_stats, rng_advance=self._take_rng_advance())
@@ -233,6 +253,14 @@ class OffPolicyAlgorithm(BaseAlgorithm):
             vn.after_device_step()
         self.policy.set_training_mode(True)
         self._train_device_only(self.gradient_steps, self.batch_size)
+
+    def _rollout_net(self) -> Optional[dict]:
+        """The rollout policy as operands of hip_ops.rollout_step (weights = (w1, b1, w2, b2, w3, b3), act, head, out_act, w2_swz,
+        rng_ctl), or None when the one-launch rollout does not cover this algorithm / network (the separate launches run then)."""
+        return None
+
+    def _use_packed_batch(self) -> bool:
+        return False
 
     def _graph_host_bookkeeping(self, log_interval: Optional[int]) -> None:
         self.replay_buffer.note_fused_add()

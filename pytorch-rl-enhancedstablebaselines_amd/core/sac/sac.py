@@ -100,6 +100,9 @@ class SAC(OffPolicyAlgorithm):
         self._rng_advance, fa.deferred_rng = fa.deferred_rng, None  # the fused collect launch advances the Philox offset
         return out
 
+    def _rollout_net(self):
+        return self._fast_actor.rollout_operands(self._denv.obs) if self.fused_learner else None
+
     def _create_aliases(self) -> None:
         self.actor = self.policy.actor
         self.critic = self.policy.critic

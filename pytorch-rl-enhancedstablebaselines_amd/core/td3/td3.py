@@ -59,6 +59,9 @@ class TD3(OffPolicyAlgorithm):
         with th.no_grad():
             return self._fast_actor(obs, train_params=False)
 
+    def _rollout_net(self):
+        return self._fast_actor.rollout_operands(self._denv.obs) if self.fused_learner else None
+
     def _batch(self, batch_size: int):
         if self._static_batch is None or self._static_batch.observations.shape[0] != batch_size or self._packed is not None:
             self._static_batch, self._packed = self.replay_buffer.alloc_batch(batch_size), None

@@ -17,6 +17,8 @@
 
 #include "../../include/cstr_rl_hip.h"
 #include "cstr_device.h"
+#include "cstr_env_device.h"
+#include "cstr_mt_device.h"
 
 namespace {
 
@@ -1145,8 +1147,16 @@ __device__ __forceinline__ void v2_mfma_stage(const int c_begin, const int kc, c
     }
 }
 
-template <int ACT, int HEAD, bool VEC0, bool K0_SMALL, bool SMALL>
-__global__ __launch_bounds__(64 * POLICY_WAVES) void policy_rows_v2_kernel(const PolicyArgs a)
+// What the rollout launch (cstr_rollout_step_f32) does beyond the policy network: the fused collect step of the workgroup's 16 envs
+// on the sampling tail's lanes, and -- on ONE wave of the last workgroup, in the ~2 us the older waves of a SIMD wait for the
+// younger ones at the end of layer 2 -- this iteration's replay index draw (numpy legacy MT19937, cstr_mt_device.h).
+struct RolloutArgs {
+    cstr_coef_t k; CollectArgs c; const int64_t *ring_ctl; int layout, integrator;
+    uint32_t *mt_state; int32_t *sample_idx; int batch;
+};
+
+template <int ACT, int HEAD, bool VEC0, bool K0_SMALL, bool SMALL, bool FUSE>
+__device__ __forceinline__ void policy_rows_v2_body(const PolicyArgs &a, const RolloutArgs *ro)
 {
     constexpr int WAVES = POLICY_WAVES, L1_WAVES = 4;
     constexpr int MAXC = SMALL ? 16 : V2_MAX_WIDTH / 16;  // 16-wide k chunks / column tiles the instantiation is sized for (register budget)
@@ -1164,6 +1174,14 @@ __global__ __launch_bounds__(64 * POLICY_WAVES) void policy_rows_v2_kernel(const
     const int n_out = HEAD == 0 ? 2 * a.act_dim : a.act_dim;
     const float4 *w2s = reinterpret_cast<const float4 *>(a.w2s);
     const bool l1_wave = wave < L1_WAVES;
+    constexpr int MT_Q = (MT_N + 63) / 64;
+    __shared__ uint32_t mt_lds[FUSE ? MT_N : 1];
+    const bool mt_wave = FUSE && K0_SMALL && ro->mt_state != nullptr && blockIdx.x == gridDim.x - 1 && wave == 0;  // wave-uniform
+    uint32_t mtq[MT_Q];
+    // the lanes that step an env at the end (thread 8 * row of the sampling tail, waves 0-1 = layer-1 waves)
+    const bool env_lane = FUSE && K0_SMALL && tid < POLICY_ROWS * 8 && (tid & 7) == 0 && m0 + (tid >> 3) < a.m;
+    CollectIn env_in;
+    const int64_t ring_pos = FUSE ? ro->ring_ctl[0] : 0;
     V2_STAMP(0);
 
     // Roles before the first barrier. The CU's vector-memory path is ONE in-order queue that moves ~75 GB/s: layer 2's weights
@@ -1231,6 +1249,15 @@ __global__ __launch_bounds__(64 * POLICY_WAVES) void policy_rows_v2_kernel(const
             w1v[i] = load_k4_clamped<VEC0>(a.w1 + (int64_t)min(n, H1 - 1) * a.k0, 4 * h, a.k0, n < H1);
             b1v[i] = a.b1[min(n, H1 - 1)];
         }
+        if (FUSE && env_lane) {  // the collect step's operands of this lane's env: requested now, used by the sampling tail
+            if (ro->layout == 0) collect_env_load<0>(ro->c, m0 + (tid >> 3), env_in);
+            else if (ro->layout == 1) collect_env_load<1>(ro->c, m0 + (tid >> 3), env_in);
+            else collect_env_load<2>(ro->c, m0 + (tid >> 3), env_in);
+        }
+        if (FUSE && mt_wave) {  // the sampler's MT19937 image: requested behind layer 1's operands, parked in LDS before the first barrier
+#pragma unroll
+            for (int i = 0; i < MT_Q; ++i) mtq[i] = ro->mt_state[min(lane + 64 * i, MT_N - 1)];
+        }
         V2_REQUEST_B(0, PRE_OLD);
 #pragma unroll
         for (int i = 0; i < L1_T; ++i) {
@@ -1253,6 +1280,11 @@ __global__ __launch_bounds__(64 * POLICY_WAVES) void policy_rows_v2_kernel(const
                     h1s[(4 * h + e) * S1 + col] = v;
                 }
             }
+        }
+        if (FUSE && mt_wave) {
+#pragma unroll
+            for (int i = 0; i < MT_Q; ++i)
+                if (lane + 64 * i < MT_N) mt_lds[lane + 64 * i] = mtq[i];
         }
     } else {
         policy_layer<ACT, true, VEC0, false, 16>(a.x + m0 * a.ldx, a.ldx, m0 + r < a.m, a.k0, a.w1, a.b1, H1, h1s, S1, wave, L1_WAVES);
@@ -1390,6 +1422,21 @@ __global__ __launch_bounds__(64 * POLICY_WAVES) void policy_rows_v2_kernel(const
             for (int e = 0; e < 4; ++e) part[(wave * POLICY_ROWS + 4 * h + e) * 8 + r] = p0[e];
         }
     }
+    if (FUSE && mt_wave) {
+        // ReplayBuffer.sample's two index draws for the gather launch behind this one (buffers.py:112-113, :309), with the ring
+        // as ReplayBuffer.add leaves it after THIS launch's row: upper = rows if full else pos (buffers.py:280-283, :112)
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        const int64_t rpos = ro->ring_ctl[0], rows = ro->c.ring.rows;
+        const int64_t upper = (ro->ring_ctl[1] || rpos + 1 == rows) ? rows : rpos + 1;
+        int pos = (int)ro->mt_state[MT_N];
+        pos = mt_randint_fill_wave(mt_lds, pos, (uint32_t)(upper - 1), ro->batch, ro->sample_idx, lane);
+        pos = mt_randint_fill_wave(mt_lds, pos, (uint32_t)(ro->c.ring.n_envs - 1), ro->batch, ro->sample_idx + ro->batch, lane);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+        for (int i = 0; i < MT_Q; ++i)
+            if (lane + 64 * i < MT_N) ro->mt_state[lane + 64 * i] = mt_lds[lane + 64 * i];
+        if (lane == 0) ro->mt_state[MT_N] = (uint32_t)pos;
+    }
     __syncthreads();
     V2_STAMP(5);
 
@@ -1403,12 +1450,14 @@ __global__ __launch_bounds__(64 * POLICY_WAVES) void policy_rows_v2_kernel(const
         for (int w = 0; w < WAVES; ++w) sum += part[(w * POLICY_ROWS + trow) * 8 + jj];
         return sum + bias;
     };
+    float act_out = 0.0f;  // this lane's action component (FUSE: handed to the row's collect lane)
     if (HEAD == 1) {
         if (live && j < n_out) {
             float v = head_out(j, b3v0);
             if (a.out_act == ACT_RELU) v = fmaxf(v, 0.0f);
             if (a.out_act == ACT_TANH) v = tanhf(v);
-            a.action[row * a.action_stride + j] = v;
+            if (!FUSE || a.action) a.action[row * a.action_stride + j] = v;
+            act_out = v;
         }
     } else {
         if (live && j < a.act_dim) {
@@ -1420,7 +1469,8 @@ __global__ __launch_bounds__(64 * POLICY_WAVES) void policy_rows_v2_kernel(const
             const float u = mu + sd * e;
             const float act = tanhf(u);
             const float d = u - mu, var = sd * sd;
-            a.action[row * a.action_stride + j] = act;
+            if (!FUSE || a.action) a.action[row * a.action_stride + j] = act;
+            act_out = act;
             if (a.logp) {
                 term[trow * 8 + j] = -(d * d) / (2.0f * var) - logf(sd) - half_log_2pi;
                 term[POLICY_ROWS * 8 + trow * 8 + j] = logf(1.0f - act * act + 1e-6f);
@@ -1438,11 +1488,47 @@ __global__ __launch_bounds__(64 * POLICY_WAVES) void policy_rows_v2_kernel(const
             }
         }
     }
+    if (FUSE && wave < (POLICY_ROWS * 8) / 64) {
+        V2_STAMP(7);
+        // the fused collect step (cstr_collect_step_f32) of the workgroup's 16 envs: lane (row, 0) of the tail gathers the row's
+        // action components from its neighbours and steps env `row`; the ring position is only READ here (the gather launch behind
+        // this one advances it: cstr_replay_gather_packed_f32), so no workgroup hands anything to another one
+        float u4[4];
+        u4[0] = act_out; u4[1] = __shfl_down(act_out, 1); u4[2] = __shfl_down(act_out, 2); u4[3] = __shfl_down(act_out, 3);
+        if (env_lane) {
+            const int64_t ring_row = ring_pos * ro->c.ring.n_envs;
+            const bool eu = ro->integrator == CSTR_INTEGRATOR_EULER;
+            if (ro->layout == 0) {
+                if (eu) collect_env_lane<0, CSTR_INTEGRATOR_EULER>(ro->k, ro->c, ring_row, row, u4, env_in);
+                else collect_env_lane<0, CSTR_INTEGRATOR_RK4>(ro->k, ro->c, ring_row, row, u4, env_in);
+            } else if (ro->layout == 1) {
+                if (eu) collect_env_lane<1, CSTR_INTEGRATOR_EULER>(ro->k, ro->c, ring_row, row, u4, env_in);
+                else collect_env_lane<1, CSTR_INTEGRATOR_RK4>(ro->k, ro->c, ring_row, row, u4, env_in);
+            } else {
+                if (eu) collect_env_lane<2, CSTR_INTEGRATOR_EULER>(ro->k, ro->c, ring_row, row, u4, env_in);
+                else collect_env_lane<2, CSTR_INTEGRATOR_RK4>(ro->k, ro->c, ring_row, row, u4, env_in);
+            }
+        }
+    }
     V2_STAMP(6);
     if (__builtin_isnan(warm) && a.m < 0) a.action[0] = warm;  // never true; keeps the warm-up load alive
-    if (a.rng_ctl && !(a.flags & 1) && last_block_ticket_tree(reinterpret_cast<unsigned long long *>(a.rng_ctl + 2),
-                                                              reinterpret_cast<unsigned long long *>(a.rng_ctl + 4)) && tid == 0)
+    if (!FUSE && a.rng_ctl && !(a.flags & 1) && last_block_ticket_tree(reinterpret_cast<unsigned long long *>(a.rng_ctl + 2),
+                                                                       reinterpret_cast<unsigned long long *>(a.rng_ctl + 4)) && tid == 0)
         a.rng_ctl[1] = base + (uint64_t)a.m;
+}
+
+template <int ACT, int HEAD, bool VEC0, bool K0_SMALL, bool SMALL>
+__global__ __launch_bounds__(64 * POLICY_WAVES) void policy_rows_v2_kernel(const PolicyArgs a)
+{
+    policy_rows_v2_body<ACT, HEAD, VEC0, K0_SMALL, SMALL, false>(a, nullptr);
+}
+
+// The rollout of one vec-step in ONE launch: policy network + sampling (policy_rows_v2_body) + fused collect step + the replay
+// index draw (RolloutArgs). Layer-1 input width <= 16 (the CSTR observations), 16-byte aligned rows.
+template <int ACT, int HEAD, bool SMALL>
+__global__ __launch_bounds__(64 * POLICY_WAVES) void rollout_step_kernel(const PolicyArgs a, const RolloutArgs ro)
+{
+    policy_rows_v2_body<ACT, HEAD, true, true, SMALL, true>(a, &ro);
 }
 
 // ---- loss heads (single workgroup; batch <= 16384) -----------------------------------------------------
@@ -1979,10 +2065,11 @@ extern "C" int cstr_policy_swizzle_f32(const float *w, int64_t n, int64_t k, flo
     return (int)hipGetLastError();
 }
 
-extern "C" int cstr_policy_rows_fwd_f32(const cstr_policy_mlp_t *net, const float *x, int64_t ldx, const float *eps, uint64_t *rng_ctl,
-                                       float *action, int64_t action_stride, float *logp, int64_t m, cstr_stream_t stream)
+// cstr_policy_rows_fwd_f32's operand checks, shared with cstr_rollout_step_f32
+static int check_policy_net(const cstr_policy_mlp_t *net, const float *x, int64_t ldx, const float *eps, uint64_t *rng_ctl, const float *logp,
+                            int64_t action_stride, int64_t m)
 {
-    if (!net || !x || !action || m <= 0) return CSTR_E_BADARG;
+    if (!net || !x || m <= 0) return CSTR_E_BADARG;
     const cstr_policy_mlp_t &n = *net;
     if (!n.w1 || !n.b1 || !n.w2 || !n.b2 || !n.w3 || !n.b3 || n.k0 <= 0 || n.h1 <= 0 || n.h2 <= 0 || n.act_dim <= 0) return CSTR_E_BADARG;
     if (ldx < n.k0 || action_stride < n.act_dim) return CSTR_E_BADARG;
@@ -1994,9 +2081,26 @@ extern "C" int cstr_policy_rows_fwd_f32(const cstr_policy_mlp_t *net, const floa
         (n.head == 0 && n.act_dim > CSTR_MAX_HEAD_ACT) || (m + POLICY_ROWS - 1) / POLICY_ROWS > 0x7fffffff)
         return CSTR_E_UNSUPPORTED;
     if (n.reserved & ~1) return CSTR_E_BADARG;  // bit 0: the caller advances the Philox offset (no ticket in this launch)
+    if (n.w2_swizzled && !aligned16(n.w2_swizzled)) return CSTR_E_BADARG;
+    return CSTR_OK;
+}
+
+static size_t policy_v2_lds(const cstr_policy_mlp_t &n)
+{
+    const int kc1 = (n.h1 + 15) / 16, kc2 = (n.h2 + 15) / 16;
+    return (size_t)(POLICY_ROWS * (16 * kc1 + 4 + 16 * kc2 + 4) + POLICY_WAVES * POLICY_ROWS * 8 + 3 * POLICY_ROWS * 8) * sizeof(float);
+}
+
+extern "C" int cstr_policy_rows_fwd_f32(const cstr_policy_mlp_t *net, const float *x, int64_t ldx, const float *eps, uint64_t *rng_ctl,
+                                       float *action, int64_t action_stride, float *logp, int64_t m, cstr_stream_t stream)
+{
+    if (!action) return CSTR_E_BADARG;
+    const int rc = check_policy_net(net, x, ldx, eps, rng_ctl, logp, action_stride, m);
+    if (rc) return rc;
+    const cstr_policy_mlp_t &n = *net;
+    const size_t lds = (size_t)POLICY_ROWS * (n.h1 + 4 + n.h2 + 4) * sizeof(float);
     PolicyArgs a = {x, ldx, n.k0, n.w1, n.b1, n.h1, n.w2, n.b2, n.h2, n.w3, n.b3, n.act_dim, n.out_act, eps, rng_ctl,
                     action, action_stride, logp, m, n.w2_swizzled, n.reserved};
-    if (n.w2_swizzled && !aligned16(n.w2_swizzled)) return CSTR_E_BADARG;
     const unsigned grid = (unsigned)((m + POLICY_ROWS - 1) / POLICY_ROWS);
     const bool vec0 = (n.k0 & 3) == 0 && (ldx & 3) == 0 && aligned16(x) && aligned16(n.w1);
     hipStream_t s = (hipStream_t)stream;
@@ -2004,7 +2108,7 @@ extern "C" int cstr_policy_rows_fwd_f32(const cstr_policy_mlp_t *net, const floa
     if (n.w2_swizzled && n.h1 <= V2_MAX_WIDTH && n.h2 <= V2_MAX_WIDTH && !force_v1) {
         // the software-pipelined kernel (tile-major W2 required)
         const int kc1 = (n.h1 + 15) / 16, kc2 = (n.h2 + 15) / 16;
-        const size_t lds2 = (size_t)(POLICY_ROWS * (16 * kc1 + 4 + 16 * kc2 + 4) + POLICY_WAVES * POLICY_ROWS * 8 + 3 * POLICY_ROWS * 8) * sizeof(float);
+        const size_t lds2 = policy_v2_lds(n);
         const bool k0s = n.k0 <= 16, small = kc1 <= 16 && kc2 <= 16;
 #define POLV4(A, H, V, K) do { if (small) policy_rows_v2_kernel<A, H, V, K, true><<<grid, 64 * POLICY_WAVES, lds2, s>>>(a); \
                                else policy_rows_v2_kernel<A, H, V, K, false><<<grid, 64 * POLICY_WAVES, lds2, s>>>(a); } while (0)
@@ -2023,6 +2127,50 @@ extern "C" int cstr_policy_rows_fwd_f32(const cstr_policy_mlp_t *net, const floa
     else { if (n.act == 0) POL(0, 1); else if (n.act == 1) POL(1, 1); else POL(2, 1); }
 #undef POL2
 #undef POL
+    return (int)hipGetLastError();
+}
+
+extern "C" int cstr_rollout_step_f32(const cstr_policy_mlp_t *net, const float *x, int64_t ldx, uint64_t *rng_ctl, const cstr_coef_t *coef,
+                                     int integrator, const cstr_ring_t *ring, const int64_t *ring_ctl, float *env_obs, int32_t *step_count,
+                                     int squashed, const float *act_low, const float *act_high, const float *noise, const float *reset_obs,
+                                     uint64_t *pcg_state, double *static_init, float *reward_out, float *done_out, float *ep_return,
+                                     double *ep_stats, float *action_out, uint32_t *mt_state, int64_t batch, int32_t *sample_idx,
+                                     cstr_stream_t stream)
+{
+    RolloutArgs ro;
+    int rc = make_collect_args(coef, integrator, ring, env_obs, step_count, squashed, act_low, act_high, noise, reset_obs, pcg_state,
+                               static_init, reward_out, done_out, ep_return, ep_stats, ro.c);
+    if (rc) return rc;
+    if (!ring_ctl) return CSTR_E_BADARG;
+    const int64_t m = ring->n_envs;
+    rc = check_policy_net(net, x, ldx, nullptr, rng_ctl, nullptr, net ? net->act_dim : 0, m);
+    if (rc) return rc;
+    const cstr_policy_mlp_t &n = *net;
+    if (n.act_dim != ring->act_dim) return CSTR_E_BADARG;
+    if ((mt_state == nullptr) != (sample_idx == nullptr) || (mt_state && (batch <= 0 || batch > CSTR_MAX_SAMPLE_BATCH))) return CSTR_E_BADARG;
+    if (mt_state && (ring->rows >= 0xFFFFFFFFLL || ring->n_envs >= 0xFFFFFFFFLL)) return CSTR_E_UNSUPPORTED;
+    // the software-pipelined kernel with a one-chunk first layer: tile-major W2, widths <= 512, k0 <= 16 in 16-byte rows
+    const bool vec0 = (n.k0 & 3) == 0 && (ldx & 3) == 0 && aligned16(x) && aligned16(n.w1);
+    if (!n.w2_swizzled || n.h1 > V2_MAX_WIDTH || n.h2 > V2_MAX_WIDTH || n.k0 > 16 || !vec0) return CSTR_E_UNSUPPORTED;
+    ro.k = *coef;
+    ro.ring_ctl = ring_ctl;
+    ro.layout = layout_of(ring->obs_dim, ring->act_dim);
+    ro.integrator = integrator;
+    ro.mt_state = mt_state;
+    ro.sample_idx = sample_idx;
+    ro.batch = (int)batch;
+    // reserved bit 0 is implied: nobody advances a control word in this launch (the gather launch behind it does)
+    PolicyArgs a = {x, ldx, n.k0, n.w1, n.b1, n.h1, n.w2, n.b2, n.h2, n.w3, n.b3, n.act_dim, n.out_act, nullptr, rng_ctl,
+                    action_out, n.act_dim, nullptr, m, n.w2_swizzled, n.reserved | 1};
+    const unsigned grid = (unsigned)((m + POLICY_ROWS - 1) / POLICY_ROWS);
+    const size_t lds2 = policy_v2_lds(n);
+    const bool small = (n.h1 + 15) / 16 <= 16 && (n.h2 + 15) / 16 <= 16;
+    hipStream_t s = (hipStream_t)stream;
+#define ROL2(A, H) do { if (small) rollout_step_kernel<A, H, true><<<grid, 64 * POLICY_WAVES, lds2, s>>>(a, ro); \
+                        else rollout_step_kernel<A, H, false><<<grid, 64 * POLICY_WAVES, lds2, s>>>(a, ro); } while (0)
+    if (n.head == 0) { if (n.act == 0) ROL2(0, 0); else if (n.act == 1) ROL2(1, 0); else ROL2(2, 0); }
+    else { if (n.act == 0) ROL2(0, 1); else if (n.act == 1) ROL2(1, 1); else ROL2(2, 1); }
+#undef ROL2
     return (int)hipGetLastError();
 }
 

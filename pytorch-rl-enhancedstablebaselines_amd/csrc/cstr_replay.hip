@@ -13,24 +13,11 @@
 #include "../../include/cstr_rl_hip.h"
 #include "cstr_device.h"
 
+#include "cstr_mt_device.h"
+
 namespace {
 
-constexpr int MT_N = 624, MT_M = 397, TPB = 256;
-
-__device__ __forceinline__ uint32_t mt_mix(uint32_t a, uint32_t b, uint32_t far)
-{
-    const uint32_t y = (a & 0x80000000u) | (b & 0x7fffffffu);
-    return far ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
-}
-
-__device__ __forceinline__ uint32_t mt_temper(uint32_t y)
-{
-    y ^= (y >> 11);
-    y ^= (y << 7) & 0x9d2c5680u;
-    y ^= (y << 15) & 0xefc60000u;
-    y ^= (y >> 18);
-    return y;
-}
+constexpr int TPB = 256;
 
 // mt19937_gen (numpy/random/src/mt19937/mt19937.c), parallel over one workgroup. All lanes call it.
 __device__ void mt_twist(uint32_t *mt)
@@ -109,34 +96,18 @@ __device__ int mt_randint_fill(SampleShared &sh, int pos, uint32_t rng, int coun
     return pos;
 }
 
+// The gather of ReplayBuffer._get_samples (buffers.py:316-323) for `batch` (row, env) index pairs, a lane per sampled row.
 // PACKED: the batch is gathered straight into the critics' input rows (ContinuousCritic.forward's th.cat([obs, actions], 1),
 // core/common/policies.py:975-981, without the cat launches): out_obs = x_data [B][D+A] <- (obs | action),
 // out_next_obs = x_next [B][D+A] <- (next_obs | .), out_act = x_pi [B][D+A] or NULL <- (obs | .); the '.' columns belong
 // to the actor head kernel. Rows are (D+A)*4 bytes apart (8-byte aligned), so the stores are float2.
-template <int D, int A, bool PACKED = false>
-__global__ __launch_bounds__(TPB) void replay_sample_kernel(const cstr_ring_t ring, const int64_t *__restrict__ ring_ctl,
-                                                            uint32_t *__restrict__ mt_state, const int batch,
-                                                            float *__restrict__ out_obs, float *__restrict__ out_act,
-                                                            float *__restrict__ out_next_obs, float *__restrict__ out_done,
-                                                            float *__restrict__ out_rew, int64_t *__restrict__ out_row_idx,
-                                                            int64_t *__restrict__ out_env_idx)
+template <int D, int A, bool PACKED>
+__device__ __forceinline__ void gather_rows(const cstr_ring_t &ring, const int32_t *row_idx, const int32_t *env_idx, const int batch,
+                                            float *__restrict__ out_obs, float *__restrict__ out_act, float *__restrict__ out_next_obs,
+                                            float *__restrict__ out_done, float *__restrict__ out_rew, int64_t *__restrict__ out_row_idx,
+                                            int64_t *__restrict__ out_env_idx)
 {
-    __shared__ SampleShared sh;
-    extern __shared__ __align__(16) int32_t idx[];  // [2][batch]
-    int32_t *row_idx = idx, *env_idx = idx + batch;
     const int t = threadIdx.x;
-    for (int i = t; i < MT_N; i += TPB) sh.mt[i] = mt_state[i];
-    int pos = (int)mt_state[MT_N];
-    __syncthreads();
-
-    const int64_t upper = ring_ctl[1] ? ring.rows : ring_ctl[0];  // buffers.py:112
-    pos = mt_randint_fill(sh, pos, (uint32_t)(upper - 1), batch, row_idx);          // buffers.py:113
-    pos = mt_randint_fill(sh, pos, (uint32_t)(ring.n_envs - 1), batch, env_idx);    // buffers.py:309
-    __syncthreads();
-
-    for (int i = t; i < MT_N; i += TPB) mt_state[i] = sh.mt[i];
-    if (t == 0) mt_state[MT_N] = (uint32_t)pos;
-
     const int64_t n = ring.n_envs;
     for (int b = t; b < batch; b += TPB) {  // buffers.py:316-323
         const int64_t r = row_idx[b], e = env_idx[b], o = r * n + e;
@@ -177,6 +148,56 @@ __global__ __launch_bounds__(TPB) void replay_sample_kernel(const cstr_ring_t ri
         out_rew[b] = rw;
         if (out_row_idx) out_row_idx[b] = r;
         if (out_env_idx) out_env_idx[b] = e;
+    }
+}
+
+template <int D, int A, bool PACKED = false>
+__global__ __launch_bounds__(TPB) void replay_sample_kernel(const cstr_ring_t ring, const int64_t *__restrict__ ring_ctl,
+                                                            uint32_t *__restrict__ mt_state, const int batch,
+                                                            float *__restrict__ out_obs, float *__restrict__ out_act,
+                                                            float *__restrict__ out_next_obs, float *__restrict__ out_done,
+                                                            float *__restrict__ out_rew, int64_t *__restrict__ out_row_idx,
+                                                            int64_t *__restrict__ out_env_idx)
+{
+    __shared__ SampleShared sh;
+    extern __shared__ __align__(16) int32_t idx[];  // [2][batch]
+    int32_t *row_idx = idx, *env_idx = idx + batch;
+    const int t = threadIdx.x;
+    for (int i = t; i < MT_N; i += TPB) sh.mt[i] = mt_state[i];
+    int pos = (int)mt_state[MT_N];
+    __syncthreads();
+
+    const int64_t upper = ring_ctl[1] ? ring.rows : ring_ctl[0];  // buffers.py:112
+    pos = mt_randint_fill(sh, pos, (uint32_t)(upper - 1), batch, row_idx);          // buffers.py:113
+    pos = mt_randint_fill(sh, pos, (uint32_t)(ring.n_envs - 1), batch, env_idx);    // buffers.py:309
+    __syncthreads();
+
+    for (int i = t; i < MT_N; i += TPB) mt_state[i] = sh.mt[i];
+    if (t == 0) mt_state[MT_N] = (uint32_t)pos;
+
+    gather_rows<D, A, PACKED>(ring, row_idx, env_idx, batch, out_obs, out_act, out_next_obs, out_done, out_rew, out_row_idx, out_env_idx);
+}
+
+// The gather alone, for index pairs drawn earlier in the iteration by the rollout launch (cstr_rollout_step_f32: idx[0..batch) rows,
+// idx[batch..2 batch) envs), plus the control-word updates that launch left to its successor: ReplayBuffer.add's epilogue
+// (core/common/buffers.py:280-283) and the rollout policy's Philox offset. One workgroup: nobody else reads the control words.
+template <int D, int A>
+__global__ __launch_bounds__(TPB) void replay_gather_kernel(const cstr_ring_t ring, int64_t *__restrict__ ring_ctl, const int advance_ring,
+                                                            uint64_t *__restrict__ rng_ctl, const uint64_t rng_advance,
+                                                            const int32_t *__restrict__ idx, const int batch,
+                                                            float *__restrict__ x_data, float *__restrict__ x_pi, float *__restrict__ x_next,
+                                                            float *__restrict__ out_done, float *__restrict__ out_rew,
+                                                            int64_t *__restrict__ out_row_idx, int64_t *__restrict__ out_env_idx)
+{
+    gather_rows<D, A, true>(ring, idx, idx + batch, batch, x_data, x_pi, x_next, out_done, out_rew, out_row_idx, out_env_idx);
+    if (threadIdx.x == 0) {
+        if (advance_ring) {
+            int64_t pos = ring_ctl[0] + 1;
+            if (pos == ring.rows) { ring_ctl[1] = 1; pos = 0; }
+            ring_ctl[0] = pos;
+            ring_ctl[3] += 1;
+        }
+        if (rng_ctl) rng_ctl[1] += rng_advance;
     }
 }
 
@@ -388,5 +409,28 @@ extern "C" int cstr_replay_sample_packed_mt19937_f32(const cstr_ring_t *ring, co
     else if (ring->act_dim == 2) replay_sample_kernel<8, 2, true><<<1, TPB, dyn, s>>>(SAMPLE_ARGS);
     else replay_sample_kernel<8, 4, true><<<1, TPB, dyn, s>>>(SAMPLE_ARGS);
 #undef SAMPLE_ARGS
+    return (int)hipGetLastError();
+}
+
+extern "C" int cstr_replay_gather_packed_f32(const cstr_ring_t *ring, int64_t *ring_ctl, int advance_ring, uint64_t *rng_ctl,
+                                             uint64_t rng_advance, const int32_t *sample_idx, int64_t batch, float *x_data, float *x_next,
+                                             float *x_pi, float *out_done, float *out_rew, int64_t *out_row_idx, int64_t *out_env_idx,
+                                             cstr_stream_t stream)
+{
+    if (!ring || !ring->obs || !ring->next_obs || !ring->act || !ring->rew || !ring->done || !ring->timeout) return CSTR_E_BADARG;
+    if (!sample_idx || !x_data || !x_next || !out_done || !out_rew || batch <= 0) return CSTR_E_BADARG;
+    if (advance_ring && !ring_ctl) return CSTR_E_BADARG;
+    const bool lay_ok = (ring->obs_dim == 4 && ring->act_dim == 2) || (ring->obs_dim == 8 && (ring->act_dim == 2 || ring->act_dim == 4));
+    if (!lay_ok) return CSTR_E_UNSUPPORTED;
+    if (batch > CSTR_MAX_SAMPLE_BATCH || ring->rows >= 0xFFFFFFFFLL || ring->n_envs >= 0xFFFFFFFFLL) return CSTR_E_UNSUPPORTED;
+    if (!aligned16(ring->obs) || !aligned16(ring->next_obs) || !aligned8(ring->act) || !aligned8(x_data) || !aligned8(x_next) ||
+        (x_pi && !aligned8(x_pi)))
+        return CSTR_E_BADARG;
+    hipStream_t s = (hipStream_t)stream;
+#define GATHER_ARGS *ring, ring_ctl, advance_ring, rng_ctl, rng_advance, sample_idx, (int)batch, x_data, x_pi, x_next, out_done, out_rew, out_row_idx, out_env_idx
+    if (ring->obs_dim == 4) replay_gather_kernel<4, 2><<<1, TPB, 0, s>>>(GATHER_ARGS);
+    else if (ring->act_dim == 2) replay_gather_kernel<8, 2><<<1, TPB, 0, s>>>(GATHER_ARGS);
+    else replay_gather_kernel<8, 4><<<1, TPB, 0, s>>>(GATHER_ARGS);
+#undef GATHER_ARGS
     return (int)hipGetLastError();
 }

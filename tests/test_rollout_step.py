@@ -1,0 +1,180 @@
+"""GPU parity tests of the one-launch rollout (cstr_rollout_step_f32) and the gather launch behind it
+(cstr_replay_gather_packed_f32): bit-identical to the three launches they replace (cstr_policy_rows_fwd_f32 ->
+cstr_collect_step_rng_f32 -> cstr_replay_sample_packed_mt19937_f32), which the other test files pin to the oracle, the
+golden vectors and numpy; the one-wave MT19937 index draw is additionally checked against numpy's RandomState directly.
+"""
+import numpy as np
+import pytest
+import torch as th
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert th.cuda.is_available(), "GPU tests need an MI355X"
+    from core import _native as nv
+    from core.common import hip_ops
+
+    nv.lib()  # fail loudly if the HIP extension is missing
+    return hip_ops
+
+
+def _obs8(o4):
+    lo, hi = th.tensor([0.0, 273.15, 0.0, 273.15], device="cuda"), th.tensor([0.7, 400.0, 0.7, 400.0], device="cuda")
+    return th.cat([o4, th.minimum(th.maximum(lo + (o4 + 1.0) * (hi - lo) / 2.0, lo), hi)], dim=1).contiguous()
+
+
+class _World:
+    """Everything one rollout + sample touches, so that two code paths can run on identical copies."""
+
+    def __init__(self, ops, n, d, rows, batch, h1, h2, head, seed, max_steps):
+        from core import _native as nv
+
+        g = th.Generator(device="cuda").manual_seed(seed)
+        r = lambda *sh: th.randn(*sh, device="cuda", generator=g)  # noqa: E731
+        a = 2
+        self.ops, self.n, self.d, self.a, self.batch, self.head = ops, n, d, a, batch, head
+        o4 = (th.rand(n, 4, device="cuda", generator=g) * 2 - 1).contiguous()
+        self.env_obs = o4 if d == 4 else _obs8(o4)
+        self.step_count = th.randint(max_steps - 6, max_steps, (n,), device="cuda", generator=g, dtype=th.int32)
+        self.coef = nv.default_coef(max_steps=max_steps)
+        self.ring = ops.DeviceRing(rows, n, d, a, "cuda")
+        n_out = 2 * a if head == 0 else a
+        self.w = [r(h1, d) / d ** 0.5, r(h1) * 0.1, r(h2, h1) / h1 ** 0.5, r(h2) * 0.1, r(n_out, h2) / h2 ** 0.5, r(n_out) * 0.1]
+        self.swz = ops.policy_swizzle(self.w[2])
+        self.rng_ctl = ops.new_rng_ctl(123, "cuda") if head == 0 else None
+        self.pcg = th.randint(1, 2 ** 62, (n, 4), device="cuda", generator=g, dtype=th.int64)
+        self.pcg[:, 3] |= 1  # odd increment, like a seeded PCG64
+        self.mt = th.zeros(628, dtype=th.int32, device="cuda")
+        ops.mt19937_seed(self.mt, 4242 + seed)
+        self.rew, self.done = th.zeros(n, device="cuda"), th.zeros(n, device="cuda")
+        self.ep_return, self.ep_stats = th.zeros(n, device="cuda"), th.zeros(4, dtype=th.float64, device="cuda")
+        w = d + a
+        self.x_data, self.x_next, self.x_pi = (th.zeros(batch, w, device="cuda") for _ in range(3))
+        self.s_done, self.s_rew = th.zeros(batch, 1, device="cuda"), th.zeros(batch, 1, device="cuda")
+        self.bi, self.ei = th.zeros(batch, dtype=th.int64, device="cuda"), th.zeros(batch, dtype=th.int64, device="cuda")
+        self.idx = th.zeros(2, batch, dtype=th.int32, device="cuda")
+        self.low, self.high = np.array([-1, -1], np.float32), np.array([1, 1], np.float32)
+
+    def step_separate(self, noise):
+        ops, n = self.ops, self.n
+        pol = th.empty(n, self.a, device="cuda")
+        ops.policy_rows_fwd(self.env_obs, *self.w, 1, self.head, 2 if self.head else 0, pol, rng_ctl=self.rng_ctl, w2_swz=self.swz,
+                            defer_rng_advance=True)
+        ops.collect_step(self.coef, "euler" if self.d == 4 else "rk4", self.ring, self.env_obs, self.step_count, pol, 1, self.low, self.high,
+                         noise=noise, pcg_state=self.pcg, reward_out=self.rew, done_out=self.done, ep_return=self.ep_return,
+                         ep_stats=self.ep_stats, rng_advance=None if self.rng_ctl is None else (self.rng_ctl, n))
+        ops.replay_sample_packed(self.ring, self.mt, self.batch, self.x_data, self.x_next, self.x_pi, self.s_done, self.s_rew, self.bi, self.ei)
+
+    def step_fused(self, noise):
+        ops, n = self.ops, self.n
+        ops.rollout_step(self.env_obs, *self.w, 1, self.head, 2 if self.head else 0, self.swz, self.rng_ctl, self.coef,
+                         "euler" if self.d == 4 else "rk4", self.ring, self.env_obs, self.step_count, 1, self.low, self.high, noise=noise,
+                         pcg_state=self.pcg, reward_out=self.rew, done_out=self.done, ep_return=self.ep_return, ep_stats=self.ep_stats,
+                         mt_state=self.mt, sample_idx=self.idx)
+        ops.replay_gather_packed(self.ring, self.idx, self.batch, self.x_data, self.x_next, self.x_pi, self.s_done, self.s_rew, self.bi, self.ei,
+                                 advance_ring=True, rng_advance=None if self.rng_ctl is None else (self.rng_ctl, n))
+
+    def state(self):
+        r = self.ring
+        out = dict(env_obs=self.env_obs, step_count=self.step_count, pcg=self.pcg, mt=self.mt, rew=self.rew, done=self.done,
+                   ep_return=self.ep_return, x_data=self.x_data, x_next=self.x_next, x_pi=self.x_pi, s_done=self.s_done, s_rew=self.s_rew,
+                   bi=self.bi, ei=self.ei, ring_obs=r.observations, ring_next=r.next_observations, ring_act=r.actions, ring_rew=r.rewards,
+                   ring_done=r.dones, ring_timeout=r.timeouts, ring_ctl=r.ctl)
+        if self.rng_ctl is not None:
+            out["rng_ctl"] = self.rng_ctl
+        return {k: v.clone() for k, v in out.items()}
+
+
+@pytest.mark.parametrize("n,d,rows,batch,h1,h2,head", [
+    (4096, 4, 5, 256, 256, 256, 0),   # the bench shape (SAC): register-resident B operand
+    (1000, 4, 3, 100, 400, 300, 1),   # TD3's class-default widths (pipelined form), ragged last workgroup, deterministic head
+    (2048, 8, 4, 64, 64, 64, 0),      # obs 8 / RK4 (north_star variant)
+    (1040, 4, 7, 300, 256, 256, 1),
+])
+def test_rollout_step_equals_the_three_launches(ops, n, d, rows, batch, h1, h2, head):
+    """13 vec-steps (ring wraps, episodes end and reset from the PCG64 streams, the MT19937 block is twisted most steps): every
+    tensor either path touches is bit-identical after each step; the f64 episode-return sum (float atomics) to 1e-12."""
+    a, b = (_World(ops, n, d, rows, batch, h1, h2, head, seed=n + h1, max_steps=9) for _ in range(2))
+    g = th.Generator(device="cuda").manual_seed(1)
+    ends = 0
+    for k in range(13):
+        noise = None if k % 3 else (th.randn(n, 2, device="cuda", generator=g) * 0.1).contiguous()
+        a.step_separate(noise)
+        b.step_fused(noise)
+        th.cuda.synchronize()
+        sa, sb = a.state(), b.state()
+        for key in sa:
+            assert th.equal(sa[key], sb[key]), f"step {k}: {key} differs"
+        ea, eb = a.ep_stats.cpu().numpy(), b.ep_stats.cpu().numpy()
+        assert ea[0] == eb[0] and ea[2] == eb[2] and abs(ea[1] - eb[1]) <= 1e-12 * max(1.0, abs(ea[1]))
+        ends = ea[0]
+        ctl = sb["ring_ctl"].cpu().numpy()
+        assert ctl[0] == (k + 1) % rows and ctl[1] == int(k + 1 >= rows) and ctl[3] == k + 1
+    assert ends > n  # every env finished at least one episode: the reset draws ran inside the fused launch
+
+
+@pytest.mark.parametrize("rows,n_envs,batch", [(244, 4096, 256), (7, 17, 1024), (3, 1, 100), (100000, 3, 256), (5, 1025, 4000)])
+def test_one_wave_index_draw_is_numpys(ops, rows, n_envs, batch):
+    """The rollout launch's index draw against numpy's legacy stream itself: RandomState(seed).randint(0, upper, B) followed by
+    randint(0, n_envs, B) (core/common/buffers.py:113, :309), stream image and position included (n_envs = 1 consumes nothing),
+    over enough steps that small rings fill and the 624-word block is twisted many times."""
+    w = _World(ops, n_envs, 4, rows, batch, 64, 64, 1, seed=3, max_steps=50)
+    seed = 99
+    ops.mt19937_seed(w.mt, seed)
+    rs = np.random.RandomState(seed)
+    for k in range(12):
+        w.step_fused(None)
+        th.cuda.synchronize()
+        upper = rows if k + 1 >= rows else k + 1
+        bi = rs.randint(0, upper, size=batch)
+        ei = rs.randint(0, n_envs, size=batch)
+        np.testing.assert_array_equal(w.idx[0].cpu().numpy(), bi)
+        np.testing.assert_array_equal(w.idx[1].cpu().numpy(), ei)
+        st = rs.get_state(legacy=True)
+        np.testing.assert_array_equal(w.mt[:624].cpu().numpy().view(np.uint32), st[1])
+        assert int(w.mt[624]) == st[2]
+
+
+def test_rollout_step_rejects_what_it_does_not_cover(ops):
+    w = _World(ops, 64, 4, 3, 16, 64, 64, 0, seed=1, max_steps=9)
+    with pytest.raises(Exception):  # no tile-major copy
+        ops.rollout_step(w.env_obs, *w.w, 1, 0, 0, None, w.rng_ctl, w.coef, "euler", w.ring, w.env_obs, w.step_count, 1, w.low, w.high,
+                         pcg_state=w.pcg)
+    with pytest.raises(Exception):  # sampling head without its Philox stream
+        ops.rollout_step(w.env_obs, *w.w, 1, 0, 0, w.swz, None, w.coef, "euler", w.ring, w.env_obs, w.step_count, 1, w.low, w.high,
+                         pcg_state=w.pcg)
+    with pytest.raises(Exception):  # index draw without its output buffer
+        ops.rollout_step(w.env_obs, *w.w, 1, 0, 0, w.swz, w.rng_ctl, w.coef, "euler", w.ring, w.env_obs, w.step_count, 1, w.low, w.high,
+                         pcg_state=w.pcg, mt_state=w.mt)
+    with pytest.raises(Exception):  # no reset source
+        ops.rollout_step(w.env_obs, *w.w, 1, 0, 0, w.swz, w.rng_ctl, w.coef, "euler", w.ring, w.env_obs, w.step_count, 1, w.low, w.high)
+
+
+@pytest.mark.parametrize("algo", ["sac", "td3"])
+def test_learn_with_and_without_the_one_launch_rollout(algo, monkeypatch):
+    """learn() under hipGraph replay with the one-launch rollout and with the separate launches: identical weights, ring, sampler
+    stream and env state after 40 iterations (the two forms draw the same numbers in the same order)."""
+    from core.common import off_policy_algorithm as opa
+    from core.common.vec_env import CSTRVecEnv
+    from core.sac import SAC
+    from core.td3 import TD3
+
+    def run(fused_rollout):
+        monkeypatch.setattr(opa, "FUSED_ROLLOUT", fused_rollout)
+        env = CSTRVecEnv(2048, device="cuda")
+        model = (SAC if algo == "sac" else TD3)("MlpPolicy", env, seed=7, device="cuda", learning_starts=2048 * 2, buffer_size=2048 * 6)
+        model.enable_graph_capture(True)
+        model.learn(total_timesteps=2048 * 40)
+        th.cuda.synchronize()
+        assert model.graph_status()["active"] and model.graph_status()["replays"] > 20
+        if fused_rollout:
+            assert model._rollout_net() is not None  # the one-launch form really ran
+        rb = model.replay_buffer
+        flat = th.cat([p.detach().reshape(-1) for p in model.policy.parameters()])
+        return flat.clone(), rb.observations.clone(), rb.actions.clone(), rb.rewards.clone(), rb.sampler_stream.clone(), env.obs.clone(), rb.ring.ctl.clone()
+
+    a, b = run(True), run(False)
+    for i, (x, y) in enumerate(zip(a, b)):
+        assert th.equal(x, y), f"tensor {i} differs between the one-launch rollout and the separate launches"

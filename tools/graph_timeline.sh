@@ -21,7 +21,7 @@ for a, b in zip(rows, rows[1:]):
     if ns - s < 200000:  # not across a host gap
         dur[name(a)].append(e - s)
         itv[name(a)].append(ns - s)
-iters = max(len(v) for k, v in dur.items() if "collect_step" in k)
+iters = max(len(v) for k, v in dur.items() if "collect_step" in k or "rollout_step" in k)
 out = []
 for k in dur:
     out.append((sum(itv[k]) / iters / 1e3, k, len(dur[k]) / iters, statistics.mean(dur[k]) / 1e3, statistics.mean(itv[k]) / 1e3))

@@ -27,20 +27,30 @@ if __name__ == "__main__":
     n_out = 2 * a if head == 0 else a
     w3, b3 = r(n_out, h2) / 16, r(n_out)
     ctl, act, tiles = hip_ops.new_rng_ctl(1, "cuda"), th.empty(m, a, device="cuda"), hip_ops.policy_swizzle(w2)
+    rollout = "--rollout" in sys.argv  # the one-launch rollout (policy + collect step + index draw): stamp 7 of waves 0-1 = tail done
+    if rollout:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from test_rollout_step import _World
+
+        w = _World(hip_ops, m, 4, 244, 256, h1, h2, head, seed=1, max_steps=400)
+        w.step_count.zero_()
     for _ in range(20):
-        hip_ops.policy_rows_fwd(x, w1, b1, w2, b2, w3, b3, 1, head, 2 if head else 0, act, rng_ctl=ctl if head == 0 else None, w2_swz=tiles,
-                                defer_rng_advance=defer)
+        if rollout:
+            w.step_fused(None)
+        else:
+            hip_ops.policy_rows_fwd(x, w1, b1, w2, b2, w3, b3, 1, head, 2 if head else 0, act, rng_ctl=ctl if head == 0 else None, w2_swz=tiles,
+                                    defer_rng_advance=defer)
     th.cuda.synchronize()
     n_blocks = m // 16
-    words = n_blocks * 8 * 8
+    words = n_blocks * 16 * 8  # device layout: [(block * 16 + wave) * 8 + stamp]
     buf = (C.c_uint64 * words)()
     lib = nv.lib()
     lib.cstr_diag_policy_stamps.argtypes = [C.c_void_p, C.c_int64]
     assert lib.cstr_diag_policy_stamps(buf, words) == 0
-    st = np.frombuffer(buf, dtype=np.uint64).reshape(n_blocks, 8, 8).astype(np.int64)
+    st = np.frombuffer(buf, dtype=np.uint64).reshape(n_blocks, 16, 8)[:, :8, :].astype(np.int64)
     rel = st - st[:, :, 0].min(axis=1)[:, None, None]  # per workgroup (the counter differs between XCDs)
-    out = dict(shape=shape, defer=defer, clock_note="shader cycles (s_memtime); 2.4 GHz nominal -> 2400 cycles = 1 us")
-    names = ["start", "l1_done", "bar1", "l2_done", "bar2", "head_done", "tail_done", "noise_done(wave7)"]
+    out = dict(shape=shape, defer=defer, rollout=rollout, clock_note="shader cycles (s_memtime); 2.4 GHz nominal -> 2400 cycles = 1 us")
+    names = ["start", "l1_done", "bar1", "l2_done", "bar2", "head_done", "end", "noise_done(wave7)/tail_done(waves0-1,rollout)"]
     for i, nm in enumerate(names):
         v = rel[:, :, i]
         out[nm] = dict(per_wave_median=[int(np.median(v[:, w])) for w in range(8)])
