@@ -418,6 +418,160 @@ __device__ __forceinline__ void collect_env_lane(const cstr_coef_t &k, const Col
     c.step_count[i] = st;
 }
 
+// ---- the same collect step spread over the FOUR lanes of a quad (layouts with one reactor train, A = 2) --------------------------
+// The rollout kernel's sampling tail has eight lanes per env (thread = 8 * row + j) and nothing else to run: with a lane per
+// env the ~600-instruction step is a 2.8 us dependent chain on 8 active lanes of a wave (in-kernel stamps). Here lane j < 4 of
+// the env's group owns state component j (C1, T1 | C2, T2) and lanes 0, 1 own action component j: the per-component work
+// (denormalise, clip, update, normalise) is ONE instruction stream for four components, the two reactors' right-hand sides are
+// ONE stream for two reactors (lanes 0-1: reactor 1, lanes 2-3: reactor 2; each lane keeps dC or dT), the reward's terms are
+// evaluated beside each other. Every value is produced by the same IEEE operations in the same order as in cstr_step_lane /
+// collect_env_lane -- the lanes only exchange finished values (DPP quad permutes) -- so results are bit-identical.
+template <int P0, int P1, int P2, int P3>
+__device__ __forceinline__ float quad_perm(const float v)
+{
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), P0 | (P1 << 2) | (P2 << 4) | (P3 << 6), 0xF, 0xF, true));
+}
+
+__device__ __forceinline__ float sel4(const int j, const float a[4]) { return j == 0 ? a[0] : (j == 1 ? a[1] : (j == 2 ? a[2] : a[3])); }
+
+struct CollectInQ { float o, oraw, z, ep_ret; int32_t st; };
+
+template <int L>
+__device__ __forceinline__ void collect_quad_load(const CollectArgs &c, const int64_t i, const int j, CollectInQ &in)
+{
+    constexpr int D = Lay<L>::D;
+    in.o = c.env_obs[i * D + (j & 3)];
+    in.oraw = (L == 1) ? c.env_obs[i * D + 4 + (j & 3)] : 0.0f;
+    in.z = c.noise ? c.noise[i * 2 + (j & 1)] : 0.0f;
+    in.st = c.step_count[i];
+    in.ep_ret = c.ep_return ? c.ep_return[i] : 0.0f;
+}
+
+// one lane's share of cstr_rhs: d(component j)/dt of the state whose component j this lane holds in `sv`
+__device__ __forceinline__ float quad_rhs(const cstr_coef_t &k, const int j, const float sv, const float F_lane)
+{
+    const bool r2 = (j & 2) != 0;
+    const float C = quad_perm<0, 0, 2, 2>(sv), T = fmaxf(quad_perm<1, 1, 3, 3>(sv), 273.15f);              // :470-471
+    const float s0 = quad_perm<0, 0, 0, 0>(sv), T1 = fmaxf(quad_perm<1, 1, 1, 1>(sv), 273.15f);
+    const float F = fminf(fmaxf(quad_perm<0, 0, 1, 1>(F_lane), 1e-5f), 1e5f);                               // :472-473
+    float dC, dT;
+    reactor_rhs(k, r2 ? k.q_v2 : k.q_v1, r2 ? k.cool2 : k.cool1, r2 ? k.neg_ua2 : k.neg_ua1, r2 ? s0 : k.cf, r2 ? T1 : k.tf, C, T, F, dC, dT);
+    return (j & 1) ? dT : dC;
+}
+
+// All eight lanes of an env's group call this together (j = lane & 7; `live`: the env exists); lanes j >= 4 only keep the quad
+// permutes of their own quad well defined. u = the policy's action component j (lanes 0, 1).
+template <int L, int INTEG>
+__device__ __forceinline__ void collect_env_quad(const cstr_coef_t &k, const CollectArgs &c, const int64_t row, const int64_t i, const int j,
+                                                 const bool live, const float u, const CollectInQ &in)
+{
+    static_assert(L == 0 || L == 1, "one reactor train, two actions");
+    constexpr int D = Lay<L>::D;
+    const cstr_ring_t &ring = c.ring;
+    const int jj = j & 3, ja = j & 1;
+    const bool own = live && j < 4, lane0 = live && j == 0;
+    // action scaling chain of component ja (lanes 0, 1)
+    const float lo = ja ? c.ab.lo[1] : c.ab.lo[0], hi = ja ? c.ab.hi[1] : c.ab.hi[0];
+    float v = u, sa, ea;
+    if (c.squashed & 1) v = lo + (0.5f * (v + 1.0f) * (hi - lo));  // predict(): unscale_action (policies.py:375, :413)
+    if (c.squashed & 2) {
+        sa = ea = v;
+    } else {
+        float sc = 2.0f * ((v - lo) / (hi - lo)) - 1.0f;         // scale_action (policies.py:402)
+        if (c.noise) sc = fminf(fmaxf(sc + in.z, -1.0f), 1.0f);  // off_policy_algorithm.py:401-402
+        sa = sc;                                                  // buffer_action (:405)
+        ea = lo + (0.5f * (sc + 1.0f) * (hi - lo));               // unscale_action (:406)
+    }
+    // cstr_step_lane, component jj
+    const float s_lo = sel4(jj, k.s_lo), s_hi = sel4(jj, k.s_hi), s_span = sel4(jj, k.s_span);
+    const float an = fminf(fmaxf(ea, -1.0f), 1.0f);                                      // :399
+    const float F_lane = (ja ? k.a_lo[1] : k.a_lo[0]) + (an + 1.0f) * (ja ? k.a_span[1] : k.a_span[0]) / 2.0f;  // :148-149
+    const float o = in.o;
+    const float rr = s_lo + (o + 1.0f) * s_span / 2.0f;                                  // :404
+    const float s = fminf(fmaxf(rr, s_lo), s_hi);                                        // :406-410
+    const bool bad_l = j < 4 && ((o != o) || (j < 2 && ea != ea));
+    const unsigned long long bal = __ballot(bad_l);
+    const bool bad = ((bal >> (threadIdx.x & 56)) & 0xFull) != 0;                        // any lane of this env's quad
+    float n;
+    if (INTEG == CSTR_INTEGRATOR_EULER) {
+        n = s + quad_rhs(k, j, s, F_lane) * k.dt;                                        // :493-496
+    } else {
+        const float h = k.dt, h2 = 0.5f * k.dt;
+        const float k1 = quad_rhs(k, j, s, F_lane);
+        const float k2 = quad_rhs(k, j, s + h2 * k1, F_lane);
+        const float k3 = quad_rhs(k, j, s + h2 * k2, F_lane);
+        const float k4 = quad_rhs(k, j, s + h * k3, F_lane);
+        n = s + (h / 6.0f) * (k1 + 2.0f * k2 + 2.0f * k3 + k4);
+    }
+    float raw_new = fminf(fmaxf(n, s_lo), s_hi);                                         // :499-503, :424-428
+    float o_new = 2.0f * (raw_new - s_lo) / s_span - 1.0f;                               // :131, :429
+    // cstr_reward: every lane evaluates both kinds of term on ITS component, lane 0 picks C2's and T1's, T2's (:288-291, :331-341)
+    const float X = s_lo + (o_new + 1.0f) * s_span / 2.0f;
+    const float ne = fabsf(X - k.target_c2) / k.conc_span;
+    const float conc_l = -5.0f * (ne * ne) - 2.0f * ne;
+    float pen_l = 0.0f;
+    if (X < 280.0f) pen_l = 0.2f * ((280.0f - X) / 280.0f);
+    else if (X > 350.0f) pen_l = 0.5f * ((X - 350.0f) / 350.0f);
+    const float conc = quad_perm<2, 2, 2, 2>(conc_l), pen1 = quad_perm<1, 1, 1, 1>(pen_l), pen2 = quad_perm<3, 3, 3, 3>(pen_l);
+    float tp = 0.0f;
+    tp -= pen1;
+    tp -= pen2;
+    float r = 1.0f * conc + 0.5f * tp;                                                   // :432
+    int32_t st = in.st + 1;                                                              // :396
+    bool trunc = st >= k.max_steps;                                                      // :438
+    if (bad) {  // _dynamics raises (:466-467) -> step returns the old state, -10, truncated (:415-421)
+        o_new = o; raw_new = s; r = -10.0f; trunc = true;
+    }
+    const bool d = trunc;
+
+    // ring row (off_policy_algorithm.py:477-496): a lane per component
+    const int64_t e = row + i;
+    if (own) {
+        store_ring_f32(ring.obs, e * D + jj, o);
+        store_ring_f32(ring.next_obs, e * D + jj, o_new);
+        if (L == 1) {
+            store_ring_f32(ring.obs, e * D + 4 + jj, in.oraw);
+            store_ring_f32(ring.next_obs, e * D + 4 + jj, raw_new);
+        }
+        if (j < 2) store_ring_f32(ring.act, e * 2 + j, sa);
+    }
+    if (lane0) {
+        store_ring_f32(ring.rew, e, r);
+        store_ring_f32(ring.done, e, d ? 1.0f : 0.0f);
+        store_ring_f32(ring.timeout, e, trunc ? 1.0f : 0.0f);
+        if (c.reward_out) c.reward_out[i] = r;
+        if (c.done_out) c.done_out[i] = d ? 1.0f : 0.0f;
+        if (c.ep_return) {  // Monitor semantics: return/length of the episode that ends here
+            const float ret = in.ep_ret + r;
+            c.ep_return[i] = d ? 0.0f : ret;
+            if (d) {
+                atomicAdd(c.ep_stats + 0, 1.0);
+                atomicAdd(c.ep_stats + 1, (double)ret);
+                atomicAdd(c.ep_stats + 2, (double)st);
+            }
+        }
+        c.step_count[i] = d ? 0 : st;
+    }
+    // env state for the next iteration (dummy_vec_env.py:68-72)
+    if (d) {
+        if (lane0) {
+            if (c.reset_obs) {
+                copy_obs<L>(c.env_obs, i, c.reset_obs, i);
+            } else {
+                uint64_t pst[4];
+                load_pcg(c.pcg, i, pst);
+                float ro[2][4];
+                reset_draw_env<L>(k, pst, c.static_init, i, ro);
+                store_obs<L>(c.env_obs, i, ro);
+                *reinterpret_cast<ulonglong2 *>(c.pcg + 4 * i) = make_ulonglong2(pst[0], pst[1]);
+            }
+        }
+    } else if (own) {
+        c.env_obs[i * D + jj] = o_new;
+        if (L == 1) c.env_obs[i * D + 4 + jj] = raw_new;
+    }
+}
+
 }  // namespace
 
 // ---- host-side argument checks shared by the entry points that run the collect step ---------------------------------

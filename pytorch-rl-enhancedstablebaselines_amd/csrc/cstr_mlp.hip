@@ -1148,8 +1148,8 @@ __device__ __forceinline__ void v2_mfma_stage(const int c_begin, const int kc, c
 }
 
 // What the rollout launch (cstr_rollout_step_f32) does beyond the policy network: the fused collect step of the workgroup's 16 envs
-// on the sampling tail's lanes, and -- on ONE wave of the last workgroup, in the ~2 us the older waves of a SIMD wait for the
-// younger ones at the end of layer 2 -- this iteration's replay index draw (numpy legacy MT19937, cstr_mt_device.h).
+// on the sampling tail's lanes, and -- on ONE otherwise idle wave of the last workgroup, beside that tail -- this iteration's
+// replay index draw (numpy legacy MT19937, cstr_mt_device.h).
 struct RolloutArgs {
     cstr_coef_t k; CollectArgs c; const int64_t *ring_ctl; int layout, integrator;
     uint32_t *mt_state; int32_t *sample_idx; int batch;
@@ -1176,11 +1176,12 @@ __device__ __forceinline__ void policy_rows_v2_body(const PolicyArgs &a, const R
     const bool l1_wave = wave < L1_WAVES;
     constexpr int MT_Q = (MT_N + 63) / 64;
     __shared__ uint32_t mt_lds[FUSE ? MT_N : 1];
-    const bool mt_wave = FUSE && K0_SMALL && ro->mt_state != nullptr && blockIdx.x == gridDim.x - 1 && wave == 0;  // wave-uniform
+    const bool mt_wave = FUSE && K0_SMALL && ro->mt_state != nullptr && blockIdx.x == gridDim.x - 1 && wave == 2;  // wave-uniform
     uint32_t mtq[MT_Q];
     // the lanes that step an env at the end (thread 8 * row of the sampling tail, waves 0-1 = layer-1 waves)
     const bool env_lane = FUSE && K0_SMALL && tid < POLICY_ROWS * 8 && (tid & 7) == 0 && m0 + (tid >> 3) < a.m;
-    CollectIn env_in;
+    CollectIn env_in;   // layout 2 (two trains): a lane per env
+    CollectInQ env_q;   // layouts 0, 1: four lanes per env (collect_env_quad)
     const int64_t ring_pos = FUSE ? ro->ring_ctl[0] : 0;
     V2_STAMP(0);
 
@@ -1213,8 +1214,27 @@ __device__ __forceinline__ void policy_rows_v2_body(const PolicyArgs &a, const R
     // how many of the NB chunks are requested BEFORE the first barrier: a wave is held while it issues loads (~60 ns per 1 KB wave
     // load), and everybody waits at the barrier for the last issuer -- the rest follows right after the barrier, before the MFMAs
     // (waves 0-3, SMALL: none before layer 1 -- A/B on MI355X: 0 / 2 / 4 chunks ahead of layer 1 = 10.60 / 10.61 / 10.73 us)
-    constexpr int PRE_YOUNG = SMALL ? 12 : V2_CH, PRE_NOISE = SMALL ? 8 : V2_CH, PRE_OLD = SMALL ? 0 : V2_CH;
+    constexpr int PRE_YOUNG = SMALL ? 12 : V2_CH, PRE_OLD = SMALL ? 0 : V2_CH;
+    // who draws the Gaussian noise (~1.7 us of dependent VALU work that needs nothing from memory): wave 7, AFTER its weight requests.
+    // With the draw in front of them the requests sat behind everybody else's in the CU's in-order queue and wave 7 left layer 2
+    // ~1 us after the other seven (in-kernel stamps, profiles/r02_rollout_phase_stamps.json); on a layer-1 wave, between requesting
+    // its operands and using them, the draw delayed the first barrier by as much as it saved.
     const bool noise_wave = draw && wave == WAVES - 1;
+    auto draw_noise = [&]() {
+        const int64_t row = m0 + lane;
+        if (lane < POLICY_ROWS && row < a.m) {
+            for (int j0 = 0; j0 < a.act_dim; j0 += 2) {
+                const uint64_t ctr = base + (uint64_t)row;
+                uint32_t rnd[4];
+                float e0, e1;
+                philox4x32_10((uint32_t)ctr, (uint32_t)(ctr >> 32), (uint32_t)(j0 >> 1), 0u, (uint32_t)seed, (uint32_t)(seed >> 32), rnd);
+                box_muller(rnd[0], rnd[1], e0, e1);
+                eps_s[lane * 8 + j0] = e0;
+                if (j0 + 1 < a.act_dim) eps_s[lane * 8 + j0 + 1] = e1;
+            }
+        }
+        V2_STAMP(7);
+    };
     // zero the k padding of both activation images (widths that are not multiples of 16: the MFMA chunks read them)
     {
         const int p1 = 16 * kc1 - H1, p2 = 16 * kc2 - H2;
@@ -1222,23 +1242,8 @@ __device__ __forceinline__ void policy_rows_v2_body(const PolicyArgs &a, const R
         if (tid < POLICY_ROWS * p2) h2s[(tid / p2) * S2 + H2 + tid % p2] = 0.0f;
     }
     if (!l1_wave) {
-        if (!noise_wave) V2_REQUEST_B(0, PRE_YOUNG);
-        if (noise_wave) {
-            const int64_t row = m0 + lane;
-            if (lane < POLICY_ROWS && row < a.m) {
-                for (int j0 = 0; j0 < a.act_dim; j0 += 2) {
-                    const uint64_t ctr = base + (uint64_t)row;
-                    uint32_t rnd[4];
-                    float e0, e1;
-                    philox4x32_10((uint32_t)ctr, (uint32_t)(ctr >> 32), (uint32_t)(j0 >> 1), 0u, (uint32_t)seed, (uint32_t)(seed >> 32), rnd);
-                    box_muller(rnd[0], rnd[1], e0, e1);
-                    eps_s[lane * 8 + j0] = e0;
-                    if (j0 + 1 < a.act_dim) eps_s[lane * 8 + j0 + 1] = e1;
-                }
-            }
-            V2_STAMP(7);
-            V2_REQUEST_B(0, PRE_NOISE);  // the noise wave: its ~1 us chain first (it was the last arrival at the barrier), then its requests
-        }
+        V2_REQUEST_B(0, PRE_YOUNG);
+        if (noise_wave) draw_noise();
     } else if (K0_SMALL) {
         float4 w1v[L1_T];
         float b1v[L1_T];
@@ -1249,10 +1254,11 @@ __device__ __forceinline__ void policy_rows_v2_body(const PolicyArgs &a, const R
             w1v[i] = load_k4_clamped<VEC0>(a.w1 + (int64_t)min(n, H1 - 1) * a.k0, 4 * h, a.k0, n < H1);
             b1v[i] = a.b1[min(n, H1 - 1)];
         }
-        if (FUSE && env_lane) {  // the collect step's operands of this lane's env: requested now, used by the sampling tail
-            if (ro->layout == 0) collect_env_load<0>(ro->c, m0 + (tid >> 3), env_in);
-            else if (ro->layout == 1) collect_env_load<1>(ro->c, m0 + (tid >> 3), env_in);
-            else collect_env_load<2>(ro->c, m0 + (tid >> 3), env_in);
+        if (FUSE && wave < (POLICY_ROWS * 8) / 64) {  // the collect step's operands of this lane's env: requested now, used by the sampling tail
+            const int64_t e = min(m0 + (tid >> 3), a.m - 1);
+            if (ro->layout == 0) collect_quad_load<0>(ro->c, e, tid & 7, env_q);
+            else if (ro->layout == 1) collect_quad_load<1>(ro->c, e, tid & 7, env_q);
+            else if (env_lane) collect_env_load<2>(ro->c, e, env_in);
         }
         if (FUSE && mt_wave) {  // the sampler's MT19937 image: requested behind layer 1's operands, parked in LDS before the first barrier
 #pragma unroll
@@ -1305,7 +1311,6 @@ __device__ __forceinline__ void policy_rows_v2_body(const PolicyArgs &a, const R
     if (SMALL) {  // the rest of the wave's B operand
         if (l1_wave) V2_REQUEST_B(PRE_OLD, NB);
         else {
-            if (noise_wave) V2_REQUEST_B(PRE_NOISE, PRE_YOUNG);
             V2_REQUEST_B(PRE_YOUNG, NB);
         }
     }
@@ -1422,7 +1427,9 @@ __device__ __forceinline__ void policy_rows_v2_body(const PolicyArgs &a, const R
             for (int e = 0; e < 4; ++e) part[(wave * POLICY_ROWS + 4 * h + e) * 8 + r] = p0[e];
         }
     }
-    if (FUSE && mt_wave) {
+    __syncthreads();
+    V2_STAMP(5);
+    if (FUSE && mt_wave) {  // an idle wave from here on: the draw runs beside the sampling tail and the collect step of waves 0-1
         // ReplayBuffer.sample's two index draws for the gather launch behind this one (buffers.py:112-113, :309), with the ring
         // as ReplayBuffer.add leaves it after THIS launch's row: upper = rows if full else pos (buffers.py:280-283, :112)
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -1437,8 +1444,6 @@ __device__ __forceinline__ void policy_rows_v2_body(const PolicyArgs &a, const R
             if (lane + 64 * i < MT_N) ro->mt_state[lane + 64 * i] = mt_lds[lane + 64 * i];
         if (lane == 0) ro->mt_state[MT_N] = (uint32_t)pos;
     }
-    __syncthreads();
-    V2_STAMP(5);
 
     // tail: a lane per (row, output slot): thread = 8 * row + j
     const int trow = tid >> 3, j = tid & 7;
@@ -1493,18 +1498,18 @@ __device__ __forceinline__ void policy_rows_v2_body(const PolicyArgs &a, const R
         // the fused collect step (cstr_collect_step_f32) of the workgroup's 16 envs: lane (row, 0) of the tail gathers the row's
         // action components from its neighbours and steps env `row`; the ring position is only READ here (the gather launch behind
         // this one advances it: cstr_replay_gather_packed_f32), so no workgroup hands anything to another one
-        float u4[4];
-        u4[0] = act_out; u4[1] = __shfl_down(act_out, 1); u4[2] = __shfl_down(act_out, 2); u4[3] = __shfl_down(act_out, 3);
-        if (env_lane) {
-            const int64_t ring_row = ring_pos * ro->c.ring.n_envs;
-            const bool eu = ro->integrator == CSTR_INTEGRATOR_EULER;
-            if (ro->layout == 0) {
-                if (eu) collect_env_lane<0, CSTR_INTEGRATOR_EULER>(ro->k, ro->c, ring_row, row, u4, env_in);
-                else collect_env_lane<0, CSTR_INTEGRATOR_RK4>(ro->k, ro->c, ring_row, row, u4, env_in);
-            } else if (ro->layout == 1) {
-                if (eu) collect_env_lane<1, CSTR_INTEGRATOR_EULER>(ro->k, ro->c, ring_row, row, u4, env_in);
-                else collect_env_lane<1, CSTR_INTEGRATOR_RK4>(ro->k, ro->c, ring_row, row, u4, env_in);
-            } else {
+        const int64_t ring_row = ring_pos * ro->c.ring.n_envs, env = min(row, a.m - 1);
+        const bool eu = ro->integrator == CSTR_INTEGRATOR_EULER;
+        if (ro->layout == 0) {
+            if (eu) collect_env_quad<0, CSTR_INTEGRATOR_EULER>(ro->k, ro->c, ring_row, env, j, live, act_out, env_q);
+            else collect_env_quad<0, CSTR_INTEGRATOR_RK4>(ro->k, ro->c, ring_row, env, j, live, act_out, env_q);
+        } else if (ro->layout == 1) {
+            if (eu) collect_env_quad<1, CSTR_INTEGRATOR_EULER>(ro->k, ro->c, ring_row, env, j, live, act_out, env_q);
+            else collect_env_quad<1, CSTR_INTEGRATOR_RK4>(ro->k, ro->c, ring_row, env, j, live, act_out, env_q);
+        } else {
+            float u4[4];
+            u4[0] = act_out; u4[1] = __shfl_down(act_out, 1); u4[2] = __shfl_down(act_out, 2); u4[3] = __shfl_down(act_out, 3);
+            if (env_lane) {
                 if (eu) collect_env_lane<2, CSTR_INTEGRATOR_EULER>(ro->k, ro->c, ring_row, row, u4, env_in);
                 else collect_env_lane<2, CSTR_INTEGRATOR_RK4>(ro->k, ro->c, ring_row, row, u4, env_in);
             }
