@@ -247,6 +247,41 @@ def other_kernels(model, batch):
     flops = 2.0 * n_rows * (k0 * h + h * h + h * 2 * a)
     out["policy_rows_fwd_kernel"] = dict(launch_us=round(us, 3), launch_us_self_advancing=round(us_self, 3), shape=[n_rows, k0, h, h, 2 * a], bound="mfma",
                                          tflops=round(flops / us / 1e6, 2), frac=round(flops / us / 1e6 / F32_MFMA_PEAK_TFLOPS, 4))
+    # what the captured iteration really launches: the SAME network + the collect step of all envs + the replay index draw in one
+    # launch (cstr_rollout_step_f32), then the gather launch (cstr_replay_gather_packed_f32) -- against the three launches they replace
+    if k0 in (4, 8) and a == 2:
+        from core import _native as nv
+
+        ring = hip_ops.DeviceRing(8, n_rows, k0, a, p.device)
+        env_obs = (th.rand(n_rows, k0, device=p.device) * 2 - 1).contiguous()
+        steps = th.zeros(n_rows, dtype=th.int32, device=p.device)
+        pcg = th.randint(1, 2 ** 62, (n_rows, 4), device=p.device, dtype=th.int64)
+        idx = th.zeros(2, batch, dtype=th.int32, device=p.device)
+        coef, lo, hi = nv.default_coef(max_steps=1 << 30), [-1.0] * a, [1.0] * a
+        pbk = rb.alloc_packed_batch(batch)
+        integ = "euler" if k0 == 4 else "rk4"
+
+        def rollout():
+            hip_ops.rollout_step(env_obs, w1, b1, w, bias, w3, b3, 1, 0, 0, w_tiles, ctl, coef, integ, ring, env_obs, steps, 1, lo, hi,
+                                 pcg_state=pcg, mt_state=mt, sample_idx=idx)
+
+        def gather():
+            hip_ops.replay_gather_packed(ring, idx, batch, pbk.x_data, pbk.x_next, pbk.x_pi, pbk.samples.dones, pbk.samples.rewards,
+                                         advance_ring=True, rng_advance=(ctl, n_rows))
+
+        def separate():
+            hip_ops.policy_rows_fwd(env_obs, w1, b1, w, bias, w3, b3, 1, 0, 0, act_out, rng_ctl=ctl, w2_swz=w_tiles, defer_rng_advance=True)
+            hip_ops.collect_step(coef, integ, ring, env_obs, steps, act_out, 1, lo, hi, pcg_state=pcg, rng_advance=(ctl, n_rows))
+            hip_ops.replay_sample_packed(ring, mt, batch, pbk.x_data, pbk.x_next, pbk.x_pi, pbk.samples.dones, pbk.samples.rewards)
+
+        rollout(), gather()
+        us_r = event_time_us(rollout, 100, stream, in_graph=True)
+        us_rg = event_time_us(lambda: (rollout(), gather()), 100, stream, in_graph=True)
+        us_sep = event_time_us(separate, 100, stream, in_graph=True)
+        out["rollout_step_kernel"] = dict(launch_us=round(us_r, 3), with_gather_launch_us=round(us_rg, 3), three_separate_launches_us=round(us_sep, 3),
+                                          shape=[n_rows, k0, h, h, 2 * a], bound="mfma", tflops=round(flops / us_r / 1e6, 2),
+                                          frac=round(flops / us_r / 1e6 / F32_MFMA_PEAK_TFLOPS, 4),
+                                          note="policy network (the MFMA work priced here) + fused collect step of all envs + replay index draw")
     return out
 
 
@@ -548,6 +583,12 @@ def main():
                     pass
             line["roofline_mfma"] = dict(bound="mfma", kernel="policy_rows_fwd_kernel", achieved=pk["tflops"], peak=F32_MFMA_PEAK_TFLOPS,
                                          unit="TFLOP/s", frac=pk["frac"], traffic=traffic, launch_us=pk["launch_us"], shape=pk["shape"])
+            rk = line["kernels"].get("rollout_step_kernel")
+            if rk is not None:  # the launch the captured iteration runs: the same matrix work + the env step + the index draw
+                line["roofline_mfma"]["as_launched"] = dict(kernel="rollout_step_kernel", achieved=rk["tflops"], frac=rk["frac"], launch_us=rk["launch_us"],
+                                                            note="the policy network's FLOPs over the whole one-launch rollout (policy + collect "
+                                                                 "step of all envs + replay index draw: it replaces policy_rows_fwd_kernel + "
+                                                                 "collect_step_kernel + most of replay_sample_kernel)")
         if world == 1 and not args.no_variant and args.algo == "sac" and (args.obs_dim, args.integrator) == (4, "euler"):
             del model, env
             dev = f"cuda:{local_rank}"

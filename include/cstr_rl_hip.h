@@ -209,6 +209,20 @@ int cstr_replay_gather_packed_f32(const cstr_ring_t *ring, int64_t *ring_ctl, in
                                   float *x_pi, float *out_done, float *out_rew, int64_t *out_row_idx, int64_t *out_env_idx,
                                   cstr_stream_t stream);
 
+/* ReplayBuffer.sample's gather FUSED INTO ITS FIRST CONSUMER: y [M][n] = act(x W^T + b) where the input rows x are the sampled
+ * transitions themselves, read from the ring by the index pairs of cstr_rollout_step_f32 (sample_idx as in
+ * cstr_replay_gather_packed_f32). both != 0: M = 2 batch, rows [0, batch) = observations, rows [batch, 2 batch) = next
+ * observations (SAC's two actor passes of a gradient step as one 2B-row pass, core/sac/sac.py:222, :247); both == 0: M = batch
+ * rows of next observations (a target actor's first layer, core/td3/td3.py:173). w [n][obs_dim], bias [n]; act 0 none / 1 ReLU /
+ * 2 Tanh. The launch also writes the packed batch of cstr_replay_sample_packed_mt19937_f32 (x_data, x_next, x_pi or NULL,
+ * out_done, out_rew) for the launches behind it and performs the control-word updates of cstr_replay_gather_packed_f32
+ * (advance_ring, rng_ctl / rng_advance): one launch and one dependent launch boundary less per gradient step. Results are
+ * bit-identical to cstr_replay_gather_packed_f32 followed by cstr_linear_act_fwd_f32. */
+int cstr_linear_act_fwd_gather_f32(const cstr_ring_t *ring, int64_t *ring_ctl, int advance_ring, uint64_t *rng_ctl, uint64_t rng_advance,
+                                   const int32_t *sample_idx, int64_t batch, int both, const float *w, const float *bias, int act, float *y,
+                                   int64_t n, float *x_data, float *x_next, float *x_pi, float *out_done, float *out_rew,
+                                   cstr_stream_t stream);
+
 /* Target-Q: SAC core/sac/sac.py:250-254 (logp, ent_coef non-NULL), TD3 core/td3/td3.py:174-176 (both NULL):
  * out = rew + (1 - done) * gamma * (min(q1, q2) - ent_coef[0] * logp). ent_coef is a DEVICE scalar. */
 int cstr_td_target_min_f32(const float *q1, const float *q2, const float *logp, const float *rew, const float *done,

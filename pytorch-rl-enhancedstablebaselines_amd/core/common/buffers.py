@@ -183,6 +183,15 @@ class ReplayBuffer(BaseBuffer):
             raise RuntimeError("a pre-drawn sample is already pending")
         self._predrawn = (sample_idx, rng_advance)
 
+    def take_predrawn(self, pb: "PackedBatch"):
+        """Hand the pending pre-drawn sample to a consumer that gathers the rows itself (hip_ops.linear_act_fwd_gather: the first layer
+        behind the sample) and performs the control-word updates: returns (ring, sample_idx, rng_advance, pb), or None if no
+        pre-drawn sample of this batch size is pending."""
+        if self._predrawn is None or self._predrawn[0].shape[1] != pb.x_data.shape[0] or self.normalizer is not None:
+            return None
+        (idx, rng_advance), self._predrawn = self._predrawn, None
+        return self.ring, idx, rng_advance, pb
+
     def _no_predrawn(self, what: str) -> None:
         if self._predrawn is not None:
             raise RuntimeError(f"{what}: a rollout launch left its ring advance to the next packed sample, which has not run yet")

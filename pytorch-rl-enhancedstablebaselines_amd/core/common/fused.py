@@ -38,6 +38,9 @@ WHOLE_NET_MIN_ROWS = 1024
 USE_FUSED_LINEAR = os.environ.get("CSTR_FUSED_LINEAR", "1") != "0"
 # development A/B knobs: the 2B-row actor pass (_ActorPairFn) and the four-network critic / target chain (_TwinPairFn)
 USE_ACTOR_PAIR = os.environ.get("CSTR_ACTOR_PAIR", "1") != "0"
+# SAC: when the rollout launch has drawn the batch indices, the 2B-row actor pass's first layer gathers the sampled rows itself
+# (hip_ops.linear_act_fwd_gather) instead of a gather launch in front of it; "0" keeps the gather launch (A/B, bit-identical)
+USE_GATHER_IN_FIRST_LAYER = os.environ.get("CSTR_GATHER_IN_L1", "1") != "0"
 USE_TWIN_PAIR = os.environ.get("CSTR_TWIN_PAIR", "1") != "0"
 USE_LOSS_ROOT = os.environ.get("CSTR_LOSS_ROOT", "1") != "0"  # the loss launches ride in the backward's first launch
 
@@ -646,8 +649,10 @@ class FastSacActor:
                 and layers[1][0].out_features % 4 == 0 and len(q) in (0, 2) and self._hw.is_contiguous()
                 and all(lin.weight.grad is not None and lin.bias.grad is not None for lin, _ in layers))
 
-    def action_log_prob_pair(self, pb):
-        """(x_pi, log pi(a|obs)) with gradients and (x_next, log pi(a'|next_obs)) without, from ONE 2B-row pass (_ActorPairFn)."""
+    def action_log_prob_pair(self, pb, gather=None):
+        """(x_pi, log pi(a|obs)) with gradients and (x_next, log pi(a'|next_obs)) without, from ONE 2B-row pass (_ActorPairFn).
+        `gather` = ReplayBuffer.take_predrawn(pb): the batch has not been gathered yet -- the pass's first layer reads the sampled
+        rows from the ring itself and writes `pb` for the launches behind it (hip_ops.linear_act_fwd_gather)."""
         dist = self.actor.action_dist
         b, a = pb.x_pi.shape[0], self.act_dim
         eps2 = None
@@ -659,7 +664,7 @@ class FastSacActor:
         grads = (l1.weight.grad, l1.bias.grad, l2.weight.grad, l2.bias.grad, self._hwg, self._hbg)
         x2 = pb.x_pn[:, :pb.obs_dim]
         return _ActorPairFn.apply(x2, l1.weight, l1.bias, l2.weight, l2.bias, self._hw, self._hb, grads, act, eps2, self.rng_ctl,
-                                  pb.x_pi.detach(), pb.x_next.detach(), True, l1.weight, l2.weight, self.mu.weight, self.log_std.weight)
+                                  pb.x_pi.detach(), pb.x_next.detach(), True, gather, l1.weight, l2.weight, self.mu.weight, self.log_std.weight)
 
     def dist_params(self, obs: th.Tensor, train_params: bool = True) -> th.Tensor:
         """[B, 2A] = [mean | log_std_raw]"""
@@ -803,10 +808,15 @@ class _ActorPairFn(th.autograd.Function):
     of the two separate launches (counter = offset + row, obs rows first). Two hidden layers + the merged head only."""
 
     @staticmethod
-    def forward(ctx, x2, w1, b1, w2, b2, hw, hb, grads, act: int, eps2, rng_ctl, xbuf_pi, xbuf_next, train_params: bool, *owners):
+    def forward(ctx, x2, w1, b1, w2, b2, hw, hb, grads, act: int, eps2, rng_ctl, xbuf_pi, xbuf_next, train_params: bool, gather, *owners):
         n2, a = x2.shape[0], hw.shape[0] // 2
         n = n2 // 2
-        h1 = hip_ops.linear_act_fwd(x2, w1, b1, act)
+        if gather is not None:  # the sampled rows come straight from the ring; x2 (a view of pb.x_pn) is written by this launch
+            ring, idx, rng_advance, pb = gather
+            h1 = hip_ops.linear_act_fwd_gather(ring, idx, n, True, w1, b1, act, pb.x_data, pb.x_next, pb.x_pi, pb.samples.dones,
+                                               pb.samples.rewards, advance_ring=True, rng_advance=rng_advance)
+        else:
+            h1 = hip_ops.linear_act_fwd(x2, w1, b1, act)
         h2 = hip_ops.linear_act_fwd(h1, w2, b2, act)
         params = th.empty(n2, 2 * a, dtype=h2.dtype, device=h2.device)
         logp = th.empty(n2, dtype=h2.dtype, device=h2.device)
@@ -845,7 +855,7 @@ class _ActorPairFn(th.autograd.Function):
             _weight_grad(g_params, h2, hwg, hbg)
             _weight_grad(dz2, h1, w2g, b2g)
             _weight_grad(dz1, x, w1g, b1g)
-        return (None,) * (14 + ctx.n_owners)
+        return (None,) * (15 + ctx.n_owners)
 
 
 class _TwinPairFn(th.autograd.Function):

@@ -229,6 +229,31 @@ def replay_gather_packed(ring: DeviceRing, sample_idx, batch: int, x_data, x_nex
           "cstr_replay_gather_packed_f32")
 
 
+def linear_act_fwd_gather(ring: DeviceRing, sample_idx, batch: int, both: bool, weight, bias, act: int, x_data, x_next, x_pi, out_done,
+                          out_rew, advance_ring: bool = False, rng_advance=None, out=None):
+    """`replay_gather_packed` fused into the first Linear layer behind it (cstr_linear_act_fwd_gather_f32): y = act(x W^T + b) with
+    x = the sampled observations (rows [0, B)) and next observations (rows [B, 2B)) for `both`, else the B next observations; the
+    packed batch is written for the later launches and the control words are advanced like `replay_gather_packed` does."""
+    d, w = ring.obs_dim, ring.obs_dim + ring.act_dim
+    n = weight.shape[0]
+    m = 2 * batch if both else batch
+    _chk(sample_idx, "sample_idx", (2, batch), th.int32), _chk(weight, "weight", (n, d), th.float32), _chk(bias, "bias", (n,), th.float32)
+    _chk(x_data, "x_data", (batch, w), th.float32), _chk(x_next, "x_next", (batch, w), th.float32), _opt(x_pi, "x_pi", (batch, w), th.float32)
+    _chk(out_done, "out_done", (batch, 1), th.float32), _chk(out_rew, "out_rew", (batch, 1), th.float32)
+    if not 0 < batch <= nv.MAX_SAMPLE_BATCH:
+        raise ValueError(f"batch_size must be in [1, {nv.MAX_SAMPLE_BATCH}], got {batch}")
+    if out is None:
+        out = th.empty(m, n, dtype=th.float32, device=weight.device)
+    _chk(out, "out", (m, n), th.float32)
+    rng_ctl, rng_count = rng_advance if rng_advance is not None else (None, 0)
+    _opt(rng_ctl, "rng_ctl", (nv.RNG_CTL_WORDS,), th.int64)
+    check(nv.lib().cstr_linear_act_fwd_gather_f32(C.byref(ring.c), ptr(ring.ctl), C.c_int(1 if advance_ring else 0), ptr(rng_ctl),
+                                                  C.c_uint64(int(rng_count)), ptr(sample_idx), C.c_int64(batch), C.c_int(1 if both else 0),
+                                                  ptr(weight), ptr(bias), C.c_int(act), ptr(out), C.c_int64(n), ptr(x_data), ptr(x_next),
+                                                  ptr(x_pi), ptr(out_done), ptr(out_rew), stream_ptr()), "cstr_linear_act_fwd_gather_f32")
+    return out
+
+
 def td_target_min(q1, q2, logp, rew, done, ent_coef, gamma: float, out):
     n = q1.numel()
     for t, nm in ((q1, "q1"), (q2, "q2"), (rew, "rew"), (done, "done"), (out, "out")):

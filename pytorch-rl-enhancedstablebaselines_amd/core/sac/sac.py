@@ -173,9 +173,14 @@ class SAC(OffPolicyAlgorithm):
         single = getattr(self, "_single_step", False)
         acc = (lambda k: None) if single else (lambda k: s[k])  # accumulate into the sums ...
         sto = (lambda k, other: s[k]) if single else (lambda k, other: other)  # ... or store straight into them
-        pb = None
+        pb, gather = None, None
         if self._use_packed_batch():
-            pb = self.replay_buffer.sample_packed_into(self._packed_batch(batch_size))  # :215 + the critics' cat([obs, act])
+            pb = self._packed_batch(batch_size)
+            if fused.USE_GATHER_IN_FIRST_LAYER and self._fast_actor.pair_supported(pb):
+                # indices drawn by the rollout launch: the 2B-row actor pass below gathers the rows in its first layer
+                gather = self.replay_buffer.take_predrawn(pb)
+            if gather is None:
+                self.replay_buffer.sample_packed_into(pb)  # :215 + the critics' cat([obs, act])
             rd = pb.samples
         else:
             rd = self.replay_buffer.sample_into(self._batch(batch_size))  # :215
@@ -187,8 +192,9 @@ class SAC(OffPolicyAlgorithm):
         gq1, gq2 = gq[0], gq[1]
 
         pair = pb is not None and self._fast_actor.pair_supported(pb)
+        assert gather is None or pair
         if pair:  # :222 and :247 in ONE 2B-row actor pass (three launches instead of six)
-            x_pi, log_prob, x_next, next_log_prob = self._fast_actor.action_log_prob_pair(pb)
+            x_pi, log_prob, x_next, next_log_prob = self._fast_actor.action_log_prob_pair(pb, gather=gather)
         elif pb is not None:  # x_pi = (obs | pi(obs)): the actor head writes the action columns of the critic input itself
             x_pi, log_prob = self._fast_actor.action_log_prob(rd.observations, xbuf=pb.x_pi.detach())  # :222
         else:

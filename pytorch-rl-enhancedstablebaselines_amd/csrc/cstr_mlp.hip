@@ -220,6 +220,112 @@ __global__ __launch_bounds__(64 * WAVES) void linear_act_fwd_kernel(const float 
     }
 }
 
+// The FIRST layer behind ReplayBuffer.sample with the gather inside (cstr_linear_act_fwd_gather_f32): its input rows are the
+// sampled transitions themselves, fetched from the replay ring by the (row, env) index pairs an earlier launch drew
+// (cstr_rollout_step_f32), so the gather launch and one dependent launch boundary disappear. Rows [0, B) = observations of the
+// batch, rows [B, 2B) = next observations (SAC's 2B-row actor pass; `both` = 0: B rows of next observations only, TD3's target
+// actor). K = D <= 8 is ONE k chunk: one wave per 16 x 16 output tile, the same MFMA sequence as linear_act_fwd_kernel (bit-
+// identical). The workgroups of the first column tile also MATERIALISE the packed batch for the launches behind this one
+// (x_data = (obs | act), the observation columns of x_pi / x_next, rewards, dones*(1 - timeouts): ReplayBuffer._get_samples,
+// core/common/buffers.py:316-323), and thread 0 of the launch performs the control-word updates of the gather launch (nobody
+// reads them here).
+struct GatherArgs {
+    cstr_ring_t ring; int64_t *ring_ctl; int advance_ring; uint64_t *rng_ctl; uint64_t rng_advance;
+    const int32_t *idx; int batch, both;
+    float *x_data, *x_pi, *x_next, *out_done, *out_rew;
+};
+
+template <int ACT, int D, int A>
+__global__ __launch_bounds__(64) void gather_linear_act_fwd_kernel(const GatherArgs g, const float *__restrict__ w, const float *__restrict__ bias,
+                                                                   float *__restrict__ y, const int N)
+{
+    constexpr int W = D + A;
+    const int lane = threadIdx.x, r = lane & 15, h = lane >> 4;
+    const int n0 = blockIdx.x * 16, m0 = blockIdx.y * 16, B = g.batch, M = g.both ? 2 * B : B;
+    const bool row_ok = m0 + r < M, col_ok = n0 + r < N;
+    const int m = min(m0 + r, M - 1);
+    const bool next = !g.both || m >= B;  // which half of the transition this row reads
+    const int b = m >= B ? m - B : m;
+    const int64_t o = (int64_t)g.idx[b] * g.ring.n_envs + g.idx[B + b];
+    const float *src = (next ? g.ring.next_obs : g.ring.obs) + o * D;
+    float4 a = *reinterpret_cast<const float4 *>(src + min(4 * h, D - 4));
+    float4 bw = *reinterpret_cast<const float4 *>(w + (int64_t)min(n0 + r, N - 1) * D + min(4 * h, D - 4));
+    const bool first = blockIdx.x == 0 && row_ok;  // this workgroup also writes the packed batch rows of its 16 samples
+    float4 obs = a;
+    float2 act[A / 2];
+    float dn = 0.0f, to = 0.0f, rw = 0.0f;
+    if (first && 4 * h < D) {
+        if (!g.both) obs = *reinterpret_cast<const float4 *>(g.ring.obs + o * D + 4 * h);
+        if (!next || !g.both) {
+            if (h == 0) {
+#pragma unroll
+                for (int jj = 0; jj < A / 2; ++jj) act[jj] = *reinterpret_cast<const float2 *>(g.ring.act + o * A + 2 * jj);
+                dn = g.ring.done[o]; to = g.ring.timeout[o]; rw = g.ring.rew[o];
+            }
+        }
+    }
+    const bool k_ok = 4 * h < D;
+    if (!k_ok || !row_ok) a = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (!k_ok || !col_ok) bw = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bw.x, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bw.y, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bw.z, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bw.w, acc1, 0, 0, 0);
+    const f32x4 acc = acc0 + acc1;
+    const int col = n0 + r;
+    if (col < N) {
+        const float bv = bias[col];
+        float *yo = y + (int64_t)(m0 + 4 * h) * N + col;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (m0 + 4 * h + e < M) {
+                float v = acc[e] + bv;
+                if (ACT == ACT_RELU) v = fmaxf(v, 0.0f);
+                if (ACT == ACT_TANH) v = tanhf(v);
+                yo[(int64_t)e * N] = v;
+            }
+        }
+    }
+    if (first && k_ok) {
+        const float2 lo = make_float2(a.x, a.y), hi = make_float2(a.z, a.w);  // this row's own half (row_ok, k_ok: `a` is the loaded value)
+        if (g.both) {
+            float *base = next ? g.x_next : g.x_pi;
+            if (base) {
+                float *xo = base + (int64_t)b * W + 4 * h;
+                reinterpret_cast<float2 *>(xo)[0] = lo; reinterpret_cast<float2 *>(xo)[1] = hi;
+            }
+        } else {
+            float *xn = g.x_next + (int64_t)b * W + 4 * h;
+            reinterpret_cast<float2 *>(xn)[0] = lo; reinterpret_cast<float2 *>(xn)[1] = hi;
+            if (g.x_pi) {
+                float *xp = g.x_pi + (int64_t)b * W + 4 * h;
+                reinterpret_cast<float2 *>(xp)[0] = make_float2(obs.x, obs.y); reinterpret_cast<float2 *>(xp)[1] = make_float2(obs.z, obs.w);
+            }
+        }
+        if (!next || !g.both) {
+            float *xd = g.x_data + (int64_t)b * W;
+            reinterpret_cast<float2 *>(xd + 4 * h)[0] = make_float2(obs.x, obs.y);
+            reinterpret_cast<float2 *>(xd + 4 * h)[1] = make_float2(obs.z, obs.w);
+            if (h == 0) {
+#pragma unroll
+                for (int jj = 0; jj < A / 2; ++jj) *reinterpret_cast<float2 *>(xd + D + 2 * jj) = act[jj];
+                g.out_done[b] = dn * (1.0f - to);  // buffers.py:322
+                g.out_rew[b] = rw;
+            }
+        }
+    }
+    if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0) {
+        if (g.advance_ring) {  // ReplayBuffer.add's epilogue (core/common/buffers.py:280-283), left over by the rollout launch
+            int64_t pos = g.ring_ctl[0] + 1;
+            if (pos == g.ring.rows) { g.ring_ctl[1] = 1; pos = 0; }
+            g.ring_ctl[0] = pos;
+            g.ring_ctl[3] += 1;
+        }
+        if (g.rng_ctl) g.rng_ctl[1] += g.rng_advance;
+    }
+}
+
 // Pointer-table form: up to CSTR_MAX_LINEAR_SETS independent Linear layers of one shape -- every agent's actor layer in
 // MADDPG (core/maddpg/policies.py: one MLP per agent, parameters in per-agent arena slices) -- in ONE launch. Each set has
 // its own input, weight, bias and output; the output may be a column block of a wider row (the joint action).
@@ -2208,6 +2314,32 @@ extern "C" int cstr_linear_act_fwd_f32(const float *x, int64_t x_group_stride, i
     else { if (split) LIN_ACT(false, 4); else LIN_ACT(false, 1); }
 #undef LIN_ACT
 #undef LIN
+    return (int)hipGetLastError();
+}
+
+extern "C" int cstr_linear_act_fwd_gather_f32(const cstr_ring_t *ring, int64_t *ring_ctl, int advance_ring, uint64_t *rng_ctl,
+                                              uint64_t rng_advance, const int32_t *sample_idx, int64_t batch, int both, const float *w,
+                                              const float *bias, int act, float *y, int64_t n, float *x_data, float *x_next, float *x_pi,
+                                              float *out_done, float *out_rew, cstr_stream_t stream)
+{
+    if (!ring || !ring->obs || !ring->next_obs || !ring->act || !ring->rew || !ring->done || !ring->timeout) return CSTR_E_BADARG;
+    if (!sample_idx || !w || !bias || !y || !x_data || !x_next || !out_done || !out_rew || batch <= 0 || n <= 0) return CSTR_E_BADARG;
+    if (advance_ring && !ring_ctl) return CSTR_E_BADARG;
+    if (act < 0 || act > 2) return CSTR_E_BADARG;
+    const int lay = layout_of(ring->obs_dim, ring->act_dim);
+    if (lay < 0 || batch > CSTR_MAX_SAMPLE_BATCH || n > 0x7ffffff || ring->rows >= 0xFFFFFFFFLL || ring->n_envs >= 0xFFFFFFFFLL) return CSTR_E_UNSUPPORTED;
+    if (!aligned16(ring->obs) || !aligned16(ring->next_obs) || !aligned8(ring->act) || !aligned16(w) || !aligned8(x_data) || !aligned8(x_next) ||
+        (x_pi && !aligned8(x_pi)))
+        return CSTR_E_BADARG;
+    const GatherArgs g = {*ring, ring_ctl, advance_ring, rng_ctl, rng_advance, sample_idx, (int)batch, both ? 1 : 0, x_data, x_pi, x_next, out_done, out_rew};
+    const int64_t m = both ? 2 * batch : batch;
+    const dim3 grid((unsigned)((n + 15) / 16), (unsigned)((m + 15) / 16));
+    hipStream_t s = (hipStream_t)stream;
+#define GL2(A_, D_, AD_) gather_linear_act_fwd_kernel<A_, D_, AD_><<<grid, 64, 0, s>>>(g, w, bias, y, (int)n)
+#define GL(A_) do { if (lay == 0) GL2(A_, 4, 2); else if (lay == 1) GL2(A_, 8, 2); else GL2(A_, 8, 4); } while (0)
+    if (act == 0) GL(0); else if (act == 1) GL(1); else GL(2);
+#undef GL
+#undef GL2
     return (int)hipGetLastError();
 }
 

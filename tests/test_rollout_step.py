@@ -178,3 +178,63 @@ def test_learn_with_and_without_the_one_launch_rollout(algo, monkeypatch):
     a, b = run(True), run(False)
     for i, (x, y) in enumerate(zip(a, b)):
         assert th.equal(x, y), f"tensor {i} differs between the one-launch rollout and the separate launches"
+
+
+@pytest.mark.parametrize("d,a,batch,n_out,both,act", [(4, 2, 256, 256, True, 1), (8, 2, 100, 64, True, 2), (4, 2, 300, 400, False, 1),
+                                                     (8, 4, 64, 48, True, 0), (4, 2, 16, 20, False, 2)])
+def test_first_layer_with_the_gather_inside(ops, d, a, batch, n_out, both, act):
+    """cstr_linear_act_fwd_gather_f32 against cstr_replay_gather_packed_f32 followed by cstr_linear_act_fwd_f32 on the gathered
+    rows: layer output, packed batch, ring and Philox control words bit-identical."""
+    g = th.Generator(device="cuda").manual_seed(batch + n_out)
+    rows, n = 9, 333
+    ring_a, ring_b = ops.DeviceRing(rows, n, d, a, "cuda"), ops.DeviceRing(rows, n, d, a, "cuda")
+    for ra, rb_ in ((ring_a.observations, ring_b.observations), (ring_a.next_observations, ring_b.next_observations),
+                    (ring_a.actions, ring_b.actions), (ring_a.rewards, ring_b.rewards)):
+        ra.copy_(th.randn(ra.shape, device="cuda", generator=g))
+        rb_.copy_(ra)
+    for ra, rb_ in ((ring_a.dones, ring_b.dones), (ring_a.timeouts, ring_b.timeouts)):
+        ra.copy_((th.rand(ra.shape, device="cuda", generator=g) < 0.3).float())
+        rb_.copy_(ra)
+    for r in (ring_a, ring_b):
+        r.ctl.copy_(th.tensor([rows - 1, 0, 0, rows - 1]))  # the advance wraps the position and sets `full`
+    idx = th.stack([th.randint(0, rows, (batch,), device="cuda", generator=g), th.randint(0, n, (batch,), device="cuda", generator=g)]).int().contiguous()
+    w1, b1 = th.randn(n_out, d, device="cuda", generator=g), th.randn(n_out, device="cuda", generator=g)
+    ca, cb = ops.new_rng_ctl(5, "cuda"), ops.new_rng_ctl(5, "cuda")
+    w = d + a
+    mk = lambda: (th.full((batch, w), 7.0, device="cuda"), th.full((2 * batch, w), 7.0, device="cuda"), th.zeros(batch, 1, device="cuda"),  # noqa: E731
+                  th.zeros(batch, 1, device="cuda"))
+    xd_a, xpn_a, dn_a, rw_a = mk()
+    xd_b, xpn_b, dn_b, rw_b = mk()
+    ops.replay_gather_packed(ring_a, idx, batch, xd_a, xpn_a[batch:], xpn_a[:batch], dn_a, rw_a, advance_ring=True, rng_advance=(ca, 4096))
+    x_in = xpn_a[:, :d] if both else xpn_a[batch:, :d]
+    y_a = ops.linear_act_fwd(x_in, w1, b1, act)
+    y_b = ops.linear_act_fwd_gather(ring_b, idx, batch, both, w1, b1, act, xd_b, xpn_b[batch:], xpn_b[:batch], dn_b, rw_b, advance_ring=True,
+                                    rng_advance=(cb, 4096))
+    th.cuda.synchronize()
+    assert th.equal(y_a, y_b)
+    assert th.equal(xd_a, xd_b) and th.equal(xpn_a, xpn_b) and th.equal(dn_a, dn_b) and th.equal(rw_a, rw_b)
+    assert float(xpn_b[:, d:].min()) == 7.0  # the action columns of x_pi / x_next belong to the actor head
+    assert th.equal(ring_a.ctl, ring_b.ctl) and ring_b.ctl.tolist() == [0, 1, 0, rows] and th.equal(ca, cb)
+
+
+def test_sac_learn_with_the_gather_in_the_first_layer(monkeypatch):
+    """SAC under hipGraph replay: gather inside the actor pass's first layer vs the gather launch in front of it: identical weights,
+    sampler stream and ring after 40 iterations."""
+    from core.common import fused
+    from core.common.vec_env import CSTRVecEnv
+    from core.sac import SAC
+
+    def run(flag):
+        monkeypatch.setattr(fused, "USE_GATHER_IN_FIRST_LAYER", flag)
+        env = CSTRVecEnv(2048, device="cuda")
+        model = SAC("MlpPolicy", env, seed=11, device="cuda", learning_starts=2048 * 2, buffer_size=2048 * 6)
+        model.enable_graph_capture(True)
+        model.learn(total_timesteps=2048 * 40)
+        th.cuda.synchronize()
+        assert model.graph_status()["active"] and model.graph_status()["replays"] > 20
+        rb = model.replay_buffer
+        flat = th.cat([p.detach().reshape(-1) for p in model.policy.parameters()])
+        return flat.clone(), rb.sampler_stream.clone(), rb.ring.ctl.clone(), rb.rewards.clone(), model._fast_actor.rng_ctl.clone()
+
+    for i, (x, y) in enumerate(zip(run(True), run(False))):
+        assert th.equal(x, y), f"tensor {i} differs"
