@@ -62,7 +62,7 @@ def parse():
     ap.add_argument("--obs-dim", type=int, default=4, choices=[4, 8])
     ap.add_argument("--integrator", default="euler", choices=["euler", "rk4"])
     ap.add_argument("--graph", type=int, default=int(os.environ.get("CSTR_BENCH_GRAPH", "1")))
-    ap.add_argument("--graph-unroll", type=int, default=int(os.environ.get("CSTR_GRAPH_UNROLL", "4")),
+    ap.add_argument("--graph-unroll", type=int, default=int(os.environ.get("CSTR_GRAPH_UNROLL", "8")),
                     help="iterations recorded per hipGraph on one GPU: the ~9 us the GPU idles between two graph launches "
                          "(tools/graph_timeline.sh) is paid once per replay; the same launches in the same order")
     ap.add_argument("--blas", default=os.environ.get("CSTR_BLAS", "rocblas"), choices=["rocblas", "hipblaslt", "default"])

@@ -253,15 +253,42 @@ class FastMLP:
         return dict(weights=(l1.weight, l1.bias, l2.weight, l2.bias, l3.weight, l3.bias), act=act, head=1, out_act=out_act, w2_swz=swz,
                     rng_ctl=None)
 
+    def _tail(self, x: th.Tensor, first: int) -> th.Tensor:
+        """layers[first:] of an inference pass (no gradients kept)."""
+        for lin, act in self.layers[first:]:
+            x = linear(x, lin.weight, lin.bias, act, False, None, grad_is_dz=False)
+        return x
+
     def tail_below(self, train_params: bool):
         """what a fused consumer of this MLP's output needs to run the last layer's activation / bias gradient itself"""
         return (self.layers[-1][1], None)
 
-    def __call__(self, x: th.Tensor, train_params: bool = True, out_grad_is_dz: bool = False, xbuf: Optional[th.Tensor] = None) -> th.Tensor:
+    def gather_supported(self, x: th.Tensor) -> bool:
+        """`__call__(x, train_params=False, gather=...)` applies: an inference pass through the per-layer kernels whose first layer
+        can read the sampled next observations from the ring itself (hip_ops.linear_act_fwd_gather)."""
+        layers = self.layers
+        with th.no_grad():
+            whole = self._whole_net_ok(x, train_params=False)
+        lin = layers[0][0]
+        return (USE_FUSED_LINEAR and not whole and len(layers) >= 2 and x.dim() == 2 and lin.in_features == x.shape[1]
+                and lin.weight.is_contiguous() and lin.weight.data_ptr() % 16 == 0 and not (len(layers) == 2 and layers[-1][0].out_features == 1))
+
+    def __call__(self, x: th.Tensor, train_params: bool = True, out_grad_is_dz: bool = False, xbuf: Optional[th.Tensor] = None,
+                 gather=None) -> th.Tensor:
         """`out_grad_is_dz`: the consumer is a fused layer built with `below=self.tail_below(...)` (see _input_grad).
         `xbuf` [M, W]: the output is written into its last out_features columns and the BUFFER is returned (a deterministic actor's
-        action straight into the critic input, differentiable)."""
+        action straight into the critic input, differentiable).
+        `gather` = ReplayBuffer.take_predrawn(pb) (inference only, `gather_supported`): x is the not-yet-gathered next-observation
+        block of `pb`; the first layer fetches the sampled rows from the ring and writes `pb` for the launches behind it."""
         layers = self.layers
+        if gather is not None:
+            if th.is_grad_enabled() or train_params or xbuf is not None or not self.gather_supported(x):
+                raise NotImplementedError("FastMLP gather: a no-grad inference pass through the per-layer kernels only")
+            ring, idx, rng_advance, pb = gather
+            lin, act = layers[0]
+            h = hip_ops.linear_act_fwd_gather(ring, idx, x.shape[0], False, lin.weight, lin.bias, act, pb.x_data, pb.x_next, pb.x_pi,
+                                              pb.samples.dones, pb.samples.rewards, advance_ring=True, rng_advance=rng_advance)
+            return FastMLP._tail(self, h, 1)
         if xbuf is not None:
             if not USE_FUSED_LINEAR or not th.is_grad_enabled() or layers[-1][0].out_features == 1 or x.stride(-1) != 1:
                 raise NotImplementedError("FastMLP xbuf: the fused, differentiated, non-scalar-head form only")

@@ -161,9 +161,14 @@ class TD3(OffPolicyAlgorithm):
     def _gradient_step_fused(self, batch_size: int, n_updates: int) -> None:
         """td3.py:161-206 on the fused path (core/common/fused.py)."""
         s, pol = self._loss_sums, self.policy
-        pb = None
+        pb, gather = None, None
         if self._use_packed_batch():
-            pb = self.replay_buffer.sample_packed_into(self._packed_batch(batch_size))  # :161 + the critics' cat([obs, act])
+            pb = self._packed_batch(batch_size)
+            if fused.USE_GATHER_IN_FIRST_LAYER and self._fast_actor_target.gather_supported(pb.samples.next_observations):
+                # indices drawn by the rollout launch: the target actor's first layer below gathers the rows itself
+                gather = self.replay_buffer.take_predrawn(pb)
+            if gather is None:
+                self.replay_buffer.sample_packed_into(pb)  # :161 + the critics' cat([obs, act])
             rd = pb.samples
         else:
             rd = self.replay_buffer.sample_into(self._batch(batch_size))
@@ -175,7 +180,7 @@ class TD3(OffPolicyAlgorithm):
         with th.no_grad():  # :167-176
             if pb is not None:
                 # target smoothing in ONE launch (clone + normal_ + clamp + add + clamp), written into x_next's action columns
-                a_t = self._fast_actor_target(rd.next_observations, train_params=False)
+                a_t = self._fast_actor_target(rd.next_observations, train_params=False, gather=gather)
                 queued = self.noise_queue.pop(0).to(self.device, th.float32).contiguous() if self.noise_queue else None
                 hip_ops.target_smooth(a_t, queued, None if queued is not None else self._device_rng(), self.target_policy_noise,
                                       self.target_noise_clip, pb.x_next[:, pb.obs_dim:])

@@ -217,24 +217,26 @@ def test_first_layer_with_the_gather_inside(ops, d, a, batch, n_out, both, act):
     assert th.equal(ring_a.ctl, ring_b.ctl) and ring_b.ctl.tolist() == [0, 1, 0, rows] and th.equal(ca, cb)
 
 
-def test_sac_learn_with_the_gather_in_the_first_layer(monkeypatch):
-    """SAC under hipGraph replay: gather inside the actor pass's first layer vs the gather launch in front of it: identical weights,
-    sampler stream and ring after 40 iterations."""
+@pytest.mark.parametrize("algo", ["sac", "td3"])
+def test_learn_with_the_gather_in_the_first_layer(algo, monkeypatch):
+    """learn() under hipGraph replay: gather inside the first layer behind the sample (SAC: the 2B-row actor pass; TD3: the target
+    actor) vs the gather launch in front of it: identical weights, sampler stream and ring after 40 iterations."""
     from core.common import fused
     from core.common.vec_env import CSTRVecEnv
     from core.sac import SAC
+    from core.td3 import TD3
 
     def run(flag):
         monkeypatch.setattr(fused, "USE_GATHER_IN_FIRST_LAYER", flag)
         env = CSTRVecEnv(2048, device="cuda")
-        model = SAC("MlpPolicy", env, seed=11, device="cuda", learning_starts=2048 * 2, buffer_size=2048 * 6)
+        model = (SAC if algo == "sac" else TD3)("MlpPolicy", env, seed=11, device="cuda", learning_starts=2048 * 2, buffer_size=2048 * 6)
         model.enable_graph_capture(True)
         model.learn(total_timesteps=2048 * 40)
         th.cuda.synchronize()
         assert model.graph_status()["active"] and model.graph_status()["replays"] > 20
         rb = model.replay_buffer
         flat = th.cat([p.detach().reshape(-1) for p in model.policy.parameters()])
-        return flat.clone(), rb.sampler_stream.clone(), rb.ring.ctl.clone(), rb.rewards.clone(), model._fast_actor.rng_ctl.clone()
+        return flat.clone(), rb.sampler_stream.clone(), rb.ring.ctl.clone(), rb.rewards.clone(), rb.actions.clone()
 
     for i, (x, y) in enumerate(zip(run(True), run(False))):
         assert th.equal(x, y), f"tensor {i} differs"
