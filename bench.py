@@ -496,14 +496,17 @@ def main():
     prewarm = 0
     if use_graph:
         # every graph the timed region can need: `unroll`-iteration graphs (one per policy-delay phase) and, when K is not a multiple
-        # of the unroll factor, the single-iteration ones for the tail -- run both call shapes until a whole call replays
+        # of the unroll factor, the unroll / 2, unroll / 4, ... 1-iteration ones for the tail -- run both call shapes until a whole call replays
         u = model.graph_unroll if world == 1 else 1
+        # (an odd call length flips the policy-delay phase a call starts in: two clean calls in a row cover both)
         for k in ([2 * u] if args.steps % u == 0 else [2 * u, 2 * u + args.steps % u]):
+            clean = 0
             for _ in range(40):
                 before = model.graph_status()["eager_iterations"]
                 run_steps(k)
                 prewarm += k
-                if not model._graph_enabled or model.graph_status()["eager_iterations"] == before:
+                clean = clean + 1 if model.graph_status()["eager_iterations"] == before else 0
+                if not model._graph_enabled or clean >= (2 if k % 2 else 1):
                     break
     st0 = model.graph_status()
     barrier()

@@ -207,7 +207,7 @@ class OffPolicyAlgorithm(BaseAlgorithm):
 
         `unroll` (default 1, env CSTR_GRAPH_UNROLL): consecutive iterations recorded into ONE graph -- the ~10 us the GPU
         idles between two graph launches is paid once per `unroll` iterations. Used on one GPU with a constant learning
-        rate while at least `unroll` iterations remain; otherwise single-iteration graphs are replayed."""
+        rate while at least `unroll` iterations remain; the tail of a run replays graphs of unroll / 2, unroll / 4, ... 1 iterations."""
         self._graph_enabled = enabled
         self._graph, self._graph_error = None, None
         self.graph_unroll = max(1, int(unroll if unroll is not None else os.environ.get("CSTR_GRAPH_UNROLL", "1")))
@@ -280,7 +280,9 @@ class OffPolicyAlgorithm(BaseAlgorithm):
         if u <= 1 or self.world_size > 1 or getattr(self, "_force_segment_boundaries", False) or not isinstance(self.learning_rate, float):
             return 1
         remaining = (self._total_timesteps - self.num_timesteps) // self.n_envs
-        return u if remaining >= u else 1
+        while u > 1 and remaining < u:  # the tail of a run: the largest of u, u / 2, u / 4, ... that still fits
+            u //= 2
+        return max(u, 1)
 
     def _graph_iteration(self, log_interval: Optional[int], callback: Optional[BaseCallback] = None) -> None:
         vn = self._vec_normalize_env

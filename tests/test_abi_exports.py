@@ -108,3 +108,46 @@ def test_round2_entry_points_reject_bad_arguments_on_the_host():
     # the policy launch's flag word: only bit 0 is defined
     net = nv.PolicyMlp(4, 64, 64, 2, 1, 0, 0, 2, 0x1000, 0x1000, 0x1000, 0x1000, 0x1000, 0x1000, None)
     assert lib.cstr_policy_rows_fwd_f32(C.byref(net), fake, i64(4), null, fake, fake, i64(2), null, i64(16), null) == -1
+
+
+def test_rollout_entry_points_reject_bad_arguments_on_the_host():
+    """cstr_rollout_step_f32, cstr_replay_gather_packed_f32, cstr_linear_act_fwd_gather_f32: argument checks fail before anything is
+    dereferenced or launched."""
+    lib = nv.lib()
+    null, fake = C.c_void_p(None), C.c_void_p(0x1000)
+    i64, u64 = C.c_int64, C.c_uint64
+    coef = nv.default_coef()
+    ring = nv.Ring(0x1000, 0x1000, 0x1000, 0x1000, 0x1000, 0x1000, 4, 64, 4, 2)
+    lo, hi = (C.c_float * 2)(-1, -1), (C.c_float * 2)(1, 1)
+    net = nv.PolicyMlp(4, 64, 64, 2, 1, 0, 0, 1, 0x1000, 0x1000, 0x1000, 0x1000, 0x1000, 0x1000, 0x1000)
+
+    def rollout(net_, rng, pcg, mt, batch, idx, ring_=ring, ring_ctl=fake):
+        return lib.cstr_rollout_step_f32(C.byref(net_), fake, i64(4), rng, C.byref(coef), 0, C.byref(ring_), ring_ctl, fake, fake, 1, lo, hi, null,
+                                         null, pcg, null, null, null, null, null, null, mt, i64(batch), idx, null)
+
+    assert rollout(net, fake, null, null, 0, null) == -1            # no reset source
+    assert rollout(net, null, fake, null, 0, null) == -1            # sampling head without its Philox stream
+    assert rollout(net, fake, fake, fake, 256, null) == -1          # index draw without its output buffer
+    assert rollout(net, fake, fake, fake, 0, fake) == -1            # ... without a batch size
+    assert rollout(net, fake, fake, null, 0, null, ring_ctl=null) == -1
+    no_copy = nv.PolicyMlp(4, 64, 64, 2, 1, 0, 0, 1, 0x1000, 0x1000, 0x1000, 0x1000, 0x1000, 0x1000, None)
+    assert rollout(no_copy, fake, fake, null, 0, null) == -2        # needs the tile-major W2 copy
+    wide = nv.PolicyMlp(32, 64, 64, 2, 1, 0, 0, 1, 0x1000, 0x1000, 0x1000, 0x1000, 0x1000, 0x1000, 0x1000)
+    assert lib.cstr_rollout_step_f32(C.byref(wide), fake, i64(32), fake, C.byref(coef), 0, C.byref(ring), fake, fake, fake, 1, lo, hi, null, null,
+                                     fake, null, null, null, null, null, null, null, i64(0), null, null) == -2  # first layer wider than one k chunk
+    four = nv.PolicyMlp(4, 64, 64, 4, 1, 1, 2, 1, 0x1000, 0x1000, 0x1000, 0x1000, 0x1000, 0x1000, 0x1000)
+    assert rollout(four, null, fake, null, 0, null) == -1           # policy's action width != the ring's
+    # gather launch
+    assert lib.cstr_replay_gather_packed_f32(C.byref(ring), fake, 1, null, u64(0), null, i64(8), fake, fake, null, fake, fake, null, null, null) == -1
+    assert lib.cstr_replay_gather_packed_f32(C.byref(ring), null, 1, null, u64(0), fake, i64(8), fake, fake, null, fake, fake, null, null, null) == -1
+    assert lib.cstr_replay_gather_packed_f32(C.byref(ring), fake, 1, null, u64(0), fake, i64(1 << 20), fake, fake, null, fake, fake, null, null, null) == -2
+    odd = nv.Ring(0x1000, 0x1000, 0x1000, 0x1000, 0x1000, 0x1000, 4, 64, 5, 2)
+    assert lib.cstr_replay_gather_packed_f32(C.byref(odd), fake, 1, null, u64(0), fake, i64(8), fake, fake, null, fake, fake, null, null, null) == -2
+    # first layer with the gather inside
+    def gl(idx, w, act, ring_ctl=fake, batch=8, ring_=ring):
+        return lib.cstr_linear_act_fwd_gather_f32(C.byref(ring_), ring_ctl, 1, null, u64(0), idx, i64(batch), 1, w, fake, act, fake, i64(64), fake, fake,
+                                                  null, fake, fake, null)
+
+    assert gl(null, fake, 1) == -1 and gl(fake, null, 1) == -1 and gl(fake, fake, 7) == -1 and gl(fake, fake, 1, ring_ctl=null) == -1
+    assert gl(fake, C.c_void_p(0x1004), 1) == -1                   # weight rows are read as 16-byte vectors
+    assert gl(fake, fake, 1, batch=1 << 20) == -2 and gl(fake, fake, 1, ring_=odd) == -2
