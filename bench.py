@@ -588,7 +588,14 @@ def main():
                                          unit="TFLOP/s", frac=pk["frac"], traffic=traffic, launch_us=pk["launch_us"], shape=pk["shape"])
             rk = line["kernels"].get("rollout_step_kernel")
             if rk is not None:  # the launch the captured iteration runs: the same matrix work + the env step + the index draw
-                line["roofline_mfma"]["as_launched"] = dict(kernel="rollout_step_kernel", achieved=rk["tflops"], frac=rk["frac"], launch_us=rk["launch_us"],
+                rtraffic = None
+                if rk["shape"] == [4096, 4, 256, 256, 4]:
+                    try:
+                        with open(os.path.join(ROOT, "profiles", "r02_rollout_pmc.json")) as fh:
+                            rtraffic = json.load(fh)["traffic_bytes"]
+                    except (OSError, KeyError, ValueError):
+                        pass
+                line["roofline_mfma"]["as_launched"] = dict(kernel="rollout_step_kernel", achieved=rk["tflops"], frac=rk["frac"], launch_us=rk["launch_us"], traffic=rtraffic,
                                                             note="the policy network's FLOPs over the whole one-launch rollout (policy + collect "
                                                                  "step of all envs + replay index draw: it replaces policy_rows_fwd_kernel + "
                                                                  "collect_step_kernel + most of replay_sample_kernel)")

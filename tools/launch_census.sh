@@ -9,7 +9,7 @@ f=$(find $OUT/prof_x -name "*kernel_stats.csv" | head -1)
 python3 - <<PY
 import csv, json
 rows = list(csv.DictReader(open("$f")))
-iters = max(int(r["Calls"]) for r in rows if "collect_step_kernel" in r["Name"])
+iters = max(int(r["Calls"]) for r in rows if "collect_step_kernel" in r["Name"] or "rollout_step_kernel" in r["Name"])
 keep = [r for r in rows if int(r["Calls"]) >= 0.4 * iters]
 print("iterations", iters, "launches per iteration", round(sum(int(r["Calls"]) for r in keep) / iters, 2), "ms_per_step (under rocprof)",
       json.load(open("$OUT/prof_x.json"))["ms_per_step"])
