@@ -252,6 +252,11 @@ typedef struct {
      * starts shadow_begin floats into `param` -- rewritten by the same threads that update those weights, so the policy
      * kernel's copy never lags the parameters. shadow_begin and shadow_k are multiples of 4. */
     float *shadow; int64_t shadow_begin, shadow_n, shadow_k;
+    /* optional (NULL = none), Adam segments only: the soft-update target OF THESE PARAMETERS. The thread that has just computed
+     * param_new[i] also writes own_target[i] = fma(tau, param_new[i], own_target[i] * (1 - tau)) -- a cstr_polyak_f32(param,
+     * own_target, tau) that would otherwise need its own launch BEHIND this one (TD3 / MADDPG: the actor's step followed by the
+     * actor target's soft update, core/td3/td3.py:199-205, core/maddpg/maddpg.py:179-185). Uses the segment's `tau`. */
+    float *own_target;
 } cstr_adam_seg_t;
 int cstr_adam_multi_f32(const cstr_adam_seg_t *segs, int n_segs, cstr_stream_t stream);
 

@@ -48,7 +48,7 @@ class AdamSeg(C.Structure):
     _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
                 ("adam_ctl", C.c_void_p), ("lr", C.c_void_p), ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double),
                 ("grad_scale", C.c_float), ("n", C.c_int64), ("polyak_source", C.c_void_p), ("tau", C.c_double),
-                ("shadow", C.c_void_p), ("shadow_begin", C.c_int64), ("shadow_n", C.c_int64), ("shadow_k", C.c_int64)]
+                ("shadow", C.c_void_p), ("shadow_begin", C.c_int64), ("shadow_n", C.c_int64), ("shadow_k", C.c_int64), ("own_target", C.c_void_p)]
 
 
 class LinearSet(C.Structure):

@@ -202,15 +202,26 @@ class FlatAdam:
             hip_ops.policy_swizzle(self.shadow[4].detach(), self.shadow[0])
         self._shadow_version = self.shadow[4]._version
 
-    def step_with(self, *others: "FlatAdam", polyak=None) -> None:
-        """This optimiser's step, the others' and -- polyak=(source arena, target arena, tau) -- a soft target update of
-        arenas none of them touches, in ONE launch (same arithmetic as the separate calls)."""
-        segs = [self._segment()] + [o._segment() for o in others]
-        if polyak is not None:
-            source, target, tau = polyak
-            if not target.same_layout(source):
+    def step_with(self, *others: "FlatAdam", polyak=None, own_target=None) -> None:
+        """This optimiser's step, the others' and -- polyak=(source arena, target arena, tau), or a list of (source flat, target
+        flat, tau) runs -- soft target updates of parameters none of them touches, in ONE launch (same arithmetic as the separate
+        calls). own_target=(target flat tensor, tau): the soft update of THIS optimiser's parameters' target as well, by the threads
+        that have just computed the new values (cstr_adam_seg_t.own_target)."""
+        seg = self._segment()
+        if own_target is not None:
+            if own_target[0].numel() != self.arena.flat.numel():
                 raise ValueError("Iterables have different lengths")  # zip_strict's error (utils.py:447)
-            segs.append(("polyak", source.flat, target.flat, tau))
+            seg = seg[:10] + (seg[10] if len(seg) > 10 else None, own_target)
+        segs = [seg] + [o._segment() for o in others]
+        if polyak is not None:
+            if isinstance(polyak, tuple):
+                source, target, tau = polyak
+                if not target.same_layout(source):
+                    raise ValueError("Iterables have different lengths")
+                polyak = [(source.flat, target.flat, tau)]
+            for source_flat, target_flat, tau in polyak:
+                if source_flat.numel():
+                    segs.append(("polyak", source_flat, target_flat, tau))
         with th.cuda.device(self.arena.device):
             hip_ops.adam_multi(segs)
 

@@ -304,8 +304,9 @@ def adam(param, grad, exp_avg, exp_avg_sq, adam_ctl, lr_dev, beta1=0.9, beta2=0.
 
 def adam_multi(segments):
     """Several flat-arena updates in one launch; `segments` = iterable of adam()'s positional argument tuples (optionally
-    followed by a shadow = (tile-major copy tensor, begin, n, k): see policy_swizzle), or ("polyak", source, target, tau) for
-    a soft target update (<= 4 segments, mutually independent)."""
+    followed by a shadow = (tile-major copy tensor, begin, n, k) or None: see policy_swizzle, and by own_target = (target tensor,
+    tau): the soft update of THESE parameters' target in the same pass), or ("polyak", source, target, tau) for a soft target
+    update of parameters no segment changes (<= 4 segments, mutually independent)."""
     segs = list(segments)
     arr = (nv.AdamSeg * len(segs))()
     for i, seg in enumerate(segs):
@@ -314,7 +315,7 @@ def adam_multi(segments):
             n = source.numel()
             _chk(source, "source", (n,), th.float32), _chk(target, "target", (n,), th.float32)
             arr[i] = nv.AdamSeg(target.data_ptr(), None, None, None, None, None, 0.0, 0.0, 0.0, 1.0, n, source.data_ptr(), float(tau),
-                                None, 0, 0, 0)
+                                None, 0, 0, 0, None)
             continue
         param, grad, exp_avg, exp_avg_sq, adam_ctl, lr_dev, beta1, beta2, eps, grad_scale = seg[:10]
         shadow = seg[10] if len(seg) > 10 else None
@@ -328,8 +329,12 @@ def adam_multi(segments):
             if _f32c(t, "shadow").numel() != swizzled_numel(rows, cols) or begin % 4 or cols % 4 or begin + rows * cols > n:
                 raise ValueError("shadow: wrong size or position")
             sh = (t.data_ptr(), begin, rows, cols)
+        own, tau = (None, 0.0)
+        if len(seg) > 11 and seg[11] is not None:
+            own, tau = seg[11]
+            _chk(own, "own_target", (n,), th.float32)
         arr[i] = nv.AdamSeg(param.data_ptr(), grad.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(), adam_ctl.data_ptr(),
-                            lr_dev.data_ptr(), beta1, beta2, eps, grad_scale, n, None, 0.0, *sh)
+                            lr_dev.data_ptr(), beta1, beta2, eps, grad_scale, n, None, float(tau), *sh, None if own is None else own.data_ptr())
     check(nv.lib().cstr_adam_multi_f32(arr, C.c_int(len(segs)), stream_ptr()), "cstr_adam_multi_f32")
 
 

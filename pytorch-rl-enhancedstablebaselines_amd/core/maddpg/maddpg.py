@@ -390,12 +390,21 @@ class MADDPG(OffPolicyAlgorithm):
                 hip_ops.neg_mean_loss(qs_pi[0], gq[0], self._loss_now, self._loss_sums[f"actor{i}"])
                 fused.backward_q(qs_pi, gq)
                 self._allreduce_grads(pol.actor_slices[i])
-                A.optimizer_list[i].step()
+                if self.faithful_quirks:
+                    # Q3: polyak of BOTH whole arenas inside the agent loop (:183-185), in the launch of agent i's actor step: the
+                    # critics' and the other agents' actor parameters do not change in it, agent i's target follows its new weights
+                    src, tgt, sl = pol.actor_arena.flat, pol.actor_target_arena.flat, pol.actor_slices[i]
+                    if not (pol.critic_target_arena.same_layout(pol.critic_arena) and pol.actor_target_arena.same_layout(pol.actor_arena)):
+                        raise ValueError("Iterables have different lengths")  # zip_strict's error (utils.py:447)
+                    lo = sl.flat.storage_offset() - src.storage_offset()
+                    hi = lo + sl.numel
+                    A.optimizer_list[i].step_with(polyak=[(pol.critic_arena.flat, pol.critic_target_arena.flat, self.tau),
+                                                          (src[:lo], tgt[:lo], self.tau), (src[hi:], tgt[hi:], self.tau)],
+                                                  own_target=(tgt[lo:hi], self.tau))
+                else:
+                    A.optimizer_list[i].step()
                 if self.debug_capture:
                     actor_loss_now = self._loss_now.clone()
-                if self.faithful_quirks:  # Q3: polyak inside the agent loop
-                    pol.critic_target_arena.polyak_from(pol.critic_arena, self.tau)
-                    pol.actor_target_arena.polyak_from(pol.actor_arena, self.tau)
             if self.debug_capture:
                 captured.append(dict(target_q=self._target_q[i].clone(), current_q=[q.detach().clone() for q in qs],
                                      critic_loss=critic_loss_now, actor_loss=actor_loss_now))

@@ -234,9 +234,12 @@ class TD3(OffPolicyAlgorithm):
             hip_ops.neg_mean_loss(qs_pi[0], gq1, a_out, a_sum)
             fused.backward_q(qs_pi, gq)
             self._allreduce_grads(pol.actor_arena)
-            # the actor's step and the critics' soft update touch disjoint arenas: one launch (:199 and :204)
-            self.actor.optimizer.step_with(polyak=(pol.critic_arena, pol.critic_target_arena, self.tau))
-            pol.actor_target_arena.polyak_from(pol.actor_arena, self.tau)
+            # the actor's step, the critics' soft update (disjoint arenas) and the actor target's soft update (by the threads that
+            # have just computed the new actor weights) in ONE launch (:199, :204, :205)
+            if not pol.actor_target_arena.same_layout(pol.actor_arena):
+                raise ValueError("Iterables have different lengths")  # zip_strict's error (utils.py:447)
+            self.actor.optimizer.step_with(polyak=(pol.critic_arena, pol.critic_target_arena, self.tau),
+                                           own_target=(pol.actor_target_arena.flat, self.tau))
             actor_done = True
         if self.debug_capture:
             self.last_train_tensors = dict(target_q=self._target_q.clone(), current_q=[q.detach().clone() for q in qs],

@@ -64,7 +64,8 @@ struct AdamShadow { float4 *out; int64_t begin4, end4; int k, kc; };
 __device__ __forceinline__ void adam_body(float *__restrict__ param, const float *__restrict__ grad, float *__restrict__ exp_avg,
                                           float *__restrict__ exp_avg_sq, int64_t *__restrict__ adam_ctl,
                                           const double *__restrict__ lr, const double beta1, const double beta2, const double eps,
-                                          const float gscale, const int64_t n, const AdamShadow sh = AdamShadow{nullptr, 0, 0, 4, 1})
+                                          const float gscale, const int64_t n, const AdamShadow sh = AdamShadow{nullptr, 0, 0, 4, 1},
+                                          float *__restrict__ own_target = nullptr, const float tau = 0.0f, const float om = 1.0f)
 {
     __shared__ AdamScalars sa;
     if (threadIdx.x == 0) {
@@ -90,7 +91,7 @@ __device__ __forceinline__ void adam_body(float *__restrict__ param, const float
     // (non-temporal loads as well as stores: every byte is touched once) and keep two 16-byte quads per stream in flight per lane
     const bool stream_out = n >= (int64_t)(16 << 20);
     typedef float v4f __attribute__((ext_vector_type(4)));
-    if (stream_out && !sh.out) {
+    if (stream_out && !sh.out && !own_target) {
         int64_t i = tid;
         for (; i + stride < nv; i += 2 * stride) {
             const int64_t j = i + stride;
@@ -125,6 +126,12 @@ __device__ __forceinline__ void adam_body(float *__restrict__ param, const float
         adam1(p.x, g.x, m.x, v.x, a); adam1(p.y, g.y, m.y, v.y, a);
         adam1(p.z, g.z, m.z, v.z, a); adam1(p.w, g.w, m.w, v.w, a);
         p4[i] = p; m4[i] = m; v4[i] = v;
+        if (own_target) {  // the soft update of these parameters' target with the value just computed (cstr_polyak_f32's arithmetic)
+            float4 t = reinterpret_cast<float4 *>(own_target)[i];
+            t.x = polyak1(p.x, t.x, tau, om); t.y = polyak1(p.y, t.y, tau, om);
+            t.z = polyak1(p.z, t.z, tau, om); t.w = polyak1(p.w, t.w, tau, om);
+            reinterpret_cast<float4 *>(own_target)[i] = t;
+        }
         if (sh.out && i >= sh.begin4 && i < sh.end4) {  // this float4 is one lane's operand quad of the matrix
             const int64_t e = (i - sh.begin4) * 4;
             const int row = (int)(e / sh.k), col = (int)(e - (int64_t)row * sh.k);
@@ -135,6 +142,7 @@ __device__ __forceinline__ void adam_body(float *__restrict__ param, const float
         float p = param[i], m = exp_avg[i], v = exp_avg_sq[i];
         adam1(p, grad[i], m, v, a);
         param[i] = p; exp_avg[i] = m; exp_avg_sq[i] = v;
+        if (own_target) own_target[i] = polyak1(p, own_target[i], tau, om);
     }
     if (last_block_ticket(reinterpret_cast<unsigned long long *>(adam_ctl + 1)) && threadIdx.x == 0) {
         double *pw = reinterpret_cast<double *>(adam_ctl + 2);
@@ -183,7 +191,8 @@ __global__ void adam_multi_kernel(const AdamSegs segs)
     if (s.shadow)
         sh = AdamShadow{reinterpret_cast<float4 *>(s.shadow), s.shadow_begin >> 2, (s.shadow_begin + s.shadow_n * s.shadow_k) >> 2,
                         (int)s.shadow_k, (int)((s.shadow_k + 15) >> 4)};
-    adam_body(s.param, s.grad, s.exp_avg, s.exp_avg_sq, s.adam_ctl, s.lr, s.beta1, s.beta2, s.eps, s.grad_scale, s.n, sh);
+    adam_body(s.param, s.grad, s.exp_avg, s.exp_avg_sq, s.adam_ctl, s.lr, s.beta1, s.beta2, s.eps, s.grad_scale, s.n, sh, s.own_target,
+              (float)s.tau, (float)(1.0 - s.tau));
 }
 
 }  // namespace
@@ -233,6 +242,7 @@ extern "C" int cstr_adam_multi_f32(const cstr_adam_seg_t *segs, int n_segs, cstr
         } else {
             if (!s.param || !s.grad || !s.exp_avg || !s.exp_avg_sq || !s.adam_ctl || !s.lr || s.n <= 0) return CSTR_E_BADARG;
             if (!aligned16(s.param) || !aligned16(s.grad) || !aligned16(s.exp_avg) || !aligned16(s.exp_avg_sq)) return CSTR_E_BADARG;
+            if (s.own_target && (!aligned16(s.own_target) || s.own_target == s.param)) return CSTR_E_BADARG;
             if (s.shadow && (!aligned16(s.shadow) || s.shadow_begin < 0 || (s.shadow_begin & 3) || s.shadow_n <= 0 || s.shadow_k <= 0 ||
                              (s.shadow_k & 3) || s.shadow_k > 0x7fffffff || s.shadow_begin + s.shadow_n * s.shadow_k > s.n))
                 return CSTR_E_BADARG;

@@ -641,6 +641,32 @@ def test_multi_update_launch_equals_separate_calls(ops):
     assert int(ca2[0]) == 3 and int(cb2[0]) == 3
 
 
+def test_adam_segment_with_its_own_soft_target_update(ops):
+    """cstr_adam_seg_t.own_target: the Adam step and the soft update of the SAME parameters' target in one launch equal
+    cstr_adam_f32 followed by cstr_polyak_f32 bit for bit (odd tail included), next to a plain polyak segment."""
+    g = th.Generator(device="cuda").manual_seed(21)
+    n = 135744 + 3
+    mk = lambda: [th.randn(n, device="cuda", generator=th.Generator(device="cuda").manual_seed(k)) for k in (1, 2)] + \
+        [th.zeros(n, device="cuda"), th.zeros(n, device="cuda")]  # noqa: E731
+    a1, a2 = mk(), mk()
+    t1 = th.randn(n, device="cuda", generator=g)
+    t2 = t1.clone()
+    s1 = th.randn(5000, device="cuda", generator=g)
+    u1 = th.randn(5000, device="cuda", generator=g)
+    s2, u2 = s1.clone(), u1.clone()
+    c1, c2 = ops.new_adam_ctl("cuda"), ops.new_adam_ctl("cuda")
+    lr = th.tensor([1e-3], dtype=th.float64, device="cuda")
+    for _ in range(3):
+        ops.adam(a1[0], a1[1], a1[2], a1[3], c1, lr, 0.9, 0.999, 1e-8, 1.0)
+        ops.polyak(a1[0], t1, 0.005)
+        ops.polyak(s1, u1, 0.005)
+        ops.adam_multi([(a2[0], a2[1], a2[2], a2[3], c2, lr, 0.9, 0.999, 1e-8, 1.0, None, (t2, 0.005)), ("polyak", s2, u2, 0.005)])
+    for x, y in zip(a1 + [t1, u1, c1], a2 + [t2, u2, c2]):
+        assert th.equal(x, y)
+    with pytest.raises(Exception):  # a target that IS the parameter buffer
+        ops.adam_multi([(a2[0], a2[1], a2[2], a2[3], c2, lr, 0.9, 0.999, 1e-8, 1.0, None, (a2[0], 0.005))])
+
+
 def test_adam_streaming_regime_equals_cached_regime(ops):
     """Arenas of >= 2^24 parameters take the streaming form of the Adam kernel (non-temporal loads and stores, two quads per
     stream in flight): the same arithmetic, so the result equals the cached form's bit for bit -- checked by running the same data
