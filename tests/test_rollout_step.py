@@ -28,7 +28,7 @@ def _obs8(o4):
 class _World:
     """Everything one rollout + sample touches, so that two code paths can run on identical copies."""
 
-    def __init__(self, ops, n, d, rows, batch, h1, h2, head, seed, max_steps):
+    def __init__(self, ops, n, d, rows, batch, h1, h2, head, seed, max_steps, static=False):
         from core import _native as nv
 
         g = th.Generator(device="cuda").manual_seed(seed)
@@ -46,6 +46,8 @@ class _World:
         self.rng_ctl = ops.new_rng_ctl(123, "cuda") if head == 0 else None
         self.pcg = th.randint(1, 2 ** 62, (n, 4), device="cuda", generator=g, dtype=th.int64)
         self.pcg[:, 3] |= 1  # odd increment, like a seeded PCG64
+        # init_mode="static": the per-env drifting f64 init_state the reset draw perturbs in place (twoseriescstr.py:246-255)
+        self.static_init = th.tensor([0.45, 310.0, 0.25, 290.0], dtype=th.float64, device="cuda").repeat(n, 1).contiguous() if static else None
         self.mt = th.zeros(628, dtype=th.int32, device="cuda")
         ops.mt19937_seed(self.mt, 4242 + seed)
         self.rew, self.done = th.zeros(n, device="cuda"), th.zeros(n, device="cuda")
@@ -63,7 +65,7 @@ class _World:
         ops.policy_rows_fwd(self.env_obs, *self.w, 1, self.head, 2 if self.head else 0, pol, rng_ctl=self.rng_ctl, w2_swz=self.swz,
                             defer_rng_advance=True)
         ops.collect_step(self.coef, "euler" if self.d == 4 else "rk4", self.ring, self.env_obs, self.step_count, pol, 1, self.low, self.high,
-                         noise=noise, pcg_state=self.pcg, reward_out=self.rew, done_out=self.done, ep_return=self.ep_return,
+                         noise=noise, pcg_state=self.pcg, static_init=self.static_init, reward_out=self.rew, done_out=self.done, ep_return=self.ep_return,
                          ep_stats=self.ep_stats, rng_advance=None if self.rng_ctl is None else (self.rng_ctl, n))
         ops.replay_sample_packed(self.ring, self.mt, self.batch, self.x_data, self.x_next, self.x_pi, self.s_done, self.s_rew, self.bi, self.ei)
 
@@ -71,8 +73,8 @@ class _World:
         ops, n = self.ops, self.n
         ops.rollout_step(self.env_obs, *self.w, 1, self.head, 2 if self.head else 0, self.swz, self.rng_ctl, self.coef,
                          "euler" if self.d == 4 else "rk4", self.ring, self.env_obs, self.step_count, 1, self.low, self.high, noise=noise,
-                         pcg_state=self.pcg, reward_out=self.rew, done_out=self.done, ep_return=self.ep_return, ep_stats=self.ep_stats,
-                         mt_state=self.mt, sample_idx=self.idx)
+                         pcg_state=self.pcg, static_init=self.static_init, reward_out=self.rew, done_out=self.done, ep_return=self.ep_return,
+                         ep_stats=self.ep_stats, mt_state=self.mt, sample_idx=self.idx)
         ops.replay_gather_packed(self.ring, self.idx, self.batch, self.x_data, self.x_next, self.x_pi, self.s_done, self.s_rew, self.bi, self.ei,
                                  advance_ring=True, rng_advance=None if self.rng_ctl is None else (self.rng_ctl, n))
 
@@ -84,19 +86,23 @@ class _World:
                    ring_done=r.dones, ring_timeout=r.timeouts, ring_ctl=r.ctl)
         if self.rng_ctl is not None:
             out["rng_ctl"] = self.rng_ctl
+        if self.static_init is not None:
+            out["static_init"] = self.static_init
         return {k: v.clone() for k, v in out.items()}
 
 
-@pytest.mark.parametrize("n,d,rows,batch,h1,h2,head", [
-    (4096, 4, 5, 256, 256, 256, 0),   # the bench shape (SAC): register-resident B operand
-    (1000, 4, 3, 100, 400, 300, 1),   # TD3's class-default widths (pipelined form), ragged last workgroup, deterministic head
-    (2048, 8, 4, 64, 64, 64, 0),      # obs 8 / RK4 (north_star variant)
-    (1040, 4, 7, 300, 256, 256, 1),
+@pytest.mark.parametrize("n,d,rows,batch,h1,h2,head,static", [
+    (4096, 4, 5, 256, 256, 256, 0, False),   # the bench shape (SAC): register-resident B operand
+    (1000, 4, 3, 100, 400, 300, 1, False),   # TD3's class-default widths (pipelined form), ragged last workgroup, deterministic head
+    (2048, 8, 4, 64, 64, 64, 0, False),      # obs 8 / RK4 (north_star variant)
+    (1040, 4, 7, 300, 256, 256, 1, False),
+    (528, 4, 4, 32, 64, 64, 0, True),        # init_mode="static": resets walk the per-env f64 init_state
+    (520, 8, 4, 32, 64, 64, 1, True),
 ])
-def test_rollout_step_equals_the_three_launches(ops, n, d, rows, batch, h1, h2, head):
+def test_rollout_step_equals_the_three_launches(ops, n, d, rows, batch, h1, h2, head, static):
     """13 vec-steps (ring wraps, episodes end and reset from the PCG64 streams, the MT19937 block is twisted most steps): every
     tensor either path touches is bit-identical after each step; the f64 episode-return sum (float atomics) to 1e-12."""
-    a, b = (_World(ops, n, d, rows, batch, h1, h2, head, seed=n + h1, max_steps=9) for _ in range(2))
+    a, b = (_World(ops, n, d, rows, batch, h1, h2, head, seed=n + h1, max_steps=9, static=static) for _ in range(2))
     g = th.Generator(device="cuda").manual_seed(1)
     ends = 0
     for k in range(13):
