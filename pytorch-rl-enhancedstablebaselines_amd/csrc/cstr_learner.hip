@@ -68,6 +68,19 @@ __device__ __forceinline__ void adam_body(float *__restrict__ param, const float
                                           float *__restrict__ own_target = nullptr, const float tau = 0.0f, const float om = 1.0f)
 {
     __shared__ AdamScalars sa;
+    const int64_t nv = n >> 2;
+    const int64_t tid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x, stride = (int64_t)gridDim.x * blockDim.x;
+    float4 *p4 = reinterpret_cast<float4 *>(param), *m4 = reinterpret_cast<float4 *>(exp_avg), *v4 = reinterpret_cast<float4 *>(exp_avg_sq);
+    const float4 *g4 = reinterpret_cast<const float4 *>(grad);
+    // arenas far beyond the caches (a microbenchmark regime, not the learners'): stream the state past L2 in BOTH directions
+    // (non-temporal loads as well as stores: every byte is touched once) and keep two 16-byte quads per stream in flight per lane
+    const bool stream_out = n >= (int64_t)(16 << 20) && !sh.out && !own_target;
+    // The learners' regime is launch latency: every lane's FIRST quad of the four streams is requested before thread 0 turns the
+    // control words into the step's scalars (a dependent load of adam_ctl / lr, an f64 division and square root, a barrier) --
+    // the two latencies overlap instead of adding up.
+    const bool first = !stream_out && tid < nv;
+    float4 fp = make_float4(0.0f, 0.0f, 0.0f, 0.0f), fm = fp, fv = fp, fg = fp;
+    if (first) { fp = p4[tid]; fm = m4[tid]; fv = v4[tid]; fg = g4[tid]; }
     if (threadIdx.x == 0) {
         // state["step"] += 1; beta^step is carried in adam_ctl as a running product (two f64 multiplies instead of two
         // f64 pow() calls in every workgroup's prologue: 5.4 -> ~2 us per launch at 136 k parameters)
@@ -83,15 +96,24 @@ __device__ __forceinline__ void adam_body(float *__restrict__ param, const float
     }
     __syncthreads();
     const AdamScalars a = sa;
-    const int64_t nv = n >> 2;
-    const int64_t tid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x, stride = (int64_t)gridDim.x * blockDim.x;
-    float4 *p4 = reinterpret_cast<float4 *>(param), *m4 = reinterpret_cast<float4 *>(exp_avg), *v4 = reinterpret_cast<float4 *>(exp_avg_sq);
-    const float4 *g4 = reinterpret_cast<const float4 *>(grad);
-    // arenas far beyond the caches (a microbenchmark regime, not the learners'): stream the state past L2 in BOTH directions
-    // (non-temporal loads as well as stores: every byte is touched once) and keep two 16-byte quads per stream in flight per lane
-    const bool stream_out = n >= (int64_t)(16 << 20);
     typedef float v4f __attribute__((ext_vector_type(4)));
-    if (stream_out && !sh.out && !own_target) {
+    auto update = [&](const int64_t i, float4 p, float4 m, float4 v, const float4 g) {
+        adam1(p.x, g.x, m.x, v.x, a); adam1(p.y, g.y, m.y, v.y, a);
+        adam1(p.z, g.z, m.z, v.z, a); adam1(p.w, g.w, m.w, v.w, a);
+        p4[i] = p; m4[i] = m; v4[i] = v;
+        if (own_target) {  // the soft update of these parameters' target with the value just computed (cstr_polyak_f32's arithmetic)
+            float4 t = reinterpret_cast<float4 *>(own_target)[i];
+            t.x = polyak1(p.x, t.x, tau, om); t.y = polyak1(p.y, t.y, tau, om);
+            t.z = polyak1(p.z, t.z, tau, om); t.w = polyak1(p.w, t.w, tau, om);
+            reinterpret_cast<float4 *>(own_target)[i] = t;
+        }
+        if (sh.out && i >= sh.begin4 && i < sh.end4) {  // this float4 is one lane's operand quad of the matrix
+            const int64_t e = (i - sh.begin4) * 4;
+            const int row = (int)(e / sh.k), col = (int)(e - (int64_t)row * sh.k);
+            sh.out[((int64_t)(row >> 4) * sh.kc + (col >> 4)) * 64 + (row & 15) + 16 * ((col & 15) >> 2)] = p;
+        }
+    };
+    if (stream_out) {
         int64_t i = tid;
         for (; i + stride < nv; i += 2 * stride) {
             const int64_t j = i + stride;
@@ -119,24 +141,9 @@ __device__ __forceinline__ void adam_body(float *__restrict__ param, const float
             adam1(p.z, g.z, m.z, v.z, a); adam1(p.w, g.w, m.w, v.w, a);
             p4[i] = p; m4[i] = m; v4[i] = v;
         }
-    } else
-    for (int64_t i = tid; i < nv; i += stride) {
-        float4 p = p4[i], m = m4[i], v = v4[i];
-        const float4 g = g4[i];
-        adam1(p.x, g.x, m.x, v.x, a); adam1(p.y, g.y, m.y, v.y, a);
-        adam1(p.z, g.z, m.z, v.z, a); adam1(p.w, g.w, m.w, v.w, a);
-        p4[i] = p; m4[i] = m; v4[i] = v;
-        if (own_target) {  // the soft update of these parameters' target with the value just computed (cstr_polyak_f32's arithmetic)
-            float4 t = reinterpret_cast<float4 *>(own_target)[i];
-            t.x = polyak1(p.x, t.x, tau, om); t.y = polyak1(p.y, t.y, tau, om);
-            t.z = polyak1(p.z, t.z, tau, om); t.w = polyak1(p.w, t.w, tau, om);
-            reinterpret_cast<float4 *>(own_target)[i] = t;
-        }
-        if (sh.out && i >= sh.begin4 && i < sh.end4) {  // this float4 is one lane's operand quad of the matrix
-            const int64_t e = (i - sh.begin4) * 4;
-            const int row = (int)(e / sh.k), col = (int)(e - (int64_t)row * sh.k);
-            sh.out[((int64_t)(row >> 4) * sh.kc + (col >> 4)) * 64 + (row & 15) + 16 * ((col & 15) >> 2)] = p;
-        }
+    } else {
+        if (first) update(tid, fp, fm, fv, fg);
+        for (int64_t i = tid + stride; i < nv; i += stride) update(i, p4[i], m4[i], v4[i], g4[i]);
     }
     for (int64_t i = (nv << 2) + tid; i < n; i += stride) {
         float p = param[i], m = exp_avg[i], v = exp_avg_sq[i];

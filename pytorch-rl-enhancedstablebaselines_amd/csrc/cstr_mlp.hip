@@ -1276,7 +1276,6 @@ __device__ __forceinline__ void policy_rows_v2_body(const PolicyArgs &a, const R
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, h = lane >> 4;
     const int64_t m0 = (int64_t)blockIdx.x * POLICY_ROWS;
     const bool draw = HEAD == 0 && a.rng_ctl != nullptr;
-    const uint64_t seed = a.rng_ctl ? a.rng_ctl[0] : 0ull, base = a.rng_ctl ? a.rng_ctl[1] : 0ull;
     const int n_out = HEAD == 0 ? 2 * a.act_dim : a.act_dim;
     const float4 *w2s = reinterpret_cast<const float4 *>(a.w2s);
     const bool l1_wave = wave < L1_WAVES;
@@ -1288,7 +1287,7 @@ __device__ __forceinline__ void policy_rows_v2_body(const PolicyArgs &a, const R
     const bool env_lane = FUSE && K0_SMALL && tid < POLICY_ROWS * 8 && (tid & 7) == 0 && m0 + (tid >> 3) < a.m;
     CollectIn env_in;   // layout 2 (two trains): a lane per env
     CollectInQ env_q;   // layouts 0, 1: four lanes per env (collect_env_quad)
-    const int64_t ring_pos = FUSE ? ro->ring_ctl[0] : 0;
+    int64_t ring_pos = 0;
     V2_STAMP(0);
 
     // Roles before the first barrier. The CU's vector-memory path is ONE in-order queue that moves ~75 GB/s: layer 2's weights
@@ -1327,6 +1326,9 @@ __device__ __forceinline__ void policy_rows_v2_body(const PolicyArgs &a, const R
     // its operands and using them, the draw delayed the first barrier by as much as it saved.
     const bool noise_wave = draw && wave == WAVES - 1;
     auto draw_noise = [&]() {
+        // the stream's control words are read HERE, by the one wave that needs them: a dependent scalar load at the top of the
+        // kernel sits in front of every wave's first vector loads (the scalar-memory wait in front of them covers it too)
+        const uint64_t seed = a.rng_ctl[0], base = a.rng_ctl[1];
         const int64_t row = m0 + lane;
         if (lane < POLICY_ROWS && row < a.m) {
             for (int j0 = 0; j0 < a.act_dim; j0 += 2) {
@@ -1362,6 +1364,7 @@ __device__ __forceinline__ void policy_rows_v2_body(const PolicyArgs &a, const R
         }
         if (FUSE && wave < (POLICY_ROWS * 8) / 64) {  // the collect step's operands of this lane's env: requested now, used by the sampling tail
             const int64_t e = min(m0 + (tid >> 3), a.m - 1);
+            ring_pos = ro->ring_ctl[0];  // (behind layer 1's operand requests: see draw_noise)
             if (ro->layout == 0) collect_quad_load<0>(ro->c, e, tid & 7, env_q);
             else if (ro->layout == 1) collect_quad_load<1>(ro->c, e, tid & 7, env_q);
             else if (env_lane) collect_env_load<2>(ro->c, e, env_in);
@@ -1625,7 +1628,7 @@ __device__ __forceinline__ void policy_rows_v2_body(const PolicyArgs &a, const R
     if (__builtin_isnan(warm) && a.m < 0) a.action[0] = warm;  // never true; keeps the warm-up load alive
     if (!FUSE && a.rng_ctl && !(a.flags & 1) && last_block_ticket_tree(reinterpret_cast<unsigned long long *>(a.rng_ctl + 2),
                                                                        reinterpret_cast<unsigned long long *>(a.rng_ctl + 4)) && tid == 0)
-        a.rng_ctl[1] = base + (uint64_t)a.m;
+        a.rng_ctl[1] += (uint64_t)a.m;
 }
 
 template <int ACT, int HEAD, bool VEC0, bool K0_SMALL, bool SMALL>
