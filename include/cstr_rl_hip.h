@@ -291,7 +291,7 @@ int cstr_linear_act_fwd_f32(const float *x, int64_t x_group_stride, int64_t ldx,
  * IDDPG: core/maddpg/policies.py builds one MLP per agent; the reference evaluates them one after the other). Each set:
  * y[m][n] = act(x[m] . w[n] + bias[n]) with x rows ldx apart and y rows ldy apart (y may be the agent's column block of the
  * joint action). */
-#define CSTR_MAX_LINEAR_SETS 8
+#define CSTR_MAX_LINEAR_SETS 16
 typedef struct { const float *x; int64_t ldx; const float *w; const float *bias; float *y; int64_t ldy; } cstr_linear_set_t;
 int cstr_linear_act_fwd_sets_f32(const cstr_linear_set_t *sets, int n_sets, int act, int64_t m, int64_t n, int64_t k,
                                  cstr_stream_t stream);

@@ -15,7 +15,7 @@ INTEGRATORS = {"euler": 0, "rk4": 1}
 RING_CTL_WORDS, ADAM_CTL_WORDS, MT_STATE_WORDS, PCG_STATE_WORDS, MAX_SAMPLE_BATCH = 4, 4, 628, 4, 16384
 MAX_NOISE_PERIOD = 8
 VECNORM_STATE_WORDS = 20
-RNG_CTL_WORDS, MAX_HEAD_ACT, MAX_LINEAR_SETS = 16, 4, 8
+RNG_CTL_WORDS, MAX_HEAD_ACT, MAX_LINEAR_SETS, MAX_ADAM_SEGS = 16, 4, 16, 4
 
 SYMBOLS = (
     "cstr_abi_version", "cstr_error_string", "cstr_default_coef", "cstr_vec_step_f32", "cstr_reset_draw_f32",

@@ -893,16 +893,29 @@ class _TwinPairFn(th.autograd.Function):
     chain's usual launches. Networks = Linear-act-Linear-act-Linear(., 1), twin."""
 
     @staticmethod
-    def forward(ctx, x_data, x_next, cs, ts, grads, act: int, *owners):
+    def chain_sets(x_data, x_next, cs, ts):
+        """The chain's buffers and, per layer, its four pointer-table sets (critic nets on x_data, target nets on x_next)."""
         (w1, b1), (w2, b2), (w3, b3) = cs
         (tw1, tb1), (tw2, tb2), (tw3, tb3) = ts
         m, n1, n2 = x_data.shape[0], w1.shape[1], w2.shape[1]
         e = lambda *sh: th.empty(*sh, dtype=x_data.dtype, device=x_data.device)  # noqa: E731
         h1, y2, q = e(4, m, n1), e(4, m, n2), e(4, m, 1)
         xs = (x_data, x_data, x_next, x_next)
-        hip_ops.linear_act_fwd_sets([(xs[g], (w1, tw1)[g >> 1][g & 1], (b1, tb1)[g >> 1][g & 1], h1[g]) for g in range(4)], act)
-        hip_ops.linear_act_fwd_sets([(h1[g], (w2, tw2)[g >> 1][g & 1], (b2, tb2)[g >> 1][g & 1], y2[g]) for g in range(4)], act)
-        hip_ops.linear_act_fwd_sets([(y2[g], (w3, tw3)[g >> 1][g & 1], (b3, tb3)[g >> 1][g & 1], q[g]) for g in range(4)], ACT_NONE)
+        layers = ([(xs[g], (w1, tw1)[g >> 1][g & 1], (b1, tb1)[g >> 1][g & 1], h1[g]) for g in range(4)],
+                  [(h1[g], (w2, tw2)[g >> 1][g & 1], (b2, tb2)[g >> 1][g & 1], y2[g]) for g in range(4)],
+                  [(y2[g], (w3, tw3)[g >> 1][g & 1], (b3, tb3)[g >> 1][g & 1], q[g]) for g in range(4)])
+        return (h1, y2, q), layers
+
+    @staticmethod
+    def forward(ctx, x_data, x_next, cs, ts, grads, act: int, pre, *owners):
+        """`pre` = (h1, y2, q) already computed by `twin_pair_forward_many` (several chains per launch), or None."""
+        w2, w3 = cs[1][0], cs[2][0]
+        if pre is None:
+            (h1, y2, q), layers = _TwinPairFn.chain_sets(x_data, x_next, cs, ts)
+            for li, sets in enumerate(layers):
+                hip_ops.linear_act_fwd_sets(sets, act if li < 2 else ACT_NONE)
+        else:
+            h1, y2, q = pre
         ctx.act, ctx.grads, ctx.n_owners = act, grads, len(owners)
         ctx.save_for_backward(x_data, h1[:2], w2, y2[:2], w3)
         ctx.set_materialize_grads(False)  # no zero-fill launch for the (undefined) gradient of the target's output
@@ -919,7 +932,7 @@ class _TwinPairFn(th.autograd.Function):
         _weight_grad(dz2, h1, gw2, None)  # gb2 came out of the head kernel
         dz1 = hip_ops.linear_bwd_input(dz2, w2, h1, ctx.act)
         _weight_grad(dz1, x, gw1, gb1)
-        return (None,) * (6 + ctx.n_owners)
+        return (None,) * (7 + ctx.n_owners)
 
 
 class QOut(tuple):
@@ -997,10 +1010,36 @@ def twin_pair_forward(critic: "FastTwinCritic", target: "FastTwinCritic", x_data
     ts = [(w.detach(), b.detach()) for w, _, b, _ in target.stack]
     grads = [(wg, bg) for _, wg, _, bg in critic.stack]
     owners = [p for layer in critic.owners for p in layer]
-    q_c, q_t = _TwinPairFn.apply(x_data, x_next.detach(), cs, ts, grads, critic.acts[0], *owners)
+    q_c, q_t = _TwinPairFn.apply(x_data, x_next.detach(), cs, ts, grads, critic.acts[0], None, *owners)
     out = QOut(q_c[i] for i in range(2))
     out.stacked = q_c
     return out, (q_t[0], q_t[1])
+
+
+def twin_pair_forward_many(critics, targets, x_data: th.Tensor, x_next: th.Tensor) -> list:
+    """`twin_pair_forward` for SEVERAL (critic, target) pairs that read the same inputs and do not depend on each other (MADDPG's
+    per-agent centralised critics on a step without a policy update, core/maddpg/maddpg.py:146-164): every layer of all pairs in
+    ceil(4 pairs / MAX_LINEAR_SETS) pointer-table launches instead of one per pair. Returns [(QOut, (q1_target, q2_target))]."""
+    x_next = x_next.detach()
+    chains = []
+    for critic, target in zip(critics, targets):
+        cs = [(w, b) for w, _, b, _ in critic.stack]
+        ts = [(w.detach(), b.detach()) for w, _, b, _ in target.stack]
+        chains.append((cs, ts) + _TwinPairFn.chain_sets(x_data, x_next, cs, ts))
+    cap = hip_ops.nv.MAX_LINEAR_SETS
+    for li in range(3):
+        sets = [st for _, _, _, layers in chains for st in layers[li]]
+        for i in range(0, len(sets), cap):
+            hip_ops.linear_act_fwd_sets(sets[i:i + cap], critics[0].acts[0] if li < 2 else ACT_NONE)
+    outs = []
+    for (cs, ts, pre, _), critic in zip(chains, critics):
+        grads = [(wg, bg) for _, wg, _, bg in critic.stack]
+        owners = [p for layer in critic.owners for p in layer]
+        q_c, q_t = _TwinPairFn.apply(x_data, x_next, cs, ts, grads, critic.acts[0], pre, *owners)
+        out = QOut(q_c[i] for i in range(2))
+        out.stacked = q_c
+        outs.append((out, (q_t[0], q_t[1])))
+    return outs
 
 
 def twin_groups(q_networks) -> list:

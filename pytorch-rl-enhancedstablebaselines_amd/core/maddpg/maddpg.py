@@ -13,6 +13,7 @@ core/common/base_class.py:931-934) -- and the reference's train() arithmetic (:1
 Each quirk is reproduced (the golden vectors come from the unmodified reference) and can be switched off with
 `faithful_quirks=False`, which gives the textbook behaviour.
 """
+import os
 from typing import List, Optional, Union
 
 import torch as th
@@ -26,6 +27,11 @@ from core.common.spaces import split_spaces
 from core.common.utils import get_schedule_fn, update_learning_rate
 from core.common.vec_env import CSTRVecEnv
 from core.maddpg.policies import MlpPolicy
+
+
+# steps without a policy update: the agents' independent critic steps share launches (fused.twin_pair_forward_many, one deferred
+# weight-gradient pass, one Adam launch); "0" = one agent after the other (A/B knob, bit-identical: tests/test_learner_parity.py)
+BATCH_AGENT_CRITIC_STEPS = os.environ.get("CSTR_MADDPG_BATCH_AGENTS", "1") != "0"
 
 
 class MADDPG(OffPolicyAlgorithm):
@@ -337,6 +343,25 @@ class MADDPG(OffPolicyAlgorithm):
                 shared_next = None if C.local else self.critic_target._input(0, rd.next_observations, next_actions)
         if pb is None:
             shared_cur = None if C.local else C._input(0, rd.observations, rd.actions)
+        if (BATCH_AGENT_CRITIC_STEPS and n_updates % self.policy_delay != 0 and shared_next is not None and not self.debug_capture and B <= fused.LOSS_ROOT_MAX_ROWS
+                and self.n_agents <= hip_ops.nv.MAX_ADAM_SEGS
+                and all(fused.twin_pair_supported(c, t) and fused.loss_root_supported(c) for c, t in zip(self._fast_critics, self._fast_critic_targets))
+                and len({c.acts[0] for c in self._fast_critics}) == 1):
+            # A step WITHOUT a policy update: the agents' critic steps (:146-164) do not depend on each other (no soft update in
+            # between), so their forward chains share pointer-table launches, their weight gradients one deferred launch pass and
+            # their Adam steps one launch. (With a policy update, quirk Q3's soft updates inside the agent loop order the agents.)
+            outs = fused.twin_pair_forward_many(self._fast_critics, self._fast_critic_targets, shared_cur, shared_next)
+            with fused.deferred_weight_grads():
+                for i, (qs, qs_t) in enumerate(outs):
+                    td_root = dict(mode="td", q1_t=qs_t[0], q2_t=qs_t[1], next_logp=None, rew=rd.rewards, done=rd.dones, ent_coef=None,
+                                   gamma=self.gamma, scale=1.0, q1=qs[0].detach(), q2=qs[1].detach(), target_out=self._target_q[i],
+                                   loss_out=self._loss_now, loss_sum=self._loss_sums[f"critic{i}"], alpha=None)
+                    with fused.loss_root(td_root):
+                        fused.backward_q(qs, gq)
+            for i in range(self.n_agents):
+                self._allreduce_grads(pol.critic_slices[i])
+            C.optimizer_list[0].step_with(*C.optimizer_list[1:])
+            return
         captured = []
         for i in range(self.n_agents):
             x_next = shared_next if shared_next is not None else self.critic_target._input(i, rd.next_observations, next_actions)

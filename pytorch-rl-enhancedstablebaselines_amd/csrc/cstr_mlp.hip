@@ -2430,7 +2430,9 @@ extern "C" int cstr_linear_act_fwd_sets_f32(const cstr_linear_set_t *sets, int n
         t.s[i] = q;
     }
     const dim3 grid((unsigned)((n + 15) / 16), (unsigned)((m + 15) / 16), (unsigned)n_sets);
-    const bool split = k > 32 && (int64_t)grid.x * grid.y * grid.z <= 2048;
+    // split-K when the tile grid is small; decided as if there were at most four sets, so that a launch carrying several
+    // independent four-set chains (fused.twin_pair_forward_many) sums in the same order as one launch per chain
+    const bool split = k > 32 && (int64_t)grid.x * grid.y * (grid.z < 4 ? grid.z : 4) <= 2048;
     hipStream_t s = (hipStream_t)stream;
 #define LIN(A, V, W) linear_act_fwd_sets_kernel<A, V, W><<<grid, 64 * W, 0, s>>>(t, (int)m, (int)n, (int)k)
 #define LIN_ACT(V, W) do { if (act == 0) LIN(0, V, W); else if (act == 1) LIN(1, V, W); else LIN(2, V, W); } while (0)

@@ -565,6 +565,35 @@ def test_maddpg_hipgraph_capture():
         assert th.isfinite(p).all()
 
 
+@pytest.mark.parametrize("graph", [False, True])
+def test_maddpg_batched_agent_critic_steps_equal_the_agent_loop(graph, monkeypatch):
+    """Steps without a policy update: the four agents' critic steps sharing launches (twin_pair_forward_many, one deferred
+    weight-gradient pass, one Adam launch) against one agent after the other -- identical weights, optimiser states and logged
+    critic losses after 24 updates at the class-default nets, eager and under hipGraph replay."""
+    from core.common.vec_env import CSTRVecEnv
+    from core.maddpg import MADDPG, maddpg as mod
+
+    def run(flag):
+        monkeypatch.setattr(mod, "BATCH_AGENT_CRITIC_STEPS", flag)
+        env = CSTRVecEnv(128, obs_dim=8, twin=True)
+        model = MADDPG(4, "MlpPolicy", env, [[0, 1], [2, 3], [4, 5], [6, 7]], [[0], [1], [2], [3]], learning_rate_list=[1e-3] * 4, seed=3,
+                       batch_size=256, buffer_size=128 * 32)
+        if graph:
+            model.enable_graph_capture()
+        model.learn(128 * 24)
+        th.cuda.synchronize()
+        assert model._n_updates == 24
+        flat = th.cat([p.detach().reshape(-1) for p in model.policy.parameters()])
+        opt = th.cat([o.exp_avg_sq for o in model.critic.optimizer_list])
+        steps = [o.step_count for o in model.critic.optimizer_list]
+        return flat.clone(), opt.clone(), model._loss_sum_buf.clone(), steps
+
+    a, b = run(True), run(False)
+    assert a[3] == b[3] == [24] * 4
+    for x, y in zip(a[:3], b[:3]):
+        assert th.equal(x, y)
+
+
 def test_single_gym_env_facade_matches_golden(golden):
     """`TwoSeriesCSTREnv` (reference constructor / gym API) as a 1-env view of the device env: step values vs the
     reference's single-step KATs; wrapping it in DummyVecEnv collapses N instances into one CSTRVecEnv."""
