@@ -472,7 +472,9 @@ int cstr_td_twin_q_loss_f32(const float *q1_t, const float *q2_t, const float *n
  * launch (logged loss, entropy-coefficient part, g_logp) with that launch's arithmetic and reduction order -- the critic
  * backward's / the actor backward's first launch and its loss launch become ONE.
  *   mode 1 (critic loss, core/sac/sac.py:245-261, core/td3/td3.py:174-182) = cstr_td_twin_q_loss_f32's fields;
- *   mode 2 (SAC actor loss, core/sac/sac.py:273-275)                       = cstr_sac_actor_loss_f32's fields (q1/q2 = Q(s, pi(s))).
+ *   mode 2 (SAC actor loss, core/sac/sac.py:273-275)                       = cstr_sac_actor_loss_f32's fields (q1/q2 = Q(s, pi(s)));
+ *   mode 3 (deterministic actors' loss -mean(Q1(s, pi(s))), core/td3/td3.py:194, core/maddpg/maddpg.py:177) = cstr_neg_mean_loss_f32's
+ *          fields (q1, loss_out, loss_sum), through the FIRST Q network alone: y / dz [1][m][k], w2 [k], gb1 / gw2 / gb2 of that network.
  * Unused pointers NULL; gq1 / gq2 of the separate launches are not produced (nothing else reads them). m <= 1024 rows. */
 typedef struct cstr_head_root {
     int32_t mode, batch;

@@ -520,7 +520,7 @@ LOSS_ROOT_MAX_ROWS = 1024  # cstr_hidden_head_bwd_root_f32 keeps the per-row gra
 
 def _take_root(groups: int) -> Optional[dict]:
     global _pending_root
-    if _pending_root is None or groups != 2:
+    if _pending_root is None or groups != (1 if _pending_root["mode"] == "neg_mean" else 2):
         return None
     root, _pending_root = _pending_root, None
     return root

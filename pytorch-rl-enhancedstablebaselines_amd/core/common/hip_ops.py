@@ -717,10 +717,11 @@ def hidden_head_bwd_root(root: dict, y, act: int, w2, dz, gb1=None, gw2=None, gb
     """`hidden_head_bwd` for the twin Q networks with the loss root inside (cstr_hidden_head_bwd_root_f32): `root` =
     dict(mode="td", q1_t, q2_t, next_logp | None, rew, done, ent_coef | None, gamma, scale, q1, q2, target_out | None, loss_out | None,
     loss_sum | None, alpha | None) -- the arguments of `td_twin_q_loss` -- or dict(mode="sac_actor", logp, q1, q2, ent_coef, g_logp,
-    loss_out | None, loss_sum | None) -- those of `sac_actor_loss`."""
+    loss_out | None, loss_sum | None) -- those of `sac_actor_loss` --, or dict(mode="neg_mean", q1, loss_out | None, loss_sum | None): the
+    deterministic actors' -mean(Q1) through the FIRST Q network alone (y [1, m, k])."""
     g, m, k = _gmn(y)
-    if g != 2:
-        raise ValueError("the loss-root form is built for the twin Q networks (2 groups)")
+    if g != (1 if root["mode"] == "neg_mean" else 2):
+        raise ValueError("the loss-root form is built for the twin Q networks (2 groups; mode 'neg_mean': the first one alone)")
     _chk(dz, "dz", y.shape, th.float32)
     for t, nm, numel in ((y, "y", g * m * k), (w2, "w2", g * k)):
         if _f32c(t, nm).numel() != numel:
@@ -749,6 +750,9 @@ def hidden_head_bwd_root(root: dict, y, act: int, w2, dz, gb1=None, gw2=None, gb
     elif root["mode"] == "sac_actor":
         rt = nv.HeadRoot(2, m, 0.0, 0.0, None, None, None, None, None, p("ent_coef", 1), p("q1"), p("q2"), None, p("logp"), p("g_logp"),
                          p("loss_out", 1), p("loss_sum", 1), part)
+    elif root["mode"] == "neg_mean":  # neg_mean_loss's arguments: loss = -mean(q1)
+        rt = nv.HeadRoot(3, m, 0.0, 0.0, None, None, None, None, None, None, p("q1"), None, None, None, None, p("loss_out", 1), p("loss_sum", 1),
+                         part)
     else:
         raise ValueError(f"unknown loss root {root['mode']!r}")
     check(nv.lib().cstr_hidden_head_bwd_root_f32(C.byref(rt), ptr(y), C.c_int(act), ptr(w2), ptr(dz), ptr(gb1), ptr(gw2), ptr(gb2),

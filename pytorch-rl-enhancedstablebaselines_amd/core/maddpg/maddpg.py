@@ -412,8 +412,14 @@ class MADDPG(OffPolicyAlgorithm):
                     else:
                         x_pi = C._input(i, rd.observations, th.cat(acts, dim=-1))
                 qs_pi = self._fast_critics[i].forward_input(x_pi, train_params=False, only_first=True)
-                hip_ops.neg_mean_loss(qs_pi[0], gq[0], self._loss_now, self._loss_sums[f"actor{i}"])
-                fused.backward_q(qs_pi, gq)
+                if qs_pi.stacked is not None and B <= fused.LOSS_ROOT_MAX_ROWS and fused.loss_root_supported(self._fast_critics[i]):
+                    # -mean(Q1) (:177) rides in the first launch of the backward through the (frozen) first Q network
+                    with fused.loss_root(dict(mode="neg_mean", q1=qs_pi[0].detach(), loss_out=self._loss_now,
+                                              loss_sum=self._loss_sums[f"actor{i}"])):
+                        fused.backward_q(qs_pi, gq)
+                else:
+                    hip_ops.neg_mean_loss(qs_pi[0], gq[0], self._loss_now, self._loss_sums[f"actor{i}"])
+                    fused.backward_q(qs_pi, gq)
                 self._allreduce_grads(pol.actor_slices[i])
                 if self.faithful_quirks:
                     # Q3: polyak of BOTH whole arenas inside the agent loop (:183-185), in the launch of agent i's actor step: the

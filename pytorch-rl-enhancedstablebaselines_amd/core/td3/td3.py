@@ -231,8 +231,13 @@ class TD3(OffPolicyAlgorithm):
                 a = self._fast_actor(rd.observations)
                 qs_pi = self._fast_critic(rd.observations, a, train_params=False, only_first=True)
             a_out, a_sum = (s["actor"], None) if single else (self._loss_now["actor"], s["actor"])
-            hip_ops.neg_mean_loss(qs_pi[0], gq1, a_out, a_sum)
-            fused.backward_q(qs_pi, gq)
+            if qs_pi.stacked is not None and B <= fused.LOSS_ROOT_MAX_ROWS and fused.loss_root_supported(self._fast_critic):
+                # -mean(Q1) (:194) rides in the first launch of the backward through the (frozen) first Q network
+                with fused.loss_root(dict(mode="neg_mean", q1=qs_pi[0].detach(), loss_out=a_out, loss_sum=a_sum)):
+                    fused.backward_q(qs_pi, gq)
+            else:
+                hip_ops.neg_mean_loss(qs_pi[0], gq1, a_out, a_sum)
+                fused.backward_q(qs_pi, gq)
             self._allreduce_grads(pol.actor_arena)
             # the actor's step, the critics' soft update (disjoint arenas) and the actor target's soft update (by the threads that
             # have just computed the new actor weights) in ONE launch (:199, :204, :205)

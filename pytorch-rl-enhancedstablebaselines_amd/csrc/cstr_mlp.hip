@@ -1787,7 +1787,8 @@ __device__ __forceinline__ float block_sum_first4(float v, float *sm)
 // batch's Q values, so every workgroup recomputes it for the rows it walks (the same expressions as td_twin_q_loss_kernel /
 // sac_actor_loss_kernel: the same bits), and ONE extra workgroup (blockIdx.x == gridDim.x - 1, group 0) does what only the
 // separate loss launch did: target_out / g_logp, the logged loss and the entropy-coefficient part, with that launch's 256-thread
-// accumulation pattern and reduction tree. Two groups (the twin Q networks).
+// accumulation pattern and reduction tree. Two groups (the twin Q networks); MODE 3 (-mean(Q1), the deterministic actors' loss,
+// core/td3/td3.py:194, core/maddpg/maddpg.py:177): one group.
 template <int ACT, int WAVES, int MODE>
 __global__ __launch_bounds__(WAVES * 64) void hidden_head_bwd_root_kernel(const cstr_head_root_t rt, const float *__restrict__ y,
                                                                           const float *__restrict__ w2, float *__restrict__ dz,
@@ -1833,6 +1834,17 @@ __global__ __launch_bounds__(WAVES * 64) void hidden_head_bwd_root_kernel(const 
                     if (rt.alpha.ent_coef_sum) rt.alpha.ent_coef_sum[0] += ec;
                 }
             }
+        } else if (MODE == 3) {  // -mean(Q1): neg_mean_loss_kernel's accumulation and tree
+            float acc = 0.0f;
+            if (tid < 256) {
+                for (int b = tid; b < rt.batch; b += 256) acc += rt.q1[b];
+            }
+            const float sum = block_sum_first4(acc, sm);
+            if (tid == 0) {
+                const float loss = -(sum * inv);
+                if (rt.loss_out) rt.loss_out[0] = loss;
+                if (rt.loss_sum) rt.loss_sum[0] += loss;
+            }
         } else {
             float acc = 0.0f;
             if (tid < 256) {
@@ -1866,6 +1878,8 @@ __global__ __launch_bounds__(WAVES * 64) void hidden_head_bwd_root_kernel(const 
                 if (rt.next_logp) q = q - ec * rt.next_logp[r];
                 const float tq = rt.rew[r] + (1.0f - rt.done[r]) * rt.gamma * q;
                 gqv = kq * (qg[r] - tq);
+            } else if (MODE == 3) {
+                gqv = -inv;
             } else {
                 const bool first = rt.q1[r] <= rt.q2[r];
                 gqv = (first == (g == 0)) ? -inv : 0.0f;
@@ -2106,15 +2120,16 @@ extern "C" int cstr_hidden_head_bwd_root_f32(const cstr_head_root_t *root, const
     if (!root || !y || !w2 || !dz || m <= 0 || k <= 0) return CSTR_E_BADARG;
     const cstr_head_root_t &r = *root;
     if ((gb1 == nullptr) != (gw2 == nullptr) || (gw2 == nullptr) != (gb2 == nullptr)) return CSTR_E_BADARG;  // all three or none
-    if ((r.mode != 1 && r.mode != 2) || r.batch != m || !r.q1 || !r.q2) return CSTR_E_BADARG;
+    if ((r.mode != 1 && r.mode != 2 && r.mode != 3) || r.batch != m || !r.q1 || (r.mode != 3 && !r.q2)) return CSTR_E_BADARG;
     if (r.mode == 1 && (!r.q1_t || !r.q2_t || !r.rew || !r.done || (r.next_logp && !r.alpha.log_alpha && !r.ent_coef))) return CSTR_E_BADARG;
     if (r.mode == 1 && r.alpha.log_alpha && (!r.alpha.logp_pi || !r.alpha.grad_out || !r.alpha.ent_coef_out)) return CSTR_E_BADARG;
     if (r.mode == 2 && (!r.logp || !r.g_logp || !r.ent_coef)) return CSTR_E_BADARG;
     if (act < 0 || act > 2 || m > HEAD_ROOT_MAX_ROWS || k > 0x7fffffff) return CSTR_E_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
-    const dim3 grid((unsigned)((k + 63) / 64) + 1u, 2u);  // + the loss workgroup
+    const dim3 grid((unsigned)((k + 63) / 64) + 1u, r.mode == 3 ? 1u : 2u);  // + the loss workgroup; mode 3: ONE Q network
 #define HH_ROOT(A, W) do { if (r.mode == 1) hidden_head_bwd_root_kernel<A, W, 1><<<grid, W * 64, 0, s>>>(r, y, w2, dz, gb1, gw2, gb2, (int)m, (int)k); \
-                           else hidden_head_bwd_root_kernel<A, W, 2><<<grid, W * 64, 0, s>>>(r, y, w2, dz, gb1, gw2, gb2, (int)m, (int)k); } while (0)
+                           else if (r.mode == 2) hidden_head_bwd_root_kernel<A, W, 2><<<grid, W * 64, 0, s>>>(r, y, w2, dz, gb1, gw2, gb2, (int)m, (int)k); \
+                           else hidden_head_bwd_root_kernel<A, W, 3><<<grid, W * 64, 0, s>>>(r, y, w2, dz, gb1, gw2, gb2, (int)m, (int)k); } while (0)
     if (m >= 64) { if (act == 0) HH_ROOT(0, 16); else if (act == 1) HH_ROOT(1, 16); else HH_ROOT(2, 16); }
     else { if (act == 0) HH_ROOT(0, 4); else if (act == 1) HH_ROOT(1, 4); else HH_ROOT(2, 4); }
 #undef HH_ROOT

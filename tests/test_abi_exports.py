@@ -81,7 +81,7 @@ def test_round2_entry_points_reject_bad_arguments_on_the_host():
     i64, f32 = C.c_int64, C.c_float
     # loss root: NULL struct, unknown mode, batch != m, missing mode-1 / mode-2 pointers, too many rows
     assert lib.cstr_hidden_head_bwd_root_f32(null, fake, 1, fake, fake, null, null, null, i64(256), i64(256), null) == -1
-    rt = nv.HeadRoot(3, 256, 0.99, 1.0, 0x1000, 0x1000, None, 0x1000, 0x1000, None, 0x1000, 0x1000, None, None, None, None, None, nv.AlphaPart())
+    rt = nv.HeadRoot(7, 256, 0.99, 1.0, 0x1000, 0x1000, None, 0x1000, 0x1000, None, 0x1000, 0x1000, None, None, None, None, None, nv.AlphaPart())
     assert lib.cstr_hidden_head_bwd_root_f32(C.byref(rt), fake, 1, fake, fake, null, null, null, i64(256), i64(256), null) == -1
     rt.mode, rt.batch = 1, 128
     assert lib.cstr_hidden_head_bwd_root_f32(C.byref(rt), fake, 1, fake, fake, null, null, null, i64(256), i64(256), null) == -1
@@ -89,6 +89,9 @@ def test_round2_entry_points_reject_bad_arguments_on_the_host():
     assert lib.cstr_hidden_head_bwd_root_f32(C.byref(rt), fake, 1, fake, fake, null, null, null, i64(256), i64(256), null) == -1
     rt.rew, rt.mode = 0x1000, 2  # mode 2 needs logp, g_logp, ent_coef
     assert lib.cstr_hidden_head_bwd_root_f32(C.byref(rt), fake, 1, fake, fake, null, null, null, i64(256), i64(256), null) == -1
+    rt.mode, rt.q1 = 3, None  # mode 3 (-mean(Q1)) still needs q1
+    assert lib.cstr_hidden_head_bwd_root_f32(C.byref(rt), fake, 1, fake, fake, null, null, null, i64(256), i64(256), null) == -1
+    rt.q1 = 0x1000
     rt.mode, rt.batch = 1, 2048
     assert lib.cstr_hidden_head_bwd_root_f32(C.byref(rt), fake, 1, fake, fake, null, null, null, i64(2048), i64(256), null) == -2
     rt.batch = 256  # gb1 / gw2 / gb2 go together

@@ -292,6 +292,37 @@ def test_hidden_layer_plus_scalar_head_kernels(ops, G, M, K, act):
         assert th.equal(q2, q[0]) and th.equal(y2, y[0])
 
 
+@pytest.mark.parametrize("M,K,act", [(256, 300, 1), (100, 64, 2), (16, 256, 0)])
+def test_deterministic_actor_loss_inside_the_head_backward(ops, M, K, act):
+    """cstr_hidden_head_bwd_root_f32 mode 3 (-mean(Q1) through the first Q network alone) against cstr_neg_mean_loss_f32 followed by
+    cstr_hidden_head_bwd_f32 on one group: logged loss, running sum and dz bit-identical; with and without parameter gradients."""
+    g = th.Generator(device="cuda").manual_seed(M + K)
+    r = lambda *sh: th.randn(*sh, device="cuda", generator=g)  # noqa: E731
+    y = r(1, M, K) if act != 1 else th.relu(r(1, M, K))
+    if act == 2:
+        y = th.tanh(y)
+    w2, q = r(1, K), r(M, 1)
+    gq = th.empty(1, M, 1, device="cuda")
+    l1, s1 = th.zeros(1, device="cuda"), th.full((1,), 2.5, device="cuda")
+    l2, s2 = th.zeros(1, device="cuda"), th.full((1,), 2.5, device="cuda")
+    dz1, dz2 = th.empty_like(y), th.empty_like(y)
+    p1 = [th.empty(1, K, device="cuda"), th.empty(1, K, device="cuda"), th.empty(1, device="cuda")]
+    p2 = [th.empty(1, K, device="cuda"), th.empty(1, K, device="cuda"), th.empty(1, device="cuda")]
+    ops.neg_mean_loss(q, gq[0], l1, s1)
+    ops.hidden_head_bwd(gq, y, act, w2, dz1, *p1)
+    ops.hidden_head_bwd_root(dict(mode="neg_mean", q1=q, loss_out=l2, loss_sum=s2), y, act, w2, dz2, *p2)
+    th.cuda.synchronize()
+    assert th.equal(l1, l2) and th.equal(s1, s2) and th.equal(dz1, dz2)
+    for a, b in zip(p1, p2):
+        assert th.equal(a, b)
+    assert abs(float(l2) + float(q.double().mean())) < 1e-5
+    dz3 = th.empty_like(y)
+    ops.hidden_head_bwd_root(dict(mode="neg_mean", q1=q, loss_out=None, loss_sum=None), y, act, w2, dz3)  # frozen parameters
+    assert th.equal(dz3, dz1)
+    with pytest.raises(Exception):  # two groups are the twin modes' business
+        ops.hidden_head_bwd_root(dict(mode="neg_mean", q1=q, loss_out=None, loss_sum=None), th.cat([y, y]), act, th.cat([w2, w2]), th.cat([dz3, dz3]))
+
+
 def test_gaussian_head_kernels_match_unfused_path_and_rng_statistics(ops):
     """cstr_gaussian_head_{fwd,bwd}_f32 = head bias + squashed-Gaussian sampling in one launch. With eps GIVEN it must equal
     bias_act_fwd + squashed_gaussian_fwd/bwd (+ the bias gradient's column sum); with the in-kernel Philox stream the noise
