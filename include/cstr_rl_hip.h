@@ -436,6 +436,15 @@ int cstr_rollout_step_f32(const cstr_policy_mlp_t *net, const float *x, int64_t 
 int cstr_target_smooth_f32(const float *action, const float *noise, uint64_t *rng_ctl, float sigma, float clip, float *out,
                            int64_t out_stride, int64_t batch, int act_dim, cstr_stream_t stream);
 
+/* A deterministic target actor's LAST Linear with that smoothing inside (core/td3/td3.py:167-173: actor_target(next_obs), then
+ * noise, clamp, add, clamp): out[row][j] = clamp(act(x W^T + b)[row][j] + clamp(z, -clip, clip), -1, 1), z as in
+ * cstr_target_smooth_f32 (noise [m][n] read, or sigma * N(0,1) drawn from rng_ctl with the same counters; the offset advances by
+ * m). One launch instead of two; bit-identical to cstr_linear_act_fwd_f32 followed by cstr_target_smooth_f32. w [n][k], n <= 16,
+ * k > 32, m <= 32768 (CSTR_E_UNSUPPORTED otherwise: use the two launches). */
+int cstr_linear_smooth_fwd_f32(const float *x, int64_t ldx, const float *w, const float *bias, int act, const float *noise,
+                               uint64_t *rng_ctl, float sigma, float clip, float *out, int64_t out_stride, int64_t m, int64_t n,
+                               int64_t k, cstr_stream_t stream);
+
 /* SAC entropy coefficient (core/sac/sac.py:230-243): ent_coef_out = exp(log_alpha); grad_out = d/dlog_alpha of
  * -mean(log_alpha * (logp + target_entropy)) = -mean(logp + target_entropy). loss_out (stored) and loss_sum /
  * ent_coef_sum (accumulated) are device scalars, each may be NULL: the values train() logs (:232, :236), no host sync. */

@@ -20,7 +20,7 @@ RNG_CTL_WORDS, MAX_HEAD_ACT, MAX_LINEAR_SETS, MAX_ADAM_SEGS = 16, 4, 16, 4
 SYMBOLS = (
     "cstr_abi_version", "cstr_error_string", "cstr_default_coef", "cstr_vec_step_f32", "cstr_reset_draw_f32",
     "cstr_replay_add_f32", "cstr_collect_step_f32", "cstr_collect_step_rng_f32", "cstr_mt19937_seed", "cstr_mt19937_normal_f32", "cstr_mt19937_normal_f64", "cstr_replay_sample_mt19937_f32", "cstr_replay_sample_packed_mt19937_f32", "cstr_replay_gather_packed_f32", "cstr_rollout_step_f32", "cstr_linear_act_fwd_gather_f32",
-    "cstr_adam_multi_f32", "cstr_gaussian_head_fwd_f32", "cstr_gaussian_head_gemm_fwd_f32", "cstr_gaussian_head_bwd_f32", "cstr_gaussian_head_bwd_input_f32", "cstr_linear_act_fwd_f32", "cstr_linear_act_fwd_sets_f32", "cstr_linear_bwd_input_f32", "cstr_linear_bwd_weight_f32", "cstr_linear_bwd_weight_sets_f32", "cstr_td_twin_q_loss_f32", "cstr_policy_rows_fwd_f32", "cstr_policy_swizzle_f32", "cstr_target_smooth_f32", "cstr_hidden_head_fwd_f32", "cstr_hidden_head_bwd_f32", "cstr_hidden_head_bwd_root_f32", "cstr_vecnorm_init_f64", "cstr_vecnorm_step_f64", "cstr_vecnorm_apply_f32",
+    "cstr_adam_multi_f32", "cstr_gaussian_head_fwd_f32", "cstr_gaussian_head_gemm_fwd_f32", "cstr_gaussian_head_bwd_f32", "cstr_gaussian_head_bwd_input_f32", "cstr_linear_act_fwd_f32", "cstr_linear_act_fwd_sets_f32", "cstr_linear_bwd_input_f32", "cstr_linear_bwd_weight_f32", "cstr_linear_bwd_weight_sets_f32", "cstr_td_twin_q_loss_f32", "cstr_policy_rows_fwd_f32", "cstr_policy_swizzle_f32", "cstr_target_smooth_f32", "cstr_linear_smooth_fwd_f32", "cstr_hidden_head_fwd_f32", "cstr_hidden_head_bwd_f32", "cstr_hidden_head_bwd_root_f32", "cstr_vecnorm_init_f64", "cstr_vecnorm_step_f64", "cstr_vecnorm_apply_f32",
     "cstr_td_target_min_f32", "cstr_polyak_f32", "cstr_adam_f32", "cstr_bias_act_fwd_f32", "cstr_bias_act_bwd_f32", "cstr_bias_act_bwd_rows_f32",
     "cstr_squashed_gaussian_fwd_f32", "cstr_squashed_gaussian_bwd_f32", "cstr_sac_alpha_f32", "cstr_twin_q_loss_f32",
     "cstr_sac_actor_loss_f32", "cstr_neg_mean_loss_f32",

@@ -41,6 +41,8 @@ USE_ACTOR_PAIR = os.environ.get("CSTR_ACTOR_PAIR", "1") != "0"
 # SAC: when the rollout launch has drawn the batch indices, the 2B-row actor pass's first layer gathers the sampled rows itself
 # (hip_ops.linear_act_fwd_gather) instead of a gather launch in front of it; "0" keeps the gather launch (A/B, bit-identical)
 USE_GATHER_IN_FIRST_LAYER = os.environ.get("CSTR_GATHER_IN_L1", "1") != "0"
+# TD3: the target actor's last layer adds the target policy smoothing itself (hip_ops.linear_smooth_fwd); "0" = separate launch
+USE_SMOOTH_IN_LAST_LAYER = os.environ.get("CSTR_SMOOTH_IN_LAST", "1") != "0"
 USE_TWIN_PAIR = os.environ.get("CSTR_TWIN_PAIR", "1") != "0"
 USE_LOSS_ROOT = os.environ.get("CSTR_LOSS_ROOT", "1") != "0"  # the loss launches ride in the backward's first launch
 
@@ -253,11 +255,25 @@ class FastMLP:
         return dict(weights=(l1.weight, l1.bias, l2.weight, l2.bias, l3.weight, l3.bias), act=act, head=1, out_act=out_act, w2_swz=swz,
                     rng_ctl=None)
 
-    def _tail(self, x: th.Tensor, first: int) -> th.Tensor:
-        """layers[first:] of an inference pass (no gradients kept)."""
-        for lin, act in self.layers[first:]:
+    def _tail(self, x: th.Tensor, first: int, smooth: Optional[dict] = None) -> th.Tensor:
+        """layers[first:] of an inference pass (no gradients kept). `smooth`: see `__call__`."""
+        last = len(self.layers) - 1
+        for li, (lin, act) in enumerate(self.layers[first:], first):
+            if li == last and smooth is not None:
+                return hip_ops.linear_smooth_fwd(x, lin.weight, lin.bias, act, smooth.get("noise"), smooth.get("rng_ctl"), smooth["sigma"],
+                                                 smooth["clip"], smooth["out"])
             x = linear(x, lin.weight, lin.bias, act, False, None, grad_is_dz=False)
         return x
+
+    def smooth_supported(self, x: th.Tensor) -> bool:
+        """`__call__(x, train_params=False, smooth=...)` applies: a per-layer inference pass whose last Linear can add the target
+        policy smoothing itself (hip_ops.linear_smooth_fwd)."""
+        layers = self.layers
+        with th.no_grad():
+            whole = self._whole_net_ok(x, train_params=False)
+        lin = layers[-1][0]
+        return (USE_FUSED_LINEAR and not whole and len(layers) >= 2 and x.dim() == 2 and x.shape[0] <= 1024
+                and hip_ops.linear_smooth_supported(x.shape[0], lin.out_features, lin.in_features) and lin.weight.is_contiguous())
 
     def tail_below(self, train_params: bool):
         """what a fused consumer of this MLP's output needs to run the last layer's activation / bias gradient itself"""
@@ -274,13 +290,19 @@ class FastMLP:
                 and lin.weight.is_contiguous() and lin.weight.data_ptr() % 16 == 0 and not (len(layers) == 2 and layers[-1][0].out_features == 1))
 
     def __call__(self, x: th.Tensor, train_params: bool = True, out_grad_is_dz: bool = False, xbuf: Optional[th.Tensor] = None,
-                 gather=None) -> th.Tensor:
+                 gather=None, smooth: Optional[dict] = None) -> th.Tensor:
         """`out_grad_is_dz`: the consumer is a fused layer built with `below=self.tail_below(...)` (see _input_grad).
         `xbuf` [M, W]: the output is written into its last out_features columns and the BUFFER is returned (a deterministic actor's
         action straight into the critic input, differentiable).
         `gather` = ReplayBuffer.take_predrawn(pb) (inference only, `gather_supported`): x is the not-yet-gathered next-observation
-        block of `pb`; the first layer fetches the sampled rows from the ring and writes `pb` for the launches behind it."""
+        block of `pb`; the first layer fetches the sampled rows from the ring and writes `pb` for the launches behind it.
+        `smooth` = dict(noise | rng_ctl, sigma, clip, out) (inference only, `smooth_supported`): the last layer adds the target policy
+        smoothing and writes the result into `out` (the action columns of the target critic's input), which is returned."""
         layers = self.layers
+        if smooth is not None and (th.is_grad_enabled() or train_params or xbuf is not None or not self.smooth_supported(x)):
+            raise NotImplementedError("FastMLP smooth: a no-grad inference pass through the per-layer kernels only")
+        if gather is None and smooth is not None:
+            return FastMLP._tail(self, x, 0, smooth)
         if gather is not None:
             if th.is_grad_enabled() or train_params or xbuf is not None or not self.gather_supported(x):
                 raise NotImplementedError("FastMLP gather: a no-grad inference pass through the per-layer kernels only")
@@ -288,7 +310,7 @@ class FastMLP:
             lin, act = layers[0]
             h = hip_ops.linear_act_fwd_gather(ring, idx, x.shape[0], False, lin.weight, lin.bias, act, pb.x_data, pb.x_next, pb.x_pi,
                                               pb.samples.dones, pb.samples.rewards, advance_ring=True, rng_advance=rng_advance)
-            return FastMLP._tail(self, h, 1)
+            return FastMLP._tail(self, h, 1, smooth)
         if xbuf is not None:
             if not USE_FUSED_LINEAR or not th.is_grad_enabled() or layers[-1][0].out_features == 1 or x.stride(-1) != 1:
                 raise NotImplementedError("FastMLP xbuf: the fused, differentiated, non-scalar-head form only")

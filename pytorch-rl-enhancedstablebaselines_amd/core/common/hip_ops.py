@@ -684,6 +684,28 @@ def target_smooth(action, noise, rng_ctl, sigma: float, clip: float, out):
     return out
 
 
+def linear_smooth_supported(m: int, n: int, k: int) -> bool:
+    return n <= 16 and k > 32 and m <= 32768
+
+
+def linear_smooth_fwd(x, weight, bias, act: int, noise, rng_ctl, sigma: float, clip: float, out):
+    """`linear_act_fwd` followed by `target_smooth` in ONE launch (cstr_linear_smooth_fwd_f32): out [M, N] (may be a column block of a
+    wider row-major matrix) = clamp(act(x W^T + b) + clamp(noise | sigma N(0, 1) from rng_ctl, -clip, clip), -1, 1)."""
+    m, k = x.shape
+    n = weight.shape[0]
+    if not (x.is_cuda and x.dtype == th.float32 and x.dim() == 2 and x.stride(1) == 1):
+        raise ValueError("x: needs a float32 device matrix with unit column stride")
+    _chk(weight, "weight", (n, k), th.float32), _chk(bias, "bias", (n,), th.float32)
+    _opt(noise, "noise", (m, n), th.float32), _opt(rng_ctl, "rng_ctl", (nv.RNG_CTL_WORDS,), th.int64)
+    if (noise is None) == (rng_ctl is None):
+        raise ValueError("exactly one noise source: noise or rng_ctl")
+    stride = _rows(out, "out", m, n)
+    check(nv.lib().cstr_linear_smooth_fwd_f32(ptr(x), C.c_int64(max(x.stride(0), k)), ptr(weight), ptr(bias), C.c_int(act), ptr(noise),
+                                              ptr(rng_ctl), C.c_float(sigma), C.c_float(clip), ptr(out), C.c_int64(stride), C.c_int64(m),
+                                              C.c_int64(n), C.c_int64(k), stream_ptr()), "cstr_linear_smooth_fwd_f32")
+    return out
+
+
 def hidden_head_fwd_(z, b1, act: int, w2, b2, q):
     """y = act(z + b1) in place on z [G, m, k] (or [m, k]); q [G, m, 1] = y . w2 + b2 (a Q network's scalar head)."""
     g, m, k = _gmn(z)

@@ -180,10 +180,16 @@ class TD3(OffPolicyAlgorithm):
         with th.no_grad():  # :167-176
             if pb is not None:
                 # target smoothing in ONE launch (clone + normal_ + clamp + add + clamp), written into x_next's action columns
-                a_t = self._fast_actor_target(rd.next_observations, train_params=False, gather=gather)
                 queued = self.noise_queue.pop(0).to(self.device, th.float32).contiguous() if self.noise_queue else None
-                hip_ops.target_smooth(a_t, queued, None if queued is not None else self._device_rng(), self.target_policy_noise,
-                                      self.target_noise_clip, pb.x_next[:, pb.obs_dim:])
+                rng = None if queued is not None else self._device_rng()
+                if fused.USE_SMOOTH_IN_LAST_LAYER and self._fast_actor_target.smooth_supported(rd.next_observations):
+                    # ... inside the target actor's last layer (one launch less)
+                    self._fast_actor_target(rd.next_observations, train_params=False, gather=gather,
+                                            smooth=dict(noise=queued, rng_ctl=rng, sigma=self.target_policy_noise, clip=self.target_noise_clip,
+                                                        out=pb.x_next[:, pb.obs_dim:]))
+                else:
+                    a_t = self._fast_actor_target(rd.next_observations, train_params=False, gather=gather)
+                    hip_ops.target_smooth(a_t, queued, rng, self.target_policy_noise, self.target_noise_clip, pb.x_next[:, pb.obs_dim:])
                 twin_pair = fused.twin_pair_supported(self._fast_critic, self._fast_critic_target)
                 if not twin_pair:
                     qs = self._fast_critic_target.forward_input(pb.x_next, train_params=False)

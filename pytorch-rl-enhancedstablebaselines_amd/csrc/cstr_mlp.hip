@@ -807,6 +807,100 @@ __global__ __launch_bounds__(64) void target_smooth_kernel(const float *__restri
         rng_ctl[1] = base + (uint64_t)batch;
 }
 
+// A deterministic TARGET actor's last layer with the target policy smoothing inside (cstr_linear_smooth_fwd_f32): out = clamp(
+// act(x W^T + b) + clamp(N(0, sigma), -clip, clip), -1, 1) written into the action columns of the target critic's input -- the
+// Linear launch and the smoothing launch (cstr_target_smooth_f32) are one. n <= 16 (one column tile), k > 32: a workgroup per 16
+// rows, four-way split-K exactly like linear_act_fwd_kernel<., ., 4> (same MFMA sequence, same LDS combine: bit-identical), the
+// noise of the tile's rows drawn while the operand loads are in flight (same Philox counters as target_smooth_kernel).
+template <int ACT, bool VEC>
+__global__ __launch_bounds__(256) void linear_smooth_fwd_kernel(const float *__restrict__ x, const int ldx, const float *__restrict__ w,
+                                                                const float *__restrict__ bias, const int M, const int N, const int K,
+                                                                const float *__restrict__ noise, uint64_t *__restrict__ rng_ctl,
+                                                                const float sigma, const float clip, float *__restrict__ out,
+                                                                const int64_t out_stride)
+{
+    constexpr int WAVES = 4;
+    __shared__ f32x4 part[WAVES - 1][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, h = lane >> 4;
+    const int m0 = blockIdx.x * 16;
+    const float *xr = x + (int64_t)(m0 + r) * ldx;
+    const float *wr = w + (int64_t)r * K;
+    const bool row_ok = m0 + r < M, col_ok = r < N;
+    f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
+    constexpr int UNROLL = 4;
+    float4 a[UNROLL], b[UNROLL];
+    const int c_first = 16 * wave;
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {  // the first batch of operand loads ...
+        const int k = c_first + 16 * WAVES * u + 4 * h;
+        a[u] = load_k4<VEC>(xr, k, K, row_ok && c_first < K);
+        b[u] = load_k4<VEC>(wr, k, K, col_ok && c_first < K);
+    }
+    // ... and, beside them, the smoothing noise of this lane's four rows (column r): target_smooth_kernel's counters
+    float nz[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    const uint64_t seed = rng_ctl ? rng_ctl[0] : 0ull, base = rng_ctl ? rng_ctl[1] : 0ull;
+    if (wave == 0 && col_ok) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int64_t row = m0 + 4 * h + e;
+            float z = 0.0f;
+            if (rng_ctl) {
+                const uint64_t ctr = base + (uint64_t)row;
+                uint32_t rr[4];
+                float e0, e1;
+                philox4x32_10((uint32_t)ctr, (uint32_t)(ctr >> 32), (uint32_t)(r >> 1), 0u, (uint32_t)seed, (uint32_t)(seed >> 32), rr);
+                box_muller(rr[0], rr[1], e0, e1);
+                e0 *= sigma;
+                e1 *= sigma;
+                z = (r & 1) ? e1 : e0;
+            } else if (row < M) {
+                z = noise[row * N + r];
+            }
+            nz[e] = fminf(fmaxf(z, -clip), clip);
+        }
+    }
+    for (int c0 = c_first; c0 < K; c0 += 16 * WAVES * UNROLL) {
+        if (c0 != c_first) {
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+                const int k = c0 + 16 * WAVES * u + 4 * h;
+                a[u] = load_k4<VEC>(xr, k, K, row_ok);
+                b[u] = load_k4<VEC>(wr, k, K, col_ok);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].x, b[u].x, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].y, b[u].y, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].z, b[u].z, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].w, b[u].w, acc1, 0, 0, 0);
+        }
+    }
+    f32x4 acc = acc0 + acc1;
+    if (wave > 0) part[wave - 1][lane] = acc;
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int v = 0; v < WAVES - 1; ++v) acc += part[v][lane];
+        if (col_ok) {
+            const float bv = bias[r];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int64_t row = m0 + 4 * h + e;
+                if (row < M) {
+                    float v = acc[e] + bv;
+                    if (ACT == ACT_RELU) v = fmaxf(v, 0.0f);
+                    if (ACT == ACT_TANH) v = tanhf(v);
+                    out[row * out_stride + r] = fminf(fmaxf(v + nz[e], -1.0f), 1.0f);
+                }
+            }
+        }
+    }
+    if (rng_ctl && last_block_ticket(reinterpret_cast<unsigned long long *>(rng_ctl + 2)) && threadIdx.x == 0)
+        rng_ctl[1] = base + (uint64_t)M;
+}
+
+
 // The same head INCLUDING its GEMM: the merged (mu | log_std) Linear has 2A <= 8 outputs, i.e. it is 2A dot products per
 // row, not a matrix-matrix product. One wave per row: 16-byte loads of the latent row and of the 2A weight rows, xor-shuffle
 // reductions, then the sampling arithmetic of gaussian_head_fwd_kernel on the reduced values (computed redundantly by every
@@ -2358,6 +2452,26 @@ extern "C" int cstr_linear_act_fwd_gather_f32(const cstr_ring_t *ring, int64_t *
     if (act == 0) GL(0); else if (act == 1) GL(1); else GL(2);
 #undef GL
 #undef GL2
+    return (int)hipGetLastError();
+}
+
+extern "C" int cstr_linear_smooth_fwd_f32(const float *x, int64_t ldx, const float *w, const float *bias, int act, const float *noise,
+                                          uint64_t *rng_ctl, float sigma, float clip, float *out, int64_t out_stride, int64_t m, int64_t n,
+                                          int64_t k, cstr_stream_t stream)
+{
+    if (!x || !w || !bias || !out || m <= 0 || n <= 0 || k <= 0 || ldx < k || out_stride < n) return CSTR_E_BADARG;
+    if ((noise == nullptr) == (rng_ctl == nullptr)) return CSTR_E_BADARG;  // exactly one noise source
+    if (!(sigma >= 0.0f) || !(clip >= 0.0f) || act < 0 || act > 2) return CSTR_E_BADARG;
+    // the shapes for which cstr_linear_act_fwd_f32 takes its four-way split-K form (bit-identical results)
+    if (n > 16 || k <= 32 || k > 0x7fffff || (m + 15) / 16 > 2048) return CSTR_E_UNSUPPORTED;
+    const unsigned grid = (unsigned)((m + 15) / 16);
+    const bool vec = (k & 3) == 0 && (ldx & 3) == 0 && aligned16(x) && aligned16(w);
+    hipStream_t s = (hipStream_t)stream;
+#define LS(A, V) linear_smooth_fwd_kernel<A, V><<<grid, 256, 0, s>>>(x, (int)ldx, w, bias, (int)m, (int)n, (int)k, noise, rng_ctl, sigma, clip, out, out_stride)
+#define LS_ACT(V) do { if (act == 0) LS(0, V); else if (act == 1) LS(1, V); else LS(2, V); } while (0)
+    if (vec) LS_ACT(true); else LS_ACT(false);
+#undef LS_ACT
+#undef LS
     return (int)hipGetLastError();
 }
 

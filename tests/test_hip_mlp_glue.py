@@ -400,6 +400,30 @@ def test_target_smoothing_kernel(ops):
         hip_ops.target_smooth(a, noise, ctl, 0.2, 0.5, x[:, D:])
 
 
+@pytest.mark.parametrize("M,K,N,act", [(256, 300, 2, 2), (100, 64, 4, 2), (1000, 256, 1, 0), (16, 36, 16, 1)])
+def test_last_layer_with_the_target_smoothing_inside(ops, M, K, N, act):
+    """cstr_linear_smooth_fwd_f32 against cstr_linear_act_fwd_f32 followed by cstr_target_smooth_f32: bit-identical output (written
+    into a column block of a wider matrix) and Philox control block, for given noise and for in-kernel noise."""
+    g = th.Generator(device="cuda").manual_seed(M + K + N)
+    r = lambda *sh: th.randn(*sh, device="cuda", generator=g)  # noqa: E731
+    x, w, b = r(M, K + 4)[:, :K], r(N, K) / K ** 0.5, r(N) * 0.1
+    noise = (r(M, N) * 0.2).contiguous()
+    for rng in (False, True):
+        c1, c2 = ops.new_rng_ctl(9, "cuda"), ops.new_rng_ctl(9, "cuda")
+        c1[1] = c2[1] = 12345
+        o1, o2 = th.full((M, 3 + N), 7.0, device="cuda"), th.full((M, 3 + N), 7.0, device="cuda")
+        a = ops.linear_act_fwd(x, w, b, act)
+        ops.target_smooth(a, None if rng else noise, c1 if rng else None, 0.2, 0.5, o1[:, 3:])
+        ops.linear_smooth_fwd(x, w, b, act, None if rng else noise, c2 if rng else None, 0.2, 0.5, o2[:, 3:])
+        th.cuda.synchronize()
+        assert th.equal(o1, o2) and th.equal(c1, c2) and float(o2[:, :3].min()) == 7.0
+        assert int(c2[1]) == 12345 + (M if rng else 0) and float(o2[:, 3:].abs().max()) <= 1.0
+    with pytest.raises(Exception):
+        ops.linear_smooth_fwd(x, w, b, act, noise, ops.new_rng_ctl(1, "cuda"), 0.2, 0.5, th.empty(M, N, device="cuda"))  # two noise sources
+    with pytest.raises(Exception):
+        ops.linear_smooth_fwd(x[:, :16], w[:, :16].contiguous(), b, act, noise, None, 0.2, 0.5, th.empty(M, N, device="cuda"))  # k <= 32
+
+
 @pytest.mark.parametrize("G,M,N,K,act", [(0, 256, 256, 256, 1), (0, 256, 256, 4, 1), (0, 4096, 256, 256, 1), (2, 256, 256, 6, 1),
                                         (2, 256, 256, 256, 1), (0, 100, 400, 10, 1), (0, 37, 300, 400, 2), (2, 33, 30, 50, 0),
                                         (0, 1, 16, 7, 2), (0, 256, 4, 256, 0)])

@@ -246,3 +246,25 @@ def test_learn_with_the_gather_in_the_first_layer(algo, monkeypatch):
 
     for i, (x, y) in enumerate(zip(run(True), run(False))):
         assert th.equal(x, y), f"tensor {i} differs"
+
+
+def test_td3_learn_with_the_smoothing_in_the_target_actors_last_layer(monkeypatch):
+    """TD3 under hipGraph replay: target policy smoothing inside the target actor's last layer vs its own launch: identical weights,
+    Philox stream and ring after 40 iterations."""
+    from core.common import fused
+    from core.common.vec_env import CSTRVecEnv
+    from core.td3 import TD3
+
+    def run(flag):
+        monkeypatch.setattr(fused, "USE_SMOOTH_IN_LAST_LAYER", flag)
+        env = CSTRVecEnv(2048, device="cuda")
+        model = TD3("MlpPolicy", env, seed=13, device="cuda", learning_starts=2048 * 2, buffer_size=2048 * 6)
+        model.enable_graph_capture(True)
+        model.learn(total_timesteps=2048 * 40)
+        th.cuda.synchronize()
+        assert model.graph_status()["active"] and model.graph_status()["replays"] > 20
+        flat = th.cat([p.detach().reshape(-1) for p in model.policy.parameters()])
+        return flat.clone(), model._device_rng().clone(), model.replay_buffer.rewards.clone()
+
+    for i, (x, y) in enumerate(zip(run(True), run(False))):
+        assert th.equal(x, y), f"tensor {i} differs"
