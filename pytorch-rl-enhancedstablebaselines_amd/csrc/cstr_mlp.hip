@@ -165,11 +165,12 @@ __device__ __forceinline__ float4 load_k4_clamped(const float *__restrict__ row,
 // WAVES > 1: split-K -- wave s takes the 16-wide K chunks s, s + WAVES, ... (all of its loads in flight at once: one L2
 // round trip for K = 256 with four waves) and the partial tiles meet in LDS.
 template <int ACT, bool VEC, int WAVES>
-__global__ __launch_bounds__(64 * WAVES) void linear_act_fwd_kernel(const float *__restrict__ x, const int64_t x_group_stride,
-                                                                    const int ldx, const float *__restrict__ w,
-                                                                    const float *__restrict__ bias, float *__restrict__ y,
-                                                                    const int M, const int N, const int K)
+__global__ __launch_bounds__(64 * WAVES) void linear_act_fwd_kernel(const float *__restrict__ x, const float *__restrict__ w,
+                                                                    const int64_t x_group_stride, const int ldx, const int M, const int N,
+                                                                    const int K, const float *__restrict__ bias, float *__restrict__ y)
 {
+    // argument order: what the operand addresses need comes first -- the first 14 dwords of a kernel's arguments arrive preloaded
+    // in SGPRs (Makefile: PRELOAD); a 15th (K, in the order x, stride, ldx, w, bias, y, M, N, K) cost a scalar load and its wait
     __shared__ f32x4 part[WAVES > 1 ? WAVES - 1 : 1][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, h = lane >> 4;
     const int n0 = blockIdx.x * 16, m0 = blockIdx.y * 16;
@@ -905,13 +906,13 @@ __global__ __launch_bounds__(256) void linear_smooth_fwd_kernel(const float *__r
 // row, not a matrix-matrix product. One wave per row: 16-byte loads of the latent row and of the 2A weight rows, xor-shuffle
 // reductions, then the sampling arithmetic of gaussian_head_fwd_kernel on the reduced values (computed redundantly by every
 // lane, stored by lane 0). params [B][2A] is written for the backward.
-__global__ __launch_bounds__(1024) void gaussian_head_gemm_fwd_kernel(const float *__restrict__ hid, const int ldh,
-                                                                     const float *__restrict__ w, const float *__restrict__ bias,
+__global__ __launch_bounds__(1024) void gaussian_head_gemm_fwd_kernel(const float *__restrict__ hid, const float *__restrict__ w,
+                                                                     const int ldh, const int K, const int64_t batch, const int act_dim,
+                                                                     const float *__restrict__ bias, uint64_t *__restrict__ rng_ctl,
                                                                      float *__restrict__ params, float *__restrict__ eps,
-                                                                     uint64_t *__restrict__ rng_ctl, float *__restrict__ action,
-                                                                     const int64_t action_stride, float *__restrict__ logp,
-                                                                     const int64_t batch, const int act_dim, const int K)
-{
+                                                                     float *__restrict__ action, const int64_t action_stride,
+                                                                     float *__restrict__ logp)
+{   // (argument order: the dot products' operands first -- see linear_act_fwd_kernel)
     const float half_log_2pi = 0.91893853320467274178f;
     const uint64_t seed = rng_ctl ? rng_ctl[0] : 0ull, base = rng_ctl ? rng_ctl[1] : 0ull;
     const int lane = threadIdx.x & 63;
@@ -2420,7 +2421,7 @@ extern "C" int cstr_linear_act_fwd_f32(const float *x, int64_t x_group_stride, i
     // one wave per tile when K fits one chunk batch of a single wave's first round trip or the grid is already large;
     // four-way split-K otherwise (K = 256 on 256 tiles: each wave's loads are one round trip)
     const bool split = k > 32 && (int64_t)grid.x * grid.y * grid.z <= 2048;
-#define LIN(A, V, W) linear_act_fwd_kernel<A, V, W><<<grid, 64 * W, 0, s>>>(x, x_group_stride, (int)ldx, w, bias, y, (int)m, (int)n, (int)k)
+#define LIN(A, V, W) linear_act_fwd_kernel<A, V, W><<<grid, 64 * W, 0, s>>>(x, w, x_group_stride, (int)ldx, (int)m, (int)n, (int)k, bias, y)
 #define LIN_ACT(V, W) do { if (act == 0) LIN(0, V, W); else if (act == 1) LIN(1, V, W); else LIN(2, V, W); } while (0)
     if (vec) { if (split) LIN_ACT(true, 4); else LIN_ACT(true, 1); }
     else { if (split) LIN_ACT(false, 4); else LIN_ACT(false, 1); }
@@ -2539,8 +2540,8 @@ extern "C" int cstr_gaussian_head_gemm_fwd_f32(const float *hidden, int64_t ldh,
     const int rows_per_wg = batch <= 1024 ? 4 : 16;
     const int64_t g = (batch + rows_per_wg - 1) / rows_per_wg;
     if (g > 0x7fffffff) return CSTR_E_UNSUPPORTED;
-    gaussian_head_gemm_fwd_kernel<<<(unsigned)g, 64 * rows_per_wg, 0, (hipStream_t)stream>>>(hidden, (int)ldh, w, bias, params, eps, rng_ctl, action,
-                                                                                action_stride, logp, batch, act_dim, (int)k);
+    gaussian_head_gemm_fwd_kernel<<<(unsigned)g, 64 * rows_per_wg, 0, (hipStream_t)stream>>>(hidden, w, (int)ldh, (int)k, batch, act_dim, bias, rng_ctl,
+                                                                                params, eps, action, action_stride, logp);
     return (int)hipGetLastError();
 }
 
