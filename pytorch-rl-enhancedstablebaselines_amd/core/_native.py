@@ -99,6 +99,12 @@ _lib: Optional[C.CDLL] = None
 def lib() -> C.CDLL:
     global _lib
     if _lib is None:
+        # PyTorch ships its own HIP runtime: it has to be the FIRST one loaded into the process. Loading this library (linked
+        # against /opt/rocm's libamdhip64) before `import torch` leaves two runtimes, and launches on torch's memory through the
+        # other one fail with "no ROCm-capable device is detected" (seen with `python __graft_entry__.py smoke`: build() loaded the
+        # library, then smoke() imported torch).
+        import torch  # noqa: F401
+
         if not os.path.exists(LIB_PATH):
             raise NativeError(
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
