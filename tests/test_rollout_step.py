@@ -158,8 +158,8 @@ def test_rollout_step_rejects_what_it_does_not_cover(ops):
         ops.rollout_step(w.env_obs, *w.w, 1, 0, 0, w.swz, w.rng_ctl, w.coef, "euler", w.ring, w.env_obs, w.step_count, 1, w.low, w.high)
 
 
-@pytest.mark.parametrize("algo", ["sac", "td3"])
-def test_learn_with_and_without_the_one_launch_rollout(algo, monkeypatch):
+@pytest.mark.parametrize("algo,obs_dim,integrator", [("sac", 4, "euler"), ("td3", 4, "euler"), ("sac", 8, "rk4")])
+def test_learn_with_and_without_the_one_launch_rollout(algo, obs_dim, integrator, monkeypatch):
     """learn() under hipGraph replay with the one-launch rollout and with the separate launches: identical weights, ring, sampler
     stream and env state after 40 iterations (the two forms draw the same numbers in the same order)."""
     from core.common import off_policy_algorithm as opa
@@ -169,7 +169,7 @@ def test_learn_with_and_without_the_one_launch_rollout(algo, monkeypatch):
 
     def run(fused_rollout):
         monkeypatch.setattr(opa, "FUSED_ROLLOUT", fused_rollout)
-        env = CSTRVecEnv(2048, device="cuda")
+        env = CSTRVecEnv(2048, obs_dim=obs_dim, integrator=integrator, device="cuda")
         model = (SAC if algo == "sac" else TD3)("MlpPolicy", env, seed=7, device="cuda", learning_starts=2048 * 2, buffer_size=2048 * 6)
         model.enable_graph_capture(True)
         model.learn(total_timesteps=2048 * 40)
