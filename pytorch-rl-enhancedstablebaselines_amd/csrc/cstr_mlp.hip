@@ -162,6 +162,23 @@ __device__ __forceinline__ float4 load_k4_clamped(const float *__restrict__ row,
     return v;
 }
 
+// Operand rows through BUFFER loads (VEC kernels): a 4-SGPR descriptor over the matrix + a 32-bit byte offset per lane. A quad outside
+// the matrix (row >= rows, or the offset the caller substitutes for k >= K) reads as zeros by the descriptor's range check -- no
+// branch around the load, no 64-bit address arithmetic per lane, no select on the loaded value. bytes < 2^30 (checked by the callers).
+constexpr int BUF_OOB = 0x40000000;
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t operand_rsrc(const float *base, const int64_t floats)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), 0, (int)(floats * 4), 0x00020000);
+}
+
+__device__ __forceinline__ float4 load_k4_buf(const __amdgpu_buffer_rsrc_t rsrc, const int row_byte, const int k, const int K)
+{
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, k < K ? row_byte + 4 * k : BUF_OOB, 0, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+
 // WAVES > 1: split-K -- wave s takes the 16-wide K chunks s, s + WAVES, ... (all of its loads in flight at once: one L2
 // round trip for K = 256 with four waves) and the partial tiles meet in LDS.
 template <int ACT, bool VEC, int WAVES>
@@ -178,6 +195,10 @@ __global__ __launch_bounds__(64 * WAVES) void linear_act_fwd_kernel(const float 
     const float *xr = x + g * x_group_stride + (int64_t)(m0 + r) * ldx;
     const float *wr = w + (g * N + n0 + r) * (int64_t)K;
     const bool row_ok = m0 + r < M, col_ok = n0 + r < N;
+    // VEC: buffer loads (rows >= M / N and k >= K read as zeros by the range check)
+    const __amdgpu_buffer_rsrc_t rx = operand_rsrc(x + g * x_group_stride, VEC ? (int64_t)(M - 1) * ldx + K : 0);
+    const __amdgpu_buffer_rsrc_t rw = operand_rsrc(w + g * N * (int64_t)K, VEC ? (int64_t)N * K : 0);
+    const int xo = 4 * (m0 + r) * ldx, wo = 4 * (n0 + r) * K;
     f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
     constexpr int UNROLL = 4;  // 8 vector loads in flight per lane
     for (int c0 = 16 * wave; c0 < K; c0 += 16 * WAVES * UNROLL) {
@@ -185,8 +206,8 @@ __global__ __launch_bounds__(64 * WAVES) void linear_act_fwd_kernel(const float 
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
             const int k = c0 + 16 * WAVES * u + 4 * h;
-            a[u] = load_k4<VEC>(xr, k, K, row_ok);
-            b[u] = load_k4<VEC>(wr, k, K, col_ok);
+            a[u] = VEC ? load_k4_buf(rx, xo, k, K) : load_k4<false>(xr, k, K, row_ok);
+            b[u] = VEC ? load_k4_buf(rw, wo, k, K) : load_k4<false>(wr, k, K, col_ok);
         }
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
@@ -342,6 +363,9 @@ __global__ __launch_bounds__(64 * WAVES) void linear_act_fwd_sets_kernel(const L
     const float *xr = st.x + (int64_t)(m0 + r) * st.ldx;
     const float *wr = st.w + (int64_t)(n0 + r) * K;
     const bool row_ok = m0 + r < M, col_ok = n0 + r < N;
+    const __amdgpu_buffer_rsrc_t rx = operand_rsrc(st.x, VEC ? (int64_t)(M - 1) * st.ldx + K : 0);  // VEC: see linear_act_fwd_kernel
+    const __amdgpu_buffer_rsrc_t rw = operand_rsrc(st.w, VEC ? (int64_t)N * K : 0);
+    const int xo = 4 * (m0 + r) * (int)st.ldx, wo = 4 * (n0 + r) * K;
     f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
     constexpr int UNROLL = 4;
     for (int c0 = 16 * wave; c0 < K; c0 += 16 * WAVES * UNROLL) {
@@ -349,8 +373,8 @@ __global__ __launch_bounds__(64 * WAVES) void linear_act_fwd_sets_kernel(const L
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
             const int k = c0 + 16 * WAVES * u + 4 * h;
-            a[u] = load_k4<VEC>(xr, k, K, row_ok);
-            b[u] = load_k4<VEC>(wr, k, K, col_ok);
+            a[u] = VEC ? load_k4_buf(rx, xo, k, K) : load_k4<false>(xr, k, K, row_ok);
+            b[u] = VEC ? load_k4_buf(rw, wo, k, K) : load_k4<false>(wr, k, K, col_ok);
         }
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
@@ -413,12 +437,25 @@ __global__ __launch_bounds__(64 * WAVES) void linear_bwd_input_kernel(const floa
     for (int gi = 0; gi < n_groups; ++gi) {
         const float *gzg = gz + (g0 + gi) * (int64_t)M * N, *wg = w + (g0 + gi) * (int64_t)N * K;
         const float *gr = gzg + (int64_t)(m0 + r) * N;
+        // VEC: buffer loads -- gz rows >= M and W rows n >= N read as zeros by the descriptors' range check (lanes of columns >= K
+        // may read other columns' values: they only feed output columns that are not stored)
+        const __amdgpu_buffer_rsrc_t rg = operand_rsrc(gzg, VEC ? (int64_t)M * N : 0), rwt = operand_rsrc(wg, VEC ? (int64_t)N * K : 0);
+        const int go = 4 * (m0 + r) * N;
         for (int c0 = 16 * wave; c0 < N; c0 += 16 * WAVES * UNROLL) {
             float4 a[UNROLL], b[UNROLL];
 #pragma unroll
             for (int u = 0; u < UNROLL; ++u) {
                 const int n = c0 + 16 * WAVES * u + 4 * h;
-                a[u] = load_k4<VEC>(gr, n, N, row_ok);
+                if (VEC) {
+                    a[u] = load_k4_buf(rg, go, n, N);
+                    const int wo = 4 * (n * K + col);
+                    b[u].x = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rwt, wo, 0, 0));
+                    b[u].y = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rwt, wo + 4 * K, 0, 0));
+                    b[u].z = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rwt, wo + 8 * K, 0, 0));
+                    b[u].w = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rwt, wo + 12 * K, 0, 0));
+                    continue;
+                }
+                a[u] = load_k4<false>(gr, n, N, row_ok);
                 const float *wn = wg + (int64_t)n * K + col;
                 b[u].x = (col_ok && n < N) ? wn[0] : 0.0f;
                 b[u].y = (col_ok && n + 1 < N) ? wn[K] : 0.0f;
@@ -465,7 +502,7 @@ __global__ __launch_bounds__(64 * WAVES) void linear_bwd_input_kernel(const floa
 // WAVES waves split the rows m; A = dz^T and B = x are both read as 64-byte row segments (lane r takes column n0 + r /
 // k0 + r of row 16c + 4h + e). The workgroups of the first k strip also add up the dz values they load anyway: db needs no
 // extra pass and, being reduced inside one workgroup in a fixed order, stays deterministic.
-template <int WAVES>
+template <int WAVES, bool BUF = false>
 __device__ __forceinline__ void linear_bwd_weight_tile(const float *__restrict__ dz, const float *__restrict__ x, const int ldx,
                                                        float *__restrict__ dw, float *__restrict__ db, const int M, const int N,
                                                        const int K, const int64_t g)
@@ -479,11 +516,26 @@ __device__ __forceinline__ void linear_bwd_weight_tile(const float *__restrict__
     f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
     float colsum = 0.0f;
     constexpr int UNROLL = 4;
+    // BUF: buffer loads -- rows m >= M read as zeros by the descriptors' range check, no branch per element (lanes of rows n >= N /
+    // columns k >= K may read neighbouring values: they only feed outputs that are not stored and column sums that are not used)
+    const __amdgpu_buffer_rsrc_t rdz = operand_rsrc(dz, BUF ? (int64_t)M * N : 0), rxx = operand_rsrc(x, BUF ? (int64_t)(M - 1) * ldx + K : 0);
     for (int c0 = 16 * wave; c0 < M; c0 += 16 * WAVES * UNROLL) {
         float4 a[UNROLL], b[UNROLL];
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
             const int m = c0 + 16 * WAVES * u + 4 * h;
+            if (BUF) {
+                const int ao = 4 * (m * N + n0 + r), bo = 4 * (m * ldx + k0 + r);
+                a[u].x = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rdz, ao, 0, 0));
+                a[u].y = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rdz, ao + 4 * N, 0, 0));
+                a[u].z = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rdz, ao + 8 * N, 0, 0));
+                a[u].w = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rdz, ao + 12 * N, 0, 0));
+                b[u].x = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rxx, bo, 0, 0));
+                b[u].y = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rxx, bo + 4 * ldx, 0, 0));
+                b[u].z = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rxx, bo + 8 * ldx, 0, 0));
+                b[u].w = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rxx, bo + 12 * ldx, 0, 0));
+                continue;
+            }
             const float *dr = dz + (int64_t)m * N + n0 + r;
             const float *xr = x + (int64_t)m * ldx + k0 + r;
             a[u].x = (n_ok && m < M) ? dr[0] : 0.0f;
@@ -528,26 +580,26 @@ __device__ __forceinline__ void linear_bwd_weight_tile(const float *__restrict__
     }
 }
 
-template <int WAVES>
+template <int WAVES, bool BUF>
 __global__ __launch_bounds__(64 * WAVES) void linear_bwd_weight_kernel(const float *__restrict__ dz, const float *__restrict__ x,
                                                                        const int64_t x_group_stride, const int ldx,
                                                                        float *__restrict__ dw, float *__restrict__ db, const int M,
                                                                        const int N, const int K)
 {
     const int64_t g = blockIdx.z;
-    linear_bwd_weight_tile<WAVES>(dz + g * (int64_t)M * N, x + g * x_group_stride, ldx, dw, db, M, N, K, g);
+    linear_bwd_weight_tile<WAVES, BUF>(dz + g * (int64_t)M * N, x + g * x_group_stride, ldx, dw, db, M, N, K, g);
 }
 
 // Several Linears' weight + bias gradients in ONE launch (an MLP's layers after its backward chain has produced every dz:
 // the parameter gradients are leaves nobody waits for): blockIdx.z selects the operand set, every set has its own shape.
 struct WgradSets { cstr_wgrad_set_t s[CSTR_MAX_LINEAR_SETS]; };
 
-template <int WAVES>
+template <int WAVES, bool BUF>
 __global__ __launch_bounds__(64 * WAVES) void linear_bwd_weight_sets_kernel(const WgradSets sets)
 {
     const cstr_wgrad_set_t &q = sets.s[blockIdx.z];
     if ((int64_t)blockIdx.x * 16 >= q.k || (int64_t)blockIdx.y * 16 >= q.n) return;  // the grid covers the largest set
-    linear_bwd_weight_tile<WAVES>(q.dz, q.x, (int)q.ldx, q.dw, q.db, (int)q.m, (int)q.n, (int)q.k, 0);
+    linear_bwd_weight_tile<WAVES, BUF>(q.dz, q.x, (int)q.ldx, q.dw, q.db, (int)q.m, (int)q.n, (int)q.k, 0);
 }
 
 // ---- last hidden layer + scalar head of a Q network ------------------------------------------------------------
@@ -2416,7 +2468,9 @@ extern "C" int cstr_linear_act_fwd_f32(const float *x, int64_t x_group_stride, i
     if (!x || !w || !bias || !y || groups <= 0 || m <= 0 || n <= 0 || k <= 0 || ldx < k || x_group_stride < 0) return CSTR_E_BADARG;
     if (act < 0 || act > 2 || m > 0x7fffff || n > 0x7fffff || k > 0x7fffff || groups > 65535 || (m + 15) / 16 > 65535) return CSTR_E_UNSUPPORTED;
     const dim3 grid((unsigned)((n + 15) / 16), (unsigned)((m + 15) / 16), (unsigned)groups);
-    const bool vec = (k & 3) == 0 && (ldx & 3) == 0 && (x_group_stride & 3) == 0 && aligned16(x) && aligned16(w);
+    // (the vector form reads its operands through buffer descriptors with 32-bit byte offsets: matrices below 1 GiB)
+    const bool vec = (k & 3) == 0 && (ldx & 3) == 0 && (x_group_stride & 3) == 0 && aligned16(x) && aligned16(w) && m * ldx < (1 << 28) &&
+                     n * k < (1 << 28);
     hipStream_t s = (hipStream_t)stream;
     // one wave per tile when K fits one chunk batch of a single wave's first round trip or the grid is already large;
     // four-way split-K otherwise (K = 256 on 256 tiles: each wave's loads are one round trip)
@@ -2483,7 +2537,7 @@ extern "C" int cstr_linear_bwd_input_f32(const float *gz, const float *w, const 
     if (act < 0 || act > 2 || m > 0x7fffff || n > 0x7fffff || k > 0x7fffff || groups > 65535 || (m + 15) / 16 > 65535) return CSTR_E_UNSUPPORTED;
     const dim3 grid((unsigned)((k + 15) / 16), (unsigned)((m + 15) / 16), (unsigned)(sum_groups ? 1 : groups));
     const int n_sum = sum_groups ? (int)groups : 0;
-    const bool vec = (n & 3) == 0 && aligned16(gz);
+    const bool vec = (n & 3) == 0 && aligned16(gz) && m * n < (1 << 28) && n * k < (1 << 28);  // (buffer descriptors: below 1 GiB)
     hipStream_t s = (hipStream_t)stream;
 #define LBI(A, V, W) linear_bwd_input_kernel<A, V, W><<<grid, 64 * W, 0, s>>>(gz, w, y, dz, (int)m, (int)n, (int)k, n_sum)
 #define LBI_ACT(V, W) do { if (act == 0) LBI(0, V, W); else if (act == 1) LBI(1, V, W); else LBI(2, V, W); } while (0)
@@ -2501,8 +2555,11 @@ extern "C" int cstr_linear_bwd_weight_f32(const float *dz, const float *x, int64
     if (m > 0x7fffff || n > 0x7fffff || k > 0x7fffff || groups > 65535 || (n + 15) / 16 > 65535) return CSTR_E_UNSUPPORTED;
     const dim3 grid((unsigned)((k + 15) / 16), (unsigned)((n + 15) / 16), (unsigned)groups);
     hipStream_t s = (hipStream_t)stream;
-    if (m > 32) linear_bwd_weight_kernel<4><<<grid, 256, 0, s>>>(dz, x, x_group_stride, (int)ldx, dw, db, (int)m, (int)n, (int)k);
-    else linear_bwd_weight_kernel<1><<<grid, 64, 0, s>>>(dz, x, x_group_stride, (int)ldx, dw, db, (int)m, (int)n, (int)k);
+    const bool buf = m * n < (1 << 28) && m * ldx < (1 << 28);  // buffer descriptors with 32-bit byte offsets: below 1 GiB
+#define LBW(W, B) linear_bwd_weight_kernel<W, B><<<grid, 64 * W, 0, s>>>(dz, x, x_group_stride, (int)ldx, dw, db, (int)m, (int)n, (int)k)
+    if (m > 32) { if (buf) LBW(4, true); else LBW(4, false); }
+    else { if (buf) LBW(1, true); else LBW(1, false); }
+#undef LBW
     return (int)hipGetLastError();
 }
 
@@ -2523,8 +2580,10 @@ extern "C" int cstr_linear_bwd_weight_sets_f32(const cstr_wgrad_set_t *sets, int
     }
     const dim3 grid((unsigned)kt, (unsigned)nt, (unsigned)n_sets);
     hipStream_t s = (hipStream_t)stream;
-    if (m_min > 32) linear_bwd_weight_sets_kernel<4><<<grid, 256, 0, s>>>(t);
-    else linear_bwd_weight_sets_kernel<1><<<grid, 64, 0, s>>>(t);
+    bool buf = true;  // operands through buffer descriptors with 32-bit byte offsets: every matrix below 1 GiB
+    for (int i = 0; i < n_sets; ++i) buf = buf && sets[i].m * sets[i].n < (1 << 28) && sets[i].m * sets[i].ldx < (1 << 28);
+    if (m_min > 32) { if (buf) linear_bwd_weight_sets_kernel<4, true><<<grid, 256, 0, s>>>(t); else linear_bwd_weight_sets_kernel<4, false><<<grid, 256, 0, s>>>(t); }
+    else { if (buf) linear_bwd_weight_sets_kernel<1, true><<<grid, 64, 0, s>>>(t); else linear_bwd_weight_sets_kernel<1, false><<<grid, 64, 0, s>>>(t); }
     return (int)hipGetLastError();
 }
 
@@ -2556,7 +2615,7 @@ extern "C" int cstr_linear_act_fwd_sets_f32(const cstr_linear_set_t *sets, int n
     for (int i = 0; i < n_sets; ++i) {
         const cstr_linear_set_t &q = sets[i];
         if (!q.x || !q.w || !q.bias || !q.y || q.ldx < k || q.ldy < n) return CSTR_E_BADARG;
-        vec = vec && (q.ldx & 3) == 0 && aligned16(q.x) && aligned16(q.w);
+        vec = vec && (q.ldx & 3) == 0 && aligned16(q.x) && aligned16(q.w) && m * q.ldx < (1 << 28) && n * k < (1 << 28);
         t.s[i] = q;
     }
     const dim3 grid((unsigned)((n + 15) / 16), (unsigned)((m + 15) / 16), (unsigned)n_sets);
