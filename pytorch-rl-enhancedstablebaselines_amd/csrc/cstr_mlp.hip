@@ -173,6 +173,17 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t operand_rsrc(const float *base
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), 0, (int)(floats * 4), 0x00020000);
 }
 
+// rows whose length is not a multiple of 4 floats (the critics' first layer: K = obs_dim + act_dim = 6): four dword loads
+__device__ __forceinline__ float4 load_k4_buf_scalar(const __amdgpu_buffer_rsrc_t rsrc, const int row_byte, const int k, const int K)
+{
+    float4 v;
+    v.x = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, k < K ? row_byte + 4 * k : BUF_OOB, 0, 0));
+    v.y = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, k + 1 < K ? row_byte + 4 * k + 4 : BUF_OOB, 0, 0));
+    v.z = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, k + 2 < K ? row_byte + 4 * k + 8 : BUF_OOB, 0, 0));
+    v.w = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, k + 3 < K ? row_byte + 4 * k + 12 : BUF_OOB, 0, 0));
+    return v;
+}
+
 __device__ __forceinline__ float4 load_k4_buf(const __amdgpu_buffer_rsrc_t rsrc, const int row_byte, const int k, const int K)
 {
     const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, k < K ? row_byte + 4 * k : BUF_OOB, 0, 0);
@@ -181,7 +192,7 @@ __device__ __forceinline__ float4 load_k4_buf(const __amdgpu_buffer_rsrc_t rsrc,
 
 // WAVES > 1: split-K -- wave s takes the 16-wide K chunks s, s + WAVES, ... (all of its loads in flight at once: one L2
 // round trip for K = 256 with four waves) and the partial tiles meet in LDS.
-template <int ACT, bool VEC, int WAVES>
+template <int ACT, bool VEC, int WAVES, bool BUF = true>
 __global__ __launch_bounds__(64 * WAVES) void linear_act_fwd_kernel(const float *__restrict__ x, const float *__restrict__ w,
                                                                     const int64_t x_group_stride, const int ldx, const int M, const int N,
                                                                     const int K, const float *__restrict__ bias, float *__restrict__ y)
@@ -195,9 +206,9 @@ __global__ __launch_bounds__(64 * WAVES) void linear_act_fwd_kernel(const float 
     const float *xr = x + g * x_group_stride + (int64_t)(m0 + r) * ldx;
     const float *wr = w + (g * N + n0 + r) * (int64_t)K;
     const bool row_ok = m0 + r < M, col_ok = n0 + r < N;
-    // VEC: buffer loads (rows >= M / N and k >= K read as zeros by the range check)
-    const __amdgpu_buffer_rsrc_t rx = operand_rsrc(x + g * x_group_stride, VEC ? (int64_t)(M - 1) * ldx + K : 0);
-    const __amdgpu_buffer_rsrc_t rw = operand_rsrc(w + g * N * (int64_t)K, VEC ? (int64_t)N * K : 0);
+    // BUF: buffer loads (rows >= M / N and k >= K read as zeros by the range check); matrices of 1 GiB and more: plain loads
+    const __amdgpu_buffer_rsrc_t rx = operand_rsrc(x + g * x_group_stride, (int64_t)(M - 1) * ldx + K);
+    const __amdgpu_buffer_rsrc_t rw = operand_rsrc(w + g * N * (int64_t)K, (int64_t)N * K);
     const int xo = 4 * (m0 + r) * ldx, wo = 4 * (n0 + r) * K;
     f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
     constexpr int UNROLL = 4;  // 8 vector loads in flight per lane
@@ -206,8 +217,8 @@ __global__ __launch_bounds__(64 * WAVES) void linear_act_fwd_kernel(const float 
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
             const int k = c0 + 16 * WAVES * u + 4 * h;
-            a[u] = VEC ? load_k4_buf(rx, xo, k, K) : load_k4<false>(xr, k, K, row_ok);
-            b[u] = VEC ? load_k4_buf(rw, wo, k, K) : load_k4<false>(wr, k, K, col_ok);
+            a[u] = BUF ? (VEC ? load_k4_buf(rx, xo, k, K) : load_k4_buf_scalar(rx, xo, k, K)) : load_k4<VEC>(xr, k, K, row_ok);
+            b[u] = BUF ? (VEC ? load_k4_buf(rw, wo, k, K) : load_k4_buf_scalar(rw, wo, k, K)) : load_k4<VEC>(wr, k, K, col_ok);
         }
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
@@ -353,7 +364,7 @@ __global__ __launch_bounds__(64) void gather_linear_act_fwd_kernel(const GatherA
 // its own input, weight, bias and output; the output may be a column block of a wider row (the joint action).
 struct LinearSets { cstr_linear_set_t s[CSTR_MAX_LINEAR_SETS]; };
 
-template <int ACT, bool VEC, int WAVES>
+template <int ACT, bool VEC, int WAVES, bool BUF = true>
 __global__ __launch_bounds__(64 * WAVES) void linear_act_fwd_sets_kernel(const LinearSets sets, const int M, const int N, const int K)
 {
     __shared__ f32x4 part[WAVES > 1 ? WAVES - 1 : 1][64];
@@ -363,8 +374,8 @@ __global__ __launch_bounds__(64 * WAVES) void linear_act_fwd_sets_kernel(const L
     const float *xr = st.x + (int64_t)(m0 + r) * st.ldx;
     const float *wr = st.w + (int64_t)(n0 + r) * K;
     const bool row_ok = m0 + r < M, col_ok = n0 + r < N;
-    const __amdgpu_buffer_rsrc_t rx = operand_rsrc(st.x, VEC ? (int64_t)(M - 1) * st.ldx + K : 0);  // VEC: see linear_act_fwd_kernel
-    const __amdgpu_buffer_rsrc_t rw = operand_rsrc(st.w, VEC ? (int64_t)N * K : 0);
+    const __amdgpu_buffer_rsrc_t rx = operand_rsrc(st.x, (int64_t)(M - 1) * st.ldx + K);  // BUF: see linear_act_fwd_kernel
+    const __amdgpu_buffer_rsrc_t rw = operand_rsrc(st.w, (int64_t)N * K);
     const int xo = 4 * (m0 + r) * (int)st.ldx, wo = 4 * (n0 + r) * K;
     f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
     constexpr int UNROLL = 4;
@@ -373,8 +384,8 @@ __global__ __launch_bounds__(64 * WAVES) void linear_act_fwd_sets_kernel(const L
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
             const int k = c0 + 16 * WAVES * u + 4 * h;
-            a[u] = VEC ? load_k4_buf(rx, xo, k, K) : load_k4<false>(xr, k, K, row_ok);
-            b[u] = VEC ? load_k4_buf(rw, wo, k, K) : load_k4<false>(wr, k, K, col_ok);
+            a[u] = BUF ? (VEC ? load_k4_buf(rx, xo, k, K) : load_k4_buf_scalar(rx, xo, k, K)) : load_k4<VEC>(xr, k, K, row_ok);
+            b[u] = BUF ? (VEC ? load_k4_buf(rw, wo, k, K) : load_k4_buf_scalar(rw, wo, k, K)) : load_k4<VEC>(wr, k, K, col_ok);
         }
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
@@ -2468,14 +2479,14 @@ extern "C" int cstr_linear_act_fwd_f32(const float *x, int64_t x_group_stride, i
     if (!x || !w || !bias || !y || groups <= 0 || m <= 0 || n <= 0 || k <= 0 || ldx < k || x_group_stride < 0) return CSTR_E_BADARG;
     if (act < 0 || act > 2 || m > 0x7fffff || n > 0x7fffff || k > 0x7fffff || groups > 65535 || (m + 15) / 16 > 65535) return CSTR_E_UNSUPPORTED;
     const dim3 grid((unsigned)((n + 15) / 16), (unsigned)((m + 15) / 16), (unsigned)groups);
-    // (the vector form reads its operands through buffer descriptors with 32-bit byte offsets: matrices below 1 GiB)
-    const bool vec = (k & 3) == 0 && (ldx & 3) == 0 && (x_group_stride & 3) == 0 && aligned16(x) && aligned16(w) && m * ldx < (1 << 28) &&
-                     n * k < (1 << 28);
+    const bool vec = (k & 3) == 0 && (ldx & 3) == 0 && (x_group_stride & 3) == 0 && aligned16(x) && aligned16(w);
+    const bool buf = m * ldx < (1 << 28) && n * k < (1 << 28);  // operands through buffer descriptors with 32-bit byte offsets: below 1 GiB
     hipStream_t s = (hipStream_t)stream;
     // one wave per tile when K fits one chunk batch of a single wave's first round trip or the grid is already large;
     // four-way split-K otherwise (K = 256 on 256 tiles: each wave's loads are one round trip)
     const bool split = k > 32 && (int64_t)grid.x * grid.y * grid.z <= 2048;
-#define LIN(A, V, W) linear_act_fwd_kernel<A, V, W><<<grid, 64 * W, 0, s>>>(x, w, x_group_stride, (int)ldx, (int)m, (int)n, (int)k, bias, y)
+#define LIN(A, V, W) do { if (buf) linear_act_fwd_kernel<A, V, W, true><<<grid, 64 * W, 0, s>>>(x, w, x_group_stride, (int)ldx, (int)m, (int)n, (int)k, bias, y); \
+                          else linear_act_fwd_kernel<A, V, W, false><<<grid, 64 * W, 0, s>>>(x, w, x_group_stride, (int)ldx, (int)m, (int)n, (int)k, bias, y); } while (0)
 #define LIN_ACT(V, W) do { if (act == 0) LIN(0, V, W); else if (act == 1) LIN(1, V, W); else LIN(2, V, W); } while (0)
     if (vec) { if (split) LIN_ACT(true, 4); else LIN_ACT(true, 1); }
     else { if (split) LIN_ACT(false, 4); else LIN_ACT(false, 1); }
@@ -2611,11 +2622,12 @@ extern "C" int cstr_linear_act_fwd_sets_f32(const cstr_linear_set_t *sets, int n
     if (n_sets > CSTR_MAX_LINEAR_SETS || act < 0 || act > 2 || m > 0x7fffff || n > 0x7fffff || k > 0x7fffff || (m + 15) / 16 > 65535)
         return CSTR_E_UNSUPPORTED;
     LinearSets t;
-    bool vec = (k & 3) == 0;
+    bool vec = (k & 3) == 0, buf = true;  // buf: operands through buffer descriptors with 32-bit byte offsets (below 1 GiB)
     for (int i = 0; i < n_sets; ++i) {
         const cstr_linear_set_t &q = sets[i];
         if (!q.x || !q.w || !q.bias || !q.y || q.ldx < k || q.ldy < n) return CSTR_E_BADARG;
-        vec = vec && (q.ldx & 3) == 0 && aligned16(q.x) && aligned16(q.w) && m * q.ldx < (1 << 28) && n * k < (1 << 28);
+        vec = vec && (q.ldx & 3) == 0 && aligned16(q.x) && aligned16(q.w);
+        buf = buf && m * q.ldx < (1 << 28) && n * k < (1 << 28);
         t.s[i] = q;
     }
     const dim3 grid((unsigned)((n + 15) / 16), (unsigned)((m + 15) / 16), (unsigned)n_sets);
@@ -2623,7 +2635,8 @@ extern "C" int cstr_linear_act_fwd_sets_f32(const cstr_linear_set_t *sets, int n
     // independent four-set chains (fused.twin_pair_forward_many) sums in the same order as one launch per chain
     const bool split = k > 32 && (int64_t)grid.x * grid.y * (grid.z < 4 ? grid.z : 4) <= 2048;
     hipStream_t s = (hipStream_t)stream;
-#define LIN(A, V, W) linear_act_fwd_sets_kernel<A, V, W><<<grid, 64 * W, 0, s>>>(t, (int)m, (int)n, (int)k)
+#define LIN(A, V, W) do { if (buf) linear_act_fwd_sets_kernel<A, V, W, true><<<grid, 64 * W, 0, s>>>(t, (int)m, (int)n, (int)k); \
+                          else linear_act_fwd_sets_kernel<A, V, W, false><<<grid, 64 * W, 0, s>>>(t, (int)m, (int)n, (int)k); } while (0)
 #define LIN_ACT(V, W) do { if (act == 0) LIN(0, V, W); else if (act == 1) LIN(1, V, W); else LIN(2, V, W); } while (0)
     if (vec) { if (split) LIN_ACT(true, 4); else LIN_ACT(true, 1); }
     else { if (split) LIN_ACT(false, 4); else LIN_ACT(false, 1); }
