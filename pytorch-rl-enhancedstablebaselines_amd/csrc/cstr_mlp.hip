@@ -426,7 +426,7 @@ __global__ __launch_bounds__(64 * WAVES) void linear_act_fwd_sets_kernel(const L
 // the reduction over n (A = gz rows as 16-byte vectors along n, B = W[n][k] read as 64-byte row segments), partial tiles
 // meet in LDS. (The lower layer's bias gradient = column sums of dz over ALL row tiles stays a separate launch: folding it
 // in needs a cross-workgroup hand-over -- agent-scope fences cost more than the launch they would save.)
-template <int ACT, bool VEC, int WAVES>
+template <int ACT, bool VEC, int WAVES, bool BUF = true>
 __global__ __launch_bounds__(64 * WAVES) void linear_bwd_input_kernel(const float *__restrict__ gz, const float *__restrict__ w,
                                                                       const float *__restrict__ y, float *__restrict__ dz,
                                                                       const int M, const int N, const int K, const int n_sum)
@@ -448,17 +448,17 @@ __global__ __launch_bounds__(64 * WAVES) void linear_bwd_input_kernel(const floa
     for (int gi = 0; gi < n_groups; ++gi) {
         const float *gzg = gz + (g0 + gi) * (int64_t)M * N, *wg = w + (g0 + gi) * (int64_t)N * K;
         const float *gr = gzg + (int64_t)(m0 + r) * N;
-        // VEC: buffer loads -- gz rows >= M and W rows n >= N read as zeros by the descriptors' range check (lanes of columns >= K
+        // BUF: buffer loads -- gz rows >= M and W rows n >= N read as zeros by the descriptors' range check (lanes of columns >= K
         // may read other columns' values: they only feed output columns that are not stored)
-        const __amdgpu_buffer_rsrc_t rg = operand_rsrc(gzg, VEC ? (int64_t)M * N : 0), rwt = operand_rsrc(wg, VEC ? (int64_t)N * K : 0);
+        const __amdgpu_buffer_rsrc_t rg = operand_rsrc(gzg, BUF ? (int64_t)M * N : 0), rwt = operand_rsrc(wg, BUF ? (int64_t)N * K : 0);
         const int go = 4 * (m0 + r) * N;
         for (int c0 = 16 * wave; c0 < N; c0 += 16 * WAVES * UNROLL) {
             float4 a[UNROLL], b[UNROLL];
 #pragma unroll
             for (int u = 0; u < UNROLL; ++u) {
                 const int n = c0 + 16 * WAVES * u + 4 * h;
-                if (VEC) {
-                    a[u] = load_k4_buf(rg, go, n, N);
+                if (BUF) {
+                    a[u] = VEC ? load_k4_buf(rg, go, n, N) : load_k4_buf_scalar(rg, go, n, N);
                     const int wo = 4 * (n * K + col);
                     b[u].x = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rwt, wo, 0, 0));
                     b[u].y = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rwt, wo + 4 * K, 0, 0));
@@ -466,7 +466,7 @@ __global__ __launch_bounds__(64 * WAVES) void linear_bwd_input_kernel(const floa
                     b[u].w = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rwt, wo + 12 * K, 0, 0));
                     continue;
                 }
-                a[u] = load_k4<false>(gr, n, N, row_ok);
+                a[u] = load_k4<VEC>(gr, n, N, row_ok);
                 const float *wn = wg + (int64_t)n * K + col;
                 b[u].x = (col_ok && n < N) ? wn[0] : 0.0f;
                 b[u].y = (col_ok && n + 1 < N) ? wn[K] : 0.0f;
@@ -2548,9 +2548,11 @@ extern "C" int cstr_linear_bwd_input_f32(const float *gz, const float *w, const 
     if (act < 0 || act > 2 || m > 0x7fffff || n > 0x7fffff || k > 0x7fffff || groups > 65535 || (m + 15) / 16 > 65535) return CSTR_E_UNSUPPORTED;
     const dim3 grid((unsigned)((k + 15) / 16), (unsigned)((m + 15) / 16), (unsigned)(sum_groups ? 1 : groups));
     const int n_sum = sum_groups ? (int)groups : 0;
-    const bool vec = (n & 3) == 0 && aligned16(gz) && m * n < (1 << 28) && n * k < (1 << 28);  // (buffer descriptors: below 1 GiB)
+    const bool vec = (n & 3) == 0 && aligned16(gz);
+    const bool buf = m * n < (1 << 28) && n * k < (1 << 28);  // operands through buffer descriptors with 32-bit byte offsets: below 1 GiB
     hipStream_t s = (hipStream_t)stream;
-#define LBI(A, V, W) linear_bwd_input_kernel<A, V, W><<<grid, 64 * W, 0, s>>>(gz, w, y, dz, (int)m, (int)n, (int)k, n_sum)
+#define LBI(A, V, W) do { if (buf) linear_bwd_input_kernel<A, V, W, true><<<grid, 64 * W, 0, s>>>(gz, w, y, dz, (int)m, (int)n, (int)k, n_sum); \
+                          else linear_bwd_input_kernel<A, V, W, false><<<grid, 64 * W, 0, s>>>(gz, w, y, dz, (int)m, (int)n, (int)k, n_sum); } while (0)
 #define LBI_ACT(V, W) do { if (act == 0) LBI(0, V, W); else if (act == 1) LBI(1, V, W); else LBI(2, V, W); } while (0)
     if (n > 32) { if (vec) LBI_ACT(true, 4); else LBI_ACT(false, 4); }
     else { if (vec) LBI_ACT(true, 1); else LBI_ACT(false, 1); }
