@@ -455,7 +455,7 @@ def main():
     total = (args.warmup + args.steps) * N
     _, callback = model._setup_learn(total, NoopCallback(), True, "bench", False)
     use_graph = bool(args.graph)  # world > 1: graph segments with the RCCL all-reduces between them
-    model.enable_graph_capture(use_graph, unroll=args.graph_unroll if world == 1 else 1)
+    model.enable_graph_capture(use_graph, unroll=args.graph_unroll)  # world > 1: multi-iteration graphs only with in-graph collectives
     if os.environ.get("CSTR_BENCH_BREAK_CAPTURE") == "1":  # test knob (tests/test_bench_contract.py): the recorded body raises
         body = model._graph_body
 
@@ -497,7 +497,8 @@ def main():
     if use_graph:
         # every graph the timed region can need: `unroll`-iteration graphs (one per policy-delay phase) and, when K is not a multiple
         # of the unroll factor, the unroll / 2, unroll / 4, ... 1-iteration ones for the tail -- run both call shapes until a whole call replays
-        u = model.graph_unroll if world == 1 else 1
+        dp = world > 1 or getattr(model, "_force_segment_boundaries", False)
+        u = model.graph_unroll if (not dp or model._collectives_in_graph()) else 1
         # (an odd call length flips the policy-delay phase a call starts in: two clean calls in a row cover both)
         for k in ([2 * u] if args.steps % u == 0 else [2 * u, 2 * u + args.steps % u]):
             clean = 0
@@ -565,7 +566,7 @@ def main():
                                              "speedup": round(value / REFERENCE_PYTHON_ENV_STEPS_PER_S, 1)},
         "config": {"workload": f"{args.algo.upper()} MlpPolicy class defaults on {N} vectorised two-series CSTR envs per GPU "
                                f"(obs {args.obs_dim}/act 2, {args.integrator}, batch 256, ring 244x{N}, 1 gradient step per vec-step)",
-                   "n_envs_per_gpu": N, "global_batch": B * world, "parallelism": f"dp{world}", "hip_graph": bool(st1["active"]), "hip_graph_requested": use_graph, "hip_graph_segments": st1["segments_per_graph"], "graph_unroll": model.graph_unroll if use_graph else 0, "blas": args.blas,
+                   "n_envs_per_gpu": N, "global_batch": B * world, "parallelism": f"dp{world}", "hip_graph": bool(st1["active"]), "hip_graph_requested": use_graph, "hip_graph_segments": st1["segments_per_graph"], "graph_unroll": (model.graph_unroll if (world == 1 and not getattr(model, "_force_segment_boundaries", False)) or st1["graph_collectives"] == "in-graph" else 1) if use_graph else 0, "blas": args.blas,
                    "n_updates": model._n_updates},
     }
     if rank == 0:

@@ -206,7 +206,8 @@ class OffPolicyAlgorithm(BaseAlgorithm):
         episodic train_freq).
 
         `unroll` (default 1, env CSTR_GRAPH_UNROLL): consecutive iterations recorded into ONE graph -- the ~10 us the GPU
-        idles between two graph launches is paid once per `unroll` iterations. Used on one GPU with a constant learning
+        idles between two graph launches is paid once per `unroll` iterations. Used on one GPU, and data-parallel when the
+        all-reduces are recorded into the graph (every rank replays the same graphs in the same order), with a constant learning
         rate while at least `unroll` iterations remain; the tail of a run replays graphs of unroll / 2, unroll / 4, ... 1 iterations."""
         self._graph_enabled = enabled
         self._graph, self._graph_error = None, None
@@ -277,8 +278,10 @@ class OffPolicyAlgorithm(BaseAlgorithm):
 
     def _graph_unroll_now(self) -> int:
         u = getattr(self, "graph_unroll", 1)
-        if u <= 1 or self.world_size > 1 or getattr(self, "_force_segment_boundaries", False) or not isinstance(self.learning_rate, float):
+        if u <= 1 or not isinstance(self.learning_rate, float):
             return 1
+        if (self.world_size > 1 or getattr(self, "_force_segment_boundaries", False)) and not self._collectives_in_graph():
+            return 1  # data-parallel with the collectives BETWEEN graph segments: one iteration per replay list
         remaining = (self._total_timesteps - self.num_timesteps) // self.n_envs
         while u > 1 and remaining < u:  # the tail of a run: the largest of u, u / 2, u / 4, ... that still fits
             u //= 2
