@@ -86,16 +86,18 @@ def _rccl_worker(rank, port, out_dir):
     du.is_distributed = lambda: True  # a world of one rank still issues its all-reduces (through RCCL)
     assert du.graph_collectives_ok("cuda:0")  # the start-up trial: capture + replay of an RCCL all-reduce
     N, B, iters, out = 64, 32, 14, {}
-    for mode in ("eager", "segmented", "in_graph"):
+    for mode in ("eager", "segmented", "in_graph", "in_graph_x4"):
         env = CSTRVecEnv(N, device="cuda:0")
         model = SAC("MlpPolicy", env, seed=5, batch_size=B, buffer_size=N * 8, learning_starts=100, device="cuda:0",
                     policy_kwargs=dict(net_arch=[32, 32]))
         model._force_segment_boundaries = True  # the data-parallel launch structure
-        model._graph_collectives = mode == "in_graph"
-        model.enable_graph_capture(mode != "eager")
+        model._graph_collectives = mode.startswith("in_graph")
+        model.enable_graph_capture(mode != "eager", unroll=4 if mode == "in_graph_x4" else 1)  # x4: four iterations (8 all-reduces) per graph
         model.learn(N * iters)
         th.cuda.synchronize()
-        if mode != "eager":
+        if mode == "in_graph_x4":
+            assert any(key[-1] == 4 for key in model._graph) and all(len(segs) == 1 for segs in model._graph.values())
+        elif mode != "eager":
             (segs,) = model._graph.values()
             assert sum(isinstance(s, th.cuda.CUDAGraph) for s in segs) == (1 if mode == "in_graph" else 3)
         out[mode] = dict(actor=model.policy.actor_arena.flat.cpu(), critic=model.policy.critic_arena.flat.cpu(),
@@ -106,11 +108,11 @@ def _rccl_worker(rank, port, out_dir):
 
 def test_collectives_inside_the_graph_match_segmented_and_eager(tmp_path):
     """The N > 1 launch structure in an RCCL world of ONE rank (all this box can hold): the all-reduces recorded INTO the
-    iteration graph (after the start-up trial passed) train bit-identically to collectives between graph segments and to
-    the eager loop."""
+    iteration graph (after the start-up trial passed; also four iterations = eight all-reduces per graph) train bit-identically to
+    collectives between graph segments and to the eager loop."""
     mp.spawn(_rccl_worker, args=(_free_port(), str(tmp_path)), nprocs=1, join=True)
     out = th.load(tmp_path / "rccl.pt")
-    for mode in ("segmented", "in_graph"):
+    for mode in ("segmented", "in_graph", "in_graph_x4"):
         assert out[mode]["n_updates"] == out["eager"]["n_updates"] == 13
         for k in ("actor", "critic", "alpha", "obs"):
             assert th.equal(out[mode][k], out["eager"][k]), (mode, k)
