@@ -1098,6 +1098,20 @@ __global__ __launch_bounds__(256) void gaussian_head_bwd_input_kernel(const floa
     __shared__ float gp[HEAD_BWD_ROWS][2 * CSTR_MAX_HEAD_ACT];
     const int64_t row0 = (int64_t)blockIdx.x * HEAD_BWD_ROWS;
     const int t = threadIdx.x;
+    // Phase 2's operands (the head's weight rows and this row's hidden activations) do not depend on phase 1: with 16-byte rows
+    // every lane requests its first quad of each NOW, so their round trip runs beside phase 1's dependent loads instead of behind the
+    // barrier, and a 256-wide layer is ONE pass per lane instead of four dependent ones.
+    const bool vec = (width & 3) == 0 && (ldh & 3) == 0 && ((reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(hidden) |
+                                                               reinterpret_cast<uintptr_t>(dz)) & 15) == 0;
+    const int c4 = 4 * (t & 63);
+    const int64_t b2 = row0 + (t >> 6);
+    float4 wq[2 * CSTR_MAX_HEAD_ACT], hq = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    const bool pre = vec && b2 < batch && c4 < width;
+    if (pre) {
+#pragma unroll
+        for (int j = 0; j < 2 * CSTR_MAX_HEAD_ACT; ++j) wq[j] = *reinterpret_cast<const float4 *>(w + (int64_t)min(j, 2 * act_dim - 1) * width + c4);
+        if (ACT != ACT_NONE) hq = *reinterpret_cast<const float4 *>(hidden + b2 * ldh + c4);
+    }
     if (t < HEAD_BWD_ROWS * CSTR_MAX_HEAD_ACT) {
         const int r = t / CSTR_MAX_HEAD_ACT, j = t % CSTR_MAX_HEAD_ACT;
         const int64_t b = row0 + r;
@@ -1122,6 +1136,32 @@ __global__ __launch_bounds__(256) void gaussian_head_bwd_input_kernel(const floa
     float g[2 * CSTR_MAX_HEAD_ACT];
 #pragma unroll
     for (int j = 0; j < 2 * CSTR_MAX_HEAD_ACT; ++j) g[j] = j < 2 * act_dim ? gp[r][j] : 0.0f;
+    if (vec) {  // the same fma chain per column (j ascending), four columns per lane
+        for (int c = c4; c < width; c += 256) {
+            if (c != c4) {
+#pragma unroll
+                for (int j = 0; j < 2 * CSTR_MAX_HEAD_ACT; ++j) wq[j] = *reinterpret_cast<const float4 *>(w + (int64_t)min(j, 2 * act_dim - 1) * width + c);
+                if (ACT != ACT_NONE) hq = *reinterpret_cast<const float4 *>(hidden + b * ldh + c);
+            }
+            float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#pragma unroll
+            for (int j = 0; j < 2 * CSTR_MAX_HEAD_ACT; ++j) {
+                if (j >= 2 * act_dim) break;
+                acc.x = __fmaf_rn(g[j], wq[j].x, acc.x); acc.y = __fmaf_rn(g[j], wq[j].y, acc.y);
+                acc.z = __fmaf_rn(g[j], wq[j].z, acc.z); acc.w = __fmaf_rn(g[j], wq[j].w, acc.w);
+            }
+            if (ACT == ACT_RELU) {
+                acc.x = hq.x > 0.0f ? acc.x : 0.0f; acc.y = hq.y > 0.0f ? acc.y : 0.0f;
+                acc.z = hq.z > 0.0f ? acc.z : 0.0f; acc.w = hq.w > 0.0f ? acc.w : 0.0f;
+            }
+            if (ACT == ACT_TANH) {
+                acc.x = acc.x * (1.0f - hq.x * hq.x); acc.y = acc.y * (1.0f - hq.y * hq.y);
+                acc.z = acc.z * (1.0f - hq.z * hq.z); acc.w = acc.w * (1.0f - hq.w * hq.w);
+            }
+            *reinterpret_cast<float4 *>(dz + b * width + c) = acc;
+        }
+        return;
+    }
     for (int c = lane; c < width; c += 64) {
         float acc = 0.0f;
 #pragma unroll
