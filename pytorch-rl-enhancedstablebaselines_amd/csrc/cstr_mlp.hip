@@ -887,9 +887,10 @@ __global__ __launch_bounds__(256) void linear_smooth_fwd_kernel(const float *__r
     __shared__ f32x4 part[WAVES - 1][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, h = lane >> 4;
     const int m0 = blockIdx.x * 16;
-    const float *xr = x + (int64_t)(m0 + r) * ldx;
-    const float *wr = w + (int64_t)r * K;
-    const bool row_ok = m0 + r < M, col_ok = r < N;
+    const bool col_ok = r < N;
+    // operands through buffer descriptors (rows >= M / N and k >= K read as zeros: see linear_act_fwd_kernel); below 1 GiB (entry point)
+    const __amdgpu_buffer_rsrc_t rx = operand_rsrc(x, (int64_t)(M - 1) * ldx + K), rw = operand_rsrc(w, (int64_t)N * K);
+    const int xo = 4 * (m0 + r) * ldx, wo = 4 * r * K;
     f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
     constexpr int UNROLL = 4;
     float4 a[UNROLL], b[UNROLL];
@@ -897,8 +898,8 @@ __global__ __launch_bounds__(256) void linear_smooth_fwd_kernel(const float *__r
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {  // the first batch of operand loads ...
         const int k = c_first + 16 * WAVES * u + 4 * h;
-        a[u] = load_k4<VEC>(xr, k, K, row_ok && c_first < K);
-        b[u] = load_k4<VEC>(wr, k, K, col_ok && c_first < K);
+        a[u] = VEC ? load_k4_buf(rx, xo, k, K) : load_k4_buf_scalar(rx, xo, k, K);
+        b[u] = VEC ? load_k4_buf(rw, wo, k, K) : load_k4_buf_scalar(rw, wo, k, K);
     }
     // ... and, beside them, the smoothing noise of this lane's four rows (column r): target_smooth_kernel's counters
     float nz[4] = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -928,8 +929,8 @@ __global__ __launch_bounds__(256) void linear_smooth_fwd_kernel(const float *__r
 #pragma unroll
             for (int u = 0; u < UNROLL; ++u) {
                 const int k = c0 + 16 * WAVES * u + 4 * h;
-                a[u] = load_k4<VEC>(xr, k, K, row_ok);
-                b[u] = load_k4<VEC>(wr, k, K, col_ok);
+                a[u] = VEC ? load_k4_buf(rx, xo, k, K) : load_k4_buf_scalar(rx, xo, k, K);
+                b[u] = VEC ? load_k4_buf(rw, wo, k, K) : load_k4_buf_scalar(rw, wo, k, K);
             }
         }
 #pragma unroll
@@ -2569,7 +2570,7 @@ extern "C" int cstr_linear_smooth_fwd_f32(const float *x, int64_t ldx, const flo
     if ((noise == nullptr) == (rng_ctl == nullptr)) return CSTR_E_BADARG;  // exactly one noise source
     if (!(sigma >= 0.0f) || !(clip >= 0.0f) || act < 0 || act > 2) return CSTR_E_BADARG;
     // the shapes for which cstr_linear_act_fwd_f32 takes its four-way split-K form (bit-identical results)
-    if (n > 16 || k <= 32 || k > 0x7fffff || (m + 15) / 16 > 2048) return CSTR_E_UNSUPPORTED;
+    if (n > 16 || k <= 32 || k > 0x7fffff || (m + 15) / 16 > 2048 || m * ldx >= (1 << 28)) return CSTR_E_UNSUPPORTED;
     const unsigned grid = (unsigned)((m + 15) / 16);
     const bool vec = (k & 3) == 0 && (ldx & 3) == 0 && aligned16(x) && aligned16(w);
     hipStream_t s = (hipStream_t)stream;
