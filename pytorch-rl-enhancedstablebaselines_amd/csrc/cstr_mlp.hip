@@ -210,6 +210,7 @@ __global__ __launch_bounds__(64 * WAVES) void linear_act_fwd_kernel(const float 
     const __amdgpu_buffer_rsrc_t rx = operand_rsrc(x + g * x_group_stride, (int64_t)(M - 1) * ldx + K);
     const __amdgpu_buffer_rsrc_t rw = operand_rsrc(w + g * N * (int64_t)K, (int64_t)N * K);
     const int xo = 4 * (m0 + r) * ldx, wo = 4 * (n0 + r) * K;
+    const float bv = bias[g * N + min(n0 + r, N - 1)];  // the epilogue's bias: requested with the operands, not behind the reduction
     f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
     constexpr int UNROLL = 4;  // 8 vector loads in flight per lane
     for (int c0 = 16 * wave; c0 < K; c0 += 16 * WAVES * UNROLL) {
@@ -239,7 +240,6 @@ __global__ __launch_bounds__(64 * WAVES) void linear_act_fwd_kernel(const float 
     // C/D map of the 16x16 MFMA: column = lane & 15, row = 4 * (lane >> 4) + register
     const int col = n0 + r;
     if (col < N) {
-        const float bv = bias[g * N + col];
         float *yo = y + (g * M + m0 + 4 * h) * (int64_t)N + col;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -283,6 +283,7 @@ __global__ __launch_bounds__(64) void gather_linear_act_fwd_kernel(const GatherA
     const float *src = (next ? g.ring.next_obs : g.ring.obs) + o * D;
     float4 a = *reinterpret_cast<const float4 *>(src + min(4 * h, D - 4));
     float4 bw = *reinterpret_cast<const float4 *>(w + (int64_t)min(n0 + r, N - 1) * D + min(4 * h, D - 4));
+    const float bv = bias[min(n0 + r, N - 1)];  // (the epilogue's bias, requested with the operands)
     const bool first = blockIdx.x == 0 && row_ok;  // this workgroup also writes the packed batch rows of its 16 samples
     float4 obs = a;
     float2 act[A / 2];
@@ -308,7 +309,6 @@ __global__ __launch_bounds__(64) void gather_linear_act_fwd_kernel(const GatherA
     const f32x4 acc = acc0 + acc1;
     const int col = n0 + r;
     if (col < N) {
-        const float bv = bias[col];
         float *yo = y + (int64_t)(m0 + 4 * h) * N + col;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -377,6 +377,7 @@ __global__ __launch_bounds__(64 * WAVES) void linear_act_fwd_sets_kernel(const L
     const __amdgpu_buffer_rsrc_t rx = operand_rsrc(st.x, (int64_t)(M - 1) * st.ldx + K);  // BUF: see linear_act_fwd_kernel
     const __amdgpu_buffer_rsrc_t rw = operand_rsrc(st.w, (int64_t)N * K);
     const int xo = 4 * (m0 + r) * (int)st.ldx, wo = 4 * (n0 + r) * K;
+    const float bv = st.bias[min(n0 + r, N - 1)];  // the epilogue's bias: requested with the operands, not behind the reduction
     f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
     constexpr int UNROLL = 4;
     for (int c0 = 16 * wave; c0 < K; c0 += 16 * WAVES * UNROLL) {
@@ -405,7 +406,6 @@ __global__ __launch_bounds__(64 * WAVES) void linear_act_fwd_sets_kernel(const L
     }
     const int col = n0 + r;
     if (col < N) {
-        const float bv = st.bias[col];
         float *yo = st.y + (int64_t)(m0 + 4 * h) * st.ldy + col;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -443,6 +443,15 @@ __global__ __launch_bounds__(64 * WAVES) void linear_bwd_input_kernel(const floa
         dz += g0 * (int64_t)M * K;
     }
     const bool col_ok = col < K, row_ok = m0 + r < M;
+    // the lower layer's outputs the epilogue multiplies by (activation gradient) do not depend on the reduction: requested NOW
+    // (column = lane & 15, rows 4 * (lane >> 4) + e of the tile), not behind the MFMA chain and the split-K combine
+    float ty[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (ACT != ACT_NONE && BUF) {
+        const __amdgpu_buffer_rsrc_t ry = operand_rsrc(y, (int64_t)M * K);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            ty[e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ry, col_ok ? 4 * ((m0 + 4 * h + e) * K + col) : BUF_OOB, 0, 0));
+    }
     f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
     constexpr int UNROLL = 4;
     for (int gi = 0; gi < n_groups; ++gi) {
@@ -498,7 +507,7 @@ __global__ __launch_bounds__(64 * WAVES) void linear_bwd_input_kernel(const floa
             const int64_t i = (int64_t)m * K + col;
             float d = acc[e];
             if (ACT != ACT_NONE) {
-                const float t = y[i];
+                const float t = BUF ? ty[e] : y[i];
                 if (ACT == ACT_RELU) d = t > 0.0f ? d : 0.0f;
                 if (ACT == ACT_TANH) d = d * (1.0f - t * t);
             }
@@ -891,6 +900,7 @@ __global__ __launch_bounds__(256) void linear_smooth_fwd_kernel(const float *__r
     // operands through buffer descriptors (rows >= M / N and k >= K read as zeros: see linear_act_fwd_kernel); below 1 GiB (entry point)
     const __amdgpu_buffer_rsrc_t rx = operand_rsrc(x, (int64_t)(M - 1) * ldx + K), rw = operand_rsrc(w, (int64_t)N * K);
     const int xo = 4 * (m0 + r) * ldx, wo = 4 * r * K;
+    const float bv = bias[min(r, N - 1)];  // (the epilogue's bias, requested with the operands)
     f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
     constexpr int UNROLL = 4;
     float4 a[UNROLL], b[UNROLL];
@@ -948,7 +958,6 @@ __global__ __launch_bounds__(256) void linear_smooth_fwd_kernel(const float *__r
 #pragma unroll
         for (int v = 0; v < WAVES - 1; ++v) acc += part[v][lane];
         if (col_ok) {
-            const float bv = bias[r];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int64_t row = m0 + 4 * h + e;
@@ -2590,7 +2599,7 @@ extern "C" int cstr_linear_bwd_input_f32(const float *gz, const float *w, const 
     const dim3 grid((unsigned)((k + 15) / 16), (unsigned)((m + 15) / 16), (unsigned)(sum_groups ? 1 : groups));
     const int n_sum = sum_groups ? (int)groups : 0;
     const bool vec = (n & 3) == 0 && aligned16(gz);
-    const bool buf = m * n < (1 << 28) && n * k < (1 << 28);  // operands through buffer descriptors with 32-bit byte offsets: below 1 GiB
+    const bool buf = m * n < (1 << 28) && n * k < (1 << 28) && m * k < (1 << 28);  // buffer descriptors with 32-bit byte offsets: below 1 GiB
     hipStream_t s = (hipStream_t)stream;
 #define LBI(A, V, W) do { if (buf) linear_bwd_input_kernel<A, V, W, true><<<grid, 64 * W, 0, s>>>(gz, w, y, dz, (int)m, (int)n, (int)k, n_sum); \
                           else linear_bwd_input_kernel<A, V, W, false><<<grid, 64 * W, 0, s>>>(gz, w, y, dz, (int)m, (int)n, (int)k, n_sum); } while (0)
