@@ -2,9 +2,13 @@
 # SQ counters of the policy kernel: matrix-core busy cycles, LDS bank conflicts, wait buckets -- separate
 # rocprofv3 --pmc passes over tools/microbench_policy.py (program directly after `--`), median per dispatch of the policy kernel.
 # Usage: tools/pmc_policy_sq.sh TAG  -> gpurun_out/TAG_policy_sq_pmc.json (+ the available-counter list once)
+# Other kernels: BENCH=tools/microbench_rollout.py KERNEL=rollout_step NAME=rollout tools/pmc_policy_sq.sh TAG -> TAG_rollout_sq_pmc.json
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out
 TAG=${1:-r02}
+BENCH=${BENCH:-tools/microbench_policy.py}
+KERNEL=${KERNEL:-policy_rows}
+NAME=${NAME:-policy}
 cd /tmp && export TMPDIR=/tmp
 [ -f $OUT/rocprof_counters_gfx950.txt ] || rocprofv3 -L > $OUT/rocprof_counters_gfx950.txt 2>&1
 PASSES=(
@@ -18,7 +22,7 @@ PASSES=(
 i=0
 for p in "${PASSES[@]}"; do
   rm -rf $OUT/sq_$i
-  rocprofv3 --pmc $p --output-format csv -d $OUT/sq_$i -o p -- python3 $ROOT/tools/microbench_policy.py > /dev/null 2> $OUT/sq_$i.err || echo "pass $i failed: $p"
+  rocprofv3 --pmc $p --output-format csv -d $OUT/sq_$i -o p -- python3 $ROOT/$BENCH > /dev/null 2> $OUT/sq_$i.err || echo "pass $i failed: $p"
   i=$((i+1))
 done
 python3 - <<PY
@@ -26,11 +30,11 @@ import csv, glob, json, statistics
 res = {}
 for d in sorted(glob.glob("$OUT/sq_*/")):
     for f in glob.glob(d + "**/*counter_collection.csv", recursive=True):
-        rows = [r for r in csv.DictReader(open(f)) if "policy_rows" in r["Kernel_Name"]]
+        rows = [r for r in csv.DictReader(open(f)) if "$KERNEL" in r["Kernel_Name"]]
         for name in sorted({r["Counter_Name"] for r in rows}):
             v = [float(r["Counter_Value"]) for r in rows if r["Counter_Name"] == name]
             res[name] = dict(median=statistics.median(v), dispatches=len(v))
 print(json.dumps(res, indent=1))
-json.dump(res, open("$OUT/${TAG}_policy_sq_pmc.json", "w"), indent=1)
+json.dump(res, open("$OUT/${TAG}_${NAME}_sq_pmc.json", "w"), indent=1)
 PY
 rm -rf $OUT/sq_[0-9]*
