@@ -121,8 +121,12 @@ def lib() -> C.CDLL:
     return _lib
 
 
+ABI_CALLS = [0]  # launching entry points called so far (every one of them reports through check()): launch census of a recorded graph
+
+
 def check(rc: int, what: str) -> None:
     """Error convention of the ABI: 0 ok, <0 cstr error, >0 hipError_t -> RuntimeError."""
+    ABI_CALLS[0] += 1
     if rc != 0:
         raise NativeError(f"{what} failed: {lib().cstr_error_string(C.c_int(rc)).decode()} (code {rc})")
 

@@ -171,7 +171,7 @@ class ReplayBuffer(BaseBuffer):
     def predraw_indices(self, batch_size: int) -> th.Tensor:
         """Static int32 [2, batch] buffer the rollout launch writes (batch_inds, env_indices) into."""
         buf = getattr(self, "_predraw_buf", None)
-        if buf is None or buf.shape[1] != batch_size:
+        if buf is None or buf.shape[1] != batch_size or buf.device != self.ring.ctl.device:  # to(device) / unpickling move the ring
             buf = self._predraw_buf = th.zeros(2, batch_size, dtype=th.int32, device=self.device)
         return buf
 

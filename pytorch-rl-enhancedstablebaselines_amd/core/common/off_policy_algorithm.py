@@ -19,6 +19,7 @@ import torch as th
 from core.common import blas
 from core.common import distributed as dist_util
 from core.common import hip_ops
+from core import _native as nv
 from core.common.base_class import BaseAlgorithm
 from core.common.buffers import ReplayBuffer
 from core.common.callbacks import BaseCallback, MaybeCallback, to_callback
@@ -210,7 +211,7 @@ class OffPolicyAlgorithm(BaseAlgorithm):
         all-reduces are recorded into the graph (every rank replays the same graphs in the same order), with a constant learning
         rate while at least `unroll` iterations remain; the tail of a run replays graphs of unroll / 2, unroll / 4, ... 1 iterations."""
         self._graph_enabled = enabled
-        self._graph, self._graph_error = None, None
+        self._graph, self._graph_error, self._abi_launches = None, None, {}
         self.graph_unroll = max(1, int(unroll if unroll is not None else os.environ.get("CSTR_GRAPH_UNROLL", "1")))
 
     def _graph_eligible(self, callback: BaseCallback) -> bool:
@@ -343,7 +344,8 @@ class OffPolicyAlgorithm(BaseAlgorithm):
             mode = "in-graph" if getattr(self, "_graph_collectives", False) else "segmented"
         return dict(requested=bool(self._graph_enabled or self._graph_error), active=bool(self._graph_enabled and len(graphs) > 0),
                     graphs=len(graphs), segments_per_graph=segs, replays=self._graph_replays, eager_iterations=self._eager_iterations,
-                    error=self._graph_error, graph_collectives=mode)
+                    error=self._graph_error, graph_collectives=mode,
+                    abi_launches_per_iteration={int(k): v for k, v in sorted(getattr(self, "_abi_launches", {}).items())})
 
     def _capture_segments(self, unroll: int = 1) -> list:
         """`_record_segments`, and if recording WITH the collectives inside the graph raises (every rank runs the same code,
@@ -380,17 +382,24 @@ class OffPolicyAlgorithm(BaseAlgorithm):
             self._cap = dict(pool=th.cuda.graph_pool_handle(), graph=th.cuda.CUDAGraph(), items=items)
             self._cap["graph"].capture_begin(pool=self._cap["pool"], capture_error_mode="thread_local")
             n_updates = self._n_updates
+            calls0 = nv.ABI_CALLS[0]
             try:
                 for _ in range(unroll):
                     self._graph_body()
                     self._n_updates += self.gradient_steps  # the next body sees its own policy-delay phase
                 self._cap["graph"].capture_end()
                 items.append(self._cap["graph"])
+                # launches recorded per iteration of this policy-delay phase (every launch of the captured body goes through the
+                # C ABI; bench.py reports it, tools/count_launches.sh is the rocprofv3 cross-check)
+                self._abi_launches[self._graph_phase()] = (nv.ABI_CALLS[0] - calls0) / unroll
             except Exception:
                 try:  # leave capture mode before the graph object is destroyed
                     self._cap["graph"].capture_end()
                 except Exception:
                     pass
+                # nothing of the recorded body ran: host-side debts of the one-launch rollout (indices "drawn" by a launch that was
+                # only recorded, a Philox advance handed to a consumer that was never reached) must not reach the eager fallback
+                self._drop_recording_debts()
                 raise
             finally:
                 self._cap = None
@@ -400,6 +409,12 @@ class OffPolicyAlgorithm(BaseAlgorithm):
         th.cuda.current_stream(self.device).wait_stream(side)
         th.cuda.synchronize(self.device)
         return items
+
+    def _drop_recording_debts(self) -> None:
+        rb = getattr(self, "replay_buffer", None)
+        if rb is not None and hasattr(rb, "_predrawn"):
+            rb._predrawn = None
+        self._rng_advance = None
 
     def _collectives_in_graph(self) -> bool:
         if getattr(self, "_graph_collectives", None) is None:

@@ -343,7 +343,7 @@ class MADDPG(OffPolicyAlgorithm):
                 shared_next = None if C.local else self.critic_target._input(0, rd.next_observations, next_actions)
         if pb is None:
             shared_cur = None if C.local else C._input(0, rd.observations, rd.actions)
-        if (BATCH_AGENT_CRITIC_STEPS and n_updates % self.policy_delay != 0 and shared_next is not None and not self.debug_capture and B <= fused.LOSS_ROOT_MAX_ROWS
+        if (BATCH_AGENT_CRITIC_STEPS and n_updates % self.policy_delay != 0 and shared_next is not None and B <= fused.LOSS_ROOT_MAX_ROWS
                 and self.n_agents <= hip_ops.nv.MAX_ADAM_SEGS
                 and all(fused.twin_pair_supported(c, t) and fused.loss_root_supported(c) for c, t in zip(self._fast_critics, self._fast_critic_targets))
                 and len({c.acts[0] for c in self._fast_critics}) == 1):
@@ -351,6 +351,7 @@ class MADDPG(OffPolicyAlgorithm):
             # between), so their forward chains share pointer-table launches, their weight gradients one deferred launch pass and
             # their Adam steps one launch. (With a policy update, quirk Q3's soft updates inside the agent loop order the agents.)
             outs = fused.twin_pair_forward_many(self._fast_critics, self._fast_critic_targets, shared_cur, shared_next)
+            captured_many = []
             with fused.deferred_weight_grads():
                 for i, (qs, qs_t) in enumerate(outs):
                     td_root = dict(mode="td", q1_t=qs_t[0], q2_t=qs_t[1], next_logp=None, rew=rd.rewards, done=rd.dones, ent_coef=None,
@@ -358,9 +359,14 @@ class MADDPG(OffPolicyAlgorithm):
                                    loss_out=self._loss_now, loss_sum=self._loss_sums[f"critic{i}"], alpha=None)
                     with fused.loss_root(td_root):
                         fused.backward_q(qs, gq)
+                    if self.debug_capture:  # the loss-root launch of agent i has run (only the weight gradients are deferred)
+                        captured_many.append(dict(target_q=self._target_q[i].clone(), current_q=[q.detach().clone() for q in qs],
+                                                  critic_loss=self._loss_now.clone(), actor_loss=None))
             for i in range(self.n_agents):
                 self._allreduce_grads(pol.critic_slices[i])
             C.optimizer_list[0].step_with(*C.optimizer_list[1:])
+            if self.debug_capture:
+                self.last_train_tensors = dict(agents=captured_many, batched_critic_steps=True)
             return
         captured = []
         for i in range(self.n_agents):

@@ -275,7 +275,8 @@ class TD3(OffPolicyAlgorithm):
 
 
 class DDPG(TD3):
-    """reference: core/ddpg/ddpg.py:14-130 -- TD3 with policy_delay 1, one critic, no target smoothing."""
+    """reference: core/ddpg/ddpg.py:14-130 -- TD3 with policy_delay 1, one critic and a smoothing draw clamped to [-0, 0]
+    (the reference passes target_policy_noise=0.1, target_noise_clip=0.0: the attribute values are kept, the noise is zero)."""
 
     @classmethod
     def _ctor_keys(cls) -> tuple:
@@ -290,6 +291,6 @@ class DDPG(TD3):
         policy_kwargs.setdefault("n_critics", 1)
         super().__init__(policy, env, learning_rate, buffer_size, learning_starts, batch_size, tau, gamma, train_freq,
                          gradient_steps, action_noise, replay_buffer_class, replay_buffer_kwargs, optimize_memory_usage,
-                         policy_delay=1, target_policy_noise=0.0, target_noise_clip=0.0, tensorboard_log=tensorboard_log,
+                         policy_delay=1, target_policy_noise=0.1, target_noise_clip=0.0, tensorboard_log=tensorboard_log,
                          policy_kwargs=policy_kwargs, verbose=verbose, seed=seed, device=device,
                          _init_setup_model=_init_setup_model)

@@ -379,13 +379,24 @@ def gen_td3():
     _gen_td3("default")
 
 
-def _gen_td3(tag):
-    """tag "small": net_arch [48, 32], batch 64; "default": the class default [400, 300] (td3/policies.py:141-145), batch 256."""
+def gen_ddpg():
+    _gen_td3("small", algo="ddpg")
+    _gen_td3("default", algo="ddpg")
+
+
+def _gen_td3(tag, algo="td3"):
+    """tag "small": net_arch [48, 32], batch 64; "default": the class default [400, 300] (td3/policies.py:141-145), batch 256.
+    algo "ddpg": core/ddpg/ddpg.py:14-130 -- TD3.train with policy_delay 1, ONE critic (one mse_loss per step) and a
+    target-smoothing draw clamped to [-0, 0] (target_policy_noise 0.1, target_noise_clip 0.0)."""
     import torch.nn.functional as F_real
 
     import core.td3.td3 as td3mod
     from core.common.logger import Logger
     from core.td3.td3 import TD3
+
+    if algo == "ddpg":
+        from core.ddpg.ddpg import DDPG as TD3
+    n_q = 1 if algo == "ddpg" else 2
 
     rec = _Recorder()
 
@@ -438,13 +449,14 @@ def _gen_td3(tag):
     finally:
         td3mod.F = F_real
         rb.sample = orig_sample
-    assert len(rec.mse) == 2 * n_steps
+    assert len(rec.mse) == n_q * n_steps and len(model.critic.q_networks) == n_q
     for k in range(n_steps):
         for fi, fname in enumerate(["observations", "actions", "next_observations", "dones", "rewards"]):
             out[f"step{k}/batch_{fname}"] = batches[k][fi]
-        out[f"step{k}/current_q1"] = rec.mse[2 * k][0].numpy()
-        out[f"step{k}/current_q2"] = rec.mse[2 * k + 1][0].numpy()
-        out[f"step{k}/target_q"] = rec.mse[2 * k][1].numpy()
+        out[f"step{k}/current_q1"] = rec.mse[n_q * k][0].numpy()
+        if n_q == 2:
+            out[f"step{k}/current_q2"] = rec.mse[2 * k + 1][0].numpy()
+        out[f"step{k}/target_q"] = rec.mse[n_q * k][1].numpy()
     for nm in ("actor", "actor_target", "critic", "critic_target"):
         out.update(_flat_sd(f"after/{nm}", getattr(model, nm).state_dict()))
     out["hyper"] = np.array([model.gamma, model.tau, model.target_policy_noise, model.target_noise_clip,
@@ -452,9 +464,9 @@ def _gen_td3(tag):
     out["np_seed"] = np.int64(555)
     if tag == "default":
         assert model.actor.mu[0].out_features == 400 and model.actor.mu[2].out_features == 300
-        save("td3_train_kat_default.npz", **slim_weights(out))
+        save(f"{algo}_train_kat_default.npz", **slim_weights(out))
     else:
-        save("td3_train_kat.npz", **out)
+        save(f"{algo}_train_kat.npz", **out)
 
 
 def gen_iddpg():
@@ -465,9 +477,40 @@ def gen_maddpg_default():
     gen_maddpg(tag="default")
 
 
-def gen_maddpg(algo="maddpg", tag="small"):
+class _BoxOnlyEnv:
+    """Harness-side env for learner fixtures whose shape no reference env has (BASELINE config 5: 4 agents, 8 obs / 4 act):
+    MADDPG.train() (maddpg.py:117-191) uses the env's SPACES only -- the batch comes from the injected ring rows."""
+
+    def __new__(cls, D, A):
+        import gymnasium
+        from gymnasium import spaces
+
+        class BoxOnly(gymnasium.Env):
+            observation_space = spaces.Box(-1, 1, (D,), np.float32)
+            action_space = spaces.Box(-1, 1, (A,), np.float32)
+
+            def reset(self, *, seed=None, options=None):
+                return np.zeros(D, np.float32), {}
+
+            def step(self, action):
+                return np.zeros(D, np.float32), 0.0, False, False, {}
+
+        return BoxOnly()
+
+
+def gen_maddpg4_default():
+    gen_maddpg(tag="default", n_agents=4)
+
+
+def gen_maddpg4():
+    gen_maddpg(tag="small", n_agents=4)
+
+
+def gen_maddpg(algo="maddpg", tag="small", n_agents=2):
     """MADDPG / IDDPG on the natural 2-agent split of the CSTR env: agent 0 = reactor 1 ([C1,T1] -> F1), agent 1 = reactor 2.
-    tag "default": the class-default per-agent nets [400, 300] (maddpg/policies.py:344-353), batch 256."""
+    tag "default": the class-default per-agent nets [400, 300] (maddpg/policies.py:344-353), batch 256.
+    n_agents=4: BASELINE config 5's learner shape -- 8 obs / 4 act, one agent per (C, T) pair and coolant flow
+    (obs splits [[0,1],[2,3],[4,5],[6,7]], act splits [[0],[1],[2],[3]]); the env only supplies the spaces."""
     import torch.nn.functional as F_real
 
     from core.common.logger import Logger
@@ -489,12 +532,17 @@ def gen_maddpg(algo="maddpg", tag="small"):
             rec.mse.append((a.detach().clone(), b.detach().clone()))
             return F_real.mse_loss(a, b, *args, **kw)
 
-    N, D, A, n_steps, n_agents = 4, 4, 2, 4, 2
+    N, D, A, n_steps = 4, 2 * n_agents, n_agents, 4
     B = 64 if tag == "small" else 256
-    venv = _make_venv(N)
-    pk = dict(policy_kwargs=dict(net_arch=[[32, 24], [32, 24]])) if tag == "small" else {}
-    model = MADDPG(n_agents, "MlpPolicy", venv, [[0, 1], [2, 3]], [[0], [1]], learning_rate_list=[1e-3, 1e-3], seed=0, device="cpu",
-                   batch_size=B, buffer_size=64 * N, **pk)
+    if n_agents == 2:
+        venv = _make_venv(N)
+    else:
+        from core.common.vec_env.dummy_vec_env import DummyVecEnv
+
+        venv = DummyVecEnv([lambda: _BoxOnlyEnv(D, A) for _ in range(N)])
+    pk = dict(policy_kwargs=dict(net_arch=[[32, 24]] * n_agents)) if tag == "small" else {}
+    model = MADDPG(n_agents, "MlpPolicy", venv, [[2 * a, 2 * a + 1] for a in range(n_agents)], [[a] for a in range(n_agents)],
+                   learning_rate_list=[1e-3] * n_agents, seed=0, device="cpu", batch_size=B, buffer_size=64 * N, **pk)
     model.set_logger(Logger(folder=None, output_formats=[]))
     rng = np.random.default_rng(2718)
     _fill_buffer(model, rng, 40, N, D, A)
@@ -554,12 +602,13 @@ def gen_maddpg(algo="maddpg", tag="small"):
     act, buf_act = model._sample_action(0, NormalActionNoise(np.zeros(1), np.ones(1)), N)
     pred, _ = model.predict(obs, deterministic=False)
     out.update(sa_obs=obs, sa_action=act, sa_buffer_action=buf_act, sa_predict=pred)
+    name = algo if n_agents == 2 else f"{algo}{n_agents}"
     if tag == "default":
         shapes = sorted({tuple(v.shape) for k, v in out.items() if k.startswith("before/actor/") and v.ndim == 2})
         assert (400, 2) in shapes and (300, 400) in shapes, shapes
-        save(f"{algo}_train_kat_default.npz", **slim_weights(out))
+        save(f"{name}_train_kat_default.npz", **slim_weights(out))
     else:
-        save(f"{algo}_train_kat.npz", **out)
+        save(f"{name}_train_kat.npz", **out)
 
 
 def gen_config1():
@@ -615,6 +664,57 @@ def gen_checkpoint():
          critic_adam_step=np.float32(float(opt["state"][0]["step"])), critic_exp_avg0=opt["state"][0]["exp_avg"].numpy(),
          n_updates=np.int64(model._n_updates))
     print("wrote", path, os.path.getsize(path))
+
+
+def gen_eval():
+    """The reference's evaluate_policy (core/common/evaluation.py:11-140) over DummyVecEnv([TwoSeriesCSTREnv] * N):
+    (a) a replaying predictor (any object with predict(), evaluation.py:88-93) over a fixed action tape with out-of-range
+        actions and two NaN actions (-> the env's exception path ends that episode early, twoseriescstr.py:413-421),
+        n_eval_episodes = 7 over 3 envs (targets [2, 2, 3], evaluation.py:79-82): per-episode returns (f64 sums of f32 rewards),
+        lengths, their order, and the (mean, std) form;
+    (b) the seeded, untrained SAC / TD3 policies at the class defaults, deterministic=True, 6 episodes over 4 envs."""
+    import contextlib
+    import io
+
+    from core.common.evaluation import evaluate_policy
+    from core.common.vec_env.dummy_vec_env import DummyVecEnv
+    from core.sac.sac import SAC
+    from core.td3.td3 import TD3
+    from twoseriescstr import TwoSeriesCSTREnv
+
+    N, n_eval, T = 3, 7, 1300
+    rng = np.random.default_rng(808)
+    tape = rng.uniform(-1.2, 1.2, size=(T, N, 2)).astype(np.float32)
+    tape[137, 0, 1] = np.nan    # env 0's first episode ends at length 138
+    tape[655, 2, 0] = np.nan    # env 2's second episode ends at length 256
+
+    class Tape:
+        def __init__(self):
+            self.t = 0
+
+        def predict(self, observations, state=None, episode_start=None, deterministic=False):
+            a = tape[self.t].copy()
+            self.t += 1
+            return a, state
+
+    def run(model, n_envs, seed, n_episodes, **kw):
+        venv = DummyVecEnv([lambda: TwoSeriesCSTREnv() for _ in range(n_envs)])
+        venv.seed(seed)
+        with contextlib.redirect_stdout(io.StringIO()):
+            return evaluate_policy(model, venv, n_eval_episodes=n_episodes, warn=False, **kw)
+
+    out = dict(tape=tape, tape_dims=np.array([N, n_eval, 11], np.int64))
+    tm = Tape()
+    rets, lens = run(tm, N, 11, n_eval, return_episode_rewards=True)
+    out.update(tape_returns=np.asarray(rets, np.float64), tape_lengths=np.asarray(lens, np.int64), tape_steps_used=np.int64(tm.t))
+    mean, std = run(Tape(), N, 11, n_eval)
+    out.update(tape_mean=np.float64(mean), tape_std=np.float64(std))
+    for name, cls in (("sac", SAC), ("td3", TD3)):
+        model = cls("MlpPolicy", DummyVecEnv([lambda: TwoSeriesCSTREnv() for _ in range(2)]), seed=0, device="cpu")
+        rets, lens = run(model, 4, 5, 6, deterministic=True, return_episode_rewards=True)
+        out[f"{name}_returns"], out[f"{name}_lengths"] = np.asarray(rets, np.float64), np.asarray(lens, np.int64)
+    out["model_dims"] = np.array([4, 6, 5, 0], np.int64)  # n_envs, n_eval_episodes, env seed, model seed
+    save("evaluate_policy_kat.npz", **out)
 
 
 def gen_init():
@@ -768,7 +868,7 @@ def gen_vecnorm():
     save("vecnormalize_kat.npz", **out)
 
 
-GENS = {"maddpg_default": gen_maddpg_default, "config1": gen_config1, "env": gen_env, "resets": gen_resets, "vecnorm": gen_vecnorm, "vecenv": gen_vecenv, "sampler": gen_sampler, "replay": gen_replay, "sac": gen_sac,
+GENS = {"maddpg_default": gen_maddpg_default, "maddpg4_default": gen_maddpg4_default, "maddpg4": gen_maddpg4, "ddpg": gen_ddpg, "eval": gen_eval, "config1": gen_config1, "env": gen_env, "resets": gen_resets, "vecnorm": gen_vecnorm, "vecenv": gen_vecenv, "sampler": gen_sampler, "replay": gen_replay, "sac": gen_sac,
         "td3": gen_td3, "init": gen_init, "maddpg": gen_maddpg, "iddpg": gen_iddpg, "checkpoint": gen_checkpoint}
 
 if __name__ == "__main__":
