@@ -8,27 +8,38 @@ LOCAL_RANK / MASTER_* in the environment), or -- plain `python bench.py --gpus N
 any GPU call, starts N fresh child processes of itself with that environment, relays rank 0's single JSON line and exits
 non-zero unless the job really ran N ranks (`n_gpus`, `rccl_world`, `allreduce_checksum` on the line prove it).
 
-A "step" is ONE iteration of `core.SAC("MlpPolicy", env).learn()` at the class defaults
-(reference: core/common/off_policy_algorithm.py:331-351): one vec-step of 4096 envs (the whole actor network + sampling
-in one f32-MFMA launch, then the fused collect kernel) followed by one gradient step (HIP MT19937 sampler, MLP
-forward/backward on hand-written f32-MFMA Linear kernels [the rocBLAS/PyTorch-ROCm variant is reported beside it],
-HIP td-target + losses, flat Adam launches, HIP polyak), replayed from a captured hipGraph. Inputs are resident in HBM
+A "step" is ONE iteration of `core.SAC("MlpPolicy", env).learn()` with the class-default HYPER-PARAMETERS
+(reference: core/common/off_policy_algorithm.py:331-351): one vec-step of 4096 envs (policy network + sampling + env step
++ ring row + the replay index draw in one launch) followed by one gradient step (gather inside the first layer behind
+the sample, MLP forward/backward on hand-written f32-MFMA kernels [the rocBLAS/PyTorch-ROCm variant is reported beside
+it], HIP td-target + losses, flat Adam launches, HIP polyak). The launches are replayed from a captured hipGraph with
+EIGHT iterations recorded per graph: `model.enable_graph_capture(True, unroll=8)` -- an opt-in of this stack, `learn()`
+alone launches eagerly and CSTR_GRAPH_UNROLL defaults to 1; the host bookkeeping (episode statistics, lazily read loss
+means) of those eight iterations runs after the replay. `config.hip_graph` / `config.graph_unroll` say so on the line and
+`unroll1_variant` is the same run with one iteration per graph. Inputs are resident in HBM
 before the timed region. The timed region is bracketed by a barrier + torch.cuda.synchronize() on both sides; the MAX
 over ranks is reported. A K-step region shorter than MIN_TIMED_S is repeated (whole multiples of K, every repeat
 bracketed the same way) until the total reaches it: `steps` stays the CLI value, `timed_steps_total` is the real count.
 The run FAILS (non-zero exit) if hipGraph replay was requested but the timed iterations ran eagerly.
 
 Extra objects on the JSON line:
-  roofline      dominant hand-written kernel (the fused collect step: 104 algorithmic B per env-step)
-                at the WORKLOAD size, timed live with HIP events on the launch stream (back-to-back launches
-                right after the timed region). At N=4096 the launch moves 426 KB and is latency-bound.
-  roofline_stream  the same kernel at N = 2^22 envs (436 MB per launch, far above every cache): what the kernel
-                reaches when it is actually bandwidth-bound. Never to be confused with the end-to-end figure.
-  roofline_mfma the longest launch of the iteration, the rollout's whole policy network in one launch (f32 matrix cores):
-                algorithmic FLOPs per launch / measured launch duration against the dense f32 MFMA peak.
+  roofline      the dominant kernel OF THE REPLAYED GRAPH: `rollout_step_kernel` (policy network + collect step of all
+                envs + replay index draw in one launch). Matrix-core bound: the policy network's algorithmic FLOPs per
+                launch / its launch duration (HIP events on the launch stream, graph-replayed back-to-back launches right
+                after the timed region) against the dense f32 MFMA peak. `hbm` inside it: the same launch against the HBM
+                roofline (104 B per env-step, SURVEY 8d, + the weights once) -- meaningless at this size and printed for
+                that reason. `traffic` = HBM bytes per launch from the committed rocprofv3 PMC passes (`traffic_source`).
+  roofline_collect / roofline_stream   the fused collect kernel alone (the launch of the eager path and of MADDPG) at the
+                workload size and at N = 2^22 envs (436 MB per launch: its bandwidth-bound regime).
+  roofline_mfma the stand-alone whole-policy launch (`policy_rows_fwd_kernel`) with the rollout launch under `as_launched`.
+  roofline_iteration  the WHOLE iteration: algorithmic bytes (2.09 MB) and FLOPs / ms_per_step against both
+                peaks, launches per iteration and the mean launch interval -- the iteration is launch-latency-bound.
   kernels       per-kernel average launch duration / algorithmic GB/s for the other HIP kernels of the step
+  td3_variant / maddpg_variant   BASELINE configs 3 and 5 (TD3 class defaults, 4096 envs; MADDPG, 4 agents on the 8-obs /
+                4-act twin-train env, 1024 envs), same loop, short runs on rank 0.
   cpu_baseline  the oracle port (C env step + ring add + MT19937 sampler with OpenMP, torch-CPU SAC step)
-                timed on this box's host cores on a bounded sample of the same workload (rank 0, N=1 only).
+                timed on this box's host cores on a bounded sample of the same workload (rank 0, N=1 only): all-cores
+                leg (`value`) and a single-thread leg, CPU model string from /proc/cpuinfo.
 """
 import argparse
 import json
@@ -285,13 +296,34 @@ def other_kernels(model, batch):
     return out
 
 
+def cpu_model() -> str:
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.lower().startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+
+    return platform.processor() or platform.machine()
+
+
 def cpu_baseline(n_envs, batch, seconds):
+    """All-cores leg (`value`) and single-thread leg of the oracle port, each a bounded sample."""
+    multi = cpu_baseline_leg(n_envs, batch, seconds, host_cores())
+    single = cpu_baseline_leg(n_envs, batch, max(3.0, seconds / 2), 1)
+    multi["cpu_model"] = cpu_model()
+    multi["single_thread"] = dict(value=single["value"], unit=single["unit"], cores=1, sample=single["sample"],
+                                  env_only_value=single["env_only_value"], ms_per_iteration=single["ms_per_iteration"])
+    return multi
+
+
+def cpu_baseline_leg(n_envs, batch, seconds, cores):
     """Oracle port of one learn() iteration on the host cores: C env step + ring add (OpenMP over envs), C MT19937
     sampler + gather, torch-CPU actor forward and SAC gradient step (oracle/sac_cpu.py). Bounded sample."""
     from oracle import cstr_oracle as orc
     from oracle import sac_cpu
 
-    cores = host_cores()
     th.set_num_threads(cores)
     rng = np.random.default_rng(0)
     rows = max(1_000_000 // n_envs, 1)
@@ -321,7 +353,7 @@ def cpu_baseline(n_envs, batch, seconds):
         n += 1
     dt = time.perf_counter() - t0
     t1 = time.perf_counter()
-    k = 50
+    k = 50 if cores > 1 else 10
     orc.collect_loop(ring, obs.copy(), np.zeros((n_envs, 2), np.float32), steps.copy(), reset, k, cores)
     env_only = k * n_envs / (time.perf_counter() - t1)
     return dict(value=round(n * n_envs / dt, 1), unit="env-steps/s", cores=cores, kind="port",
@@ -330,38 +362,83 @@ def cpu_baseline(n_envs, batch, seconds):
                 env_only_value=round(env_only, 1), ms_per_iteration=round(1e3 * dt / n, 3))
 
 
-def north_star_variant(n_envs: int, device: str, graph: bool, obs_dim: int = 8, integrator: str = "rk4", mlp_on_rocblas: bool = False) -> dict:
-    """BASELINE.json's north_star wording differs from the reference / from what is built in two places; the headline value is
-    measured on the reference-true, fastest configuration and these are the same loop on the north_star-literal ones:
-      * 8-dim state + batched RK4 (the reference: 4-dim obs, forward Euler; SURVEY D1/D2): obs = [normalised | raw], rk4;
-      * "MLP forward/backward on PyTorch-ROCm": every GEMM left to rocBLAS (CSTR_FUSED_LINEAR=0) instead of the hand-written
-        f32-MFMA Linear kernels (DESIGN D8).
-    Rank 0, one GPU, short run."""
+def variant_run(n_envs: int, device: str, graph: bool, obs_dim: int = 8, integrator: str = "rk4", mlp_on_rocblas: bool = False,
+                algo: str = "sac", unroll: int = 8, warm: int = 30, steps: int = 160) -> dict:
+    """The same loop as the headline on another configuration (rank 0, one GPU, short run):
+      * north_star-literal SAC: 8-dim state + batched RK4 (the reference: 4-dim obs, forward Euler), obs =
+        [normalised | raw]; and "MLP forward/backward on PyTorch-ROCm": every GEMM left to rocBLAS (CSTR_FUSED_LINEAR=0)
+        instead of the hand-written f32-MFMA kernels (DESIGN D8);
+      * BASELINE config 3: TD3 class defaults on the same 4096 envs (two graphs: the delayed policy update);
+      * BASELINE config 5: MADDPG, 4 agents (one per reactor) on the 8-obs / 4-act twin-train env (two reactor trains side by side
+        per env, SURVEY D4), 1024 envs, class-default nets [400, 300];
+      * the headline configuration with ONE iteration per hipGraph (`unroll=1`)."""
     from core.common import fused
     from core.common.callbacks import NoopCallback
     from core.common.vec_env import CSTRVecEnv
     from core.sac import SAC
+    from core.td3 import TD3
 
-    warm, steps = 30, 150
     fused_before = fused.USE_FUSED_LINEAR
     if mlp_on_rocblas:
         fused.USE_FUSED_LINEAR = False
-    env = CSTRVecEnv(n_envs, obs_dim=obs_dim, integrator=integrator, device=device)
-    model = SAC("MlpPolicy", env, seed=0, device=device)
+    steps = -(-steps // (2 * unroll)) * (2 * unroll)  # whole graphs of both policy-delay phases
+    if algo == "maddpg":
+        from core.maddpg import MADDPG
+
+        env = CSTRVecEnv(n_envs, obs_dim=8, twin=True, integrator=integrator, device=device)
+        model = MADDPG(4, "MlpPolicy", env, [[0, 1], [2, 3], [4, 5], [6, 7]], [[0], [1], [2], [3]], learning_rate_list=[1e-3] * 4,
+                       seed=0, device=device)
+        what = f"4 agents, {n_envs} envs, twin-train env: obs 8 / act 4, {integrator}, nets [400,300], ring {model.replay_buffer.buffer_size}x{n_envs}"
+    else:
+        env = CSTRVecEnv(n_envs, obs_dim=obs_dim, integrator=integrator, device=device)
+        model = (SAC if algo == "sac" else TD3)("MlpPolicy", env, seed=0, device=device)
+        what = f"{n_envs} envs, obs {obs_dim} / act 2, {integrator}" + (", every MLP GEMM on PyTorch-ROCm (rocBLAS)" if mlp_on_rocblas else "")
     _, cb = model._setup_learn((warm + steps) * n_envs, NoopCallback(), True, "bench", False)
-    model.enable_graph_capture(graph)
-    for _ in range(warm):
-        model._learn_iteration(cb, None)
+    model.enable_graph_capture(graph, unroll=unroll)
+
+    def run_steps(k):  # learn()'s while loop for exactly k vec-steps (a replayed graph may cover several: never past the target)
+        target = model.num_timesteps + k * n_envs
+        model._total_timesteps = target
+        while model.num_timesteps < target:
+            model._learn_iteration(cb, None)
+        assert model.num_timesteps == target
+
+    run_steps(warm)
+    if graph:  # until a whole call of the timed shape replays (every policy-delay phase's graph recorded), untimed
+        for _ in range(40):
+            before = model.graph_status()["eager_iterations"]
+            run_steps(2 * unroll)
+            if model.graph_status()["eager_iterations"] == before or not model._graph_enabled:
+                break
+    st0 = model.graph_status()
     th.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(steps):
-        model._learn_iteration(cb, None)
+    run_steps(steps)
     th.cuda.synchronize()
     dt = time.perf_counter() - t0
+    st1 = model.graph_status()
     fused.USE_FUSED_LINEAR = fused_before
-    what = f"obs {obs_dim} / act 2, {integrator}" + (", every MLP GEMM on PyTorch-ROCm (rocBLAS)" if mlp_on_rocblas else "")
-    return dict(workload=f"SAC class defaults, {n_envs} envs, {what}, batch 256", steps=steps,
-                value=round(steps * n_envs / dt, 1), unit="env-steps/s", ms_per_step=round(1e3 * dt / steps, 4))
+    launches = st1["abi_launches_per_iteration"]
+    return dict(workload=f"{algo.upper()} class defaults, {what}, batch 256", steps=steps,
+                value=round(steps * n_envs / dt, 1), unit="env-steps/s", ms_per_step=round(1e3 * dt / steps, 4), graph_unroll=unroll if graph else 0,
+                eager_iterations_in_timed_region=st1["eager_iterations"] - st0["eager_iterations"],
+                launches_per_iteration=round(sum(launches.values()) / max(len(launches), 1), 2) if launches else None)
+
+
+def iteration_model(algo: str, n_envs: int, obs_dim: int, act_dim: int, batch: int, hidden=(256, 256), n_critic_params: int = 0) -> dict:
+    """Algorithmic bytes and FLOPs of one SAC iteration (2 FLOP per multiply-add, biases / activations / losses not counted).
+    bytes: env step + ring row 2 x (8 D + 4 A + 12) per env-step; sampler gather B x that (read + write); TD target 6 x 4 B per
+    sample; soft update 12 B per critic parameter. FLOPs: rollout policy N rows; actor forward on 2B rows (obs and next_obs); four
+    Q networks forward on B rows; the two critics' backward (dX + dW ~ 2 x forward); actor loss: two Q networks forward + dX on B
+    rows, actor backward (dX + dW) on B rows."""
+    d, a, (h1, h2) = obs_dim, act_dim, hidden
+    row = 2 * 4 * d + 4 * a + 12
+    by = dict(env_and_ring=2 * row * n_envs, sampler=2 * batch * row, td_target=24 * batch, soft_update=12 * n_critic_params)
+    actor = 2.0 * (d * h1 + h1 * h2 + h2 * 2 * a)
+    q = 2.0 * ((d + a) * h1 + h1 * h2 + h2)
+    fl = dict(rollout_policy=actor * n_envs, actor_fwd_2B=actor * 2 * batch, critics_and_targets_fwd=4 * q * batch, critics_bwd=2 * 2 * q * batch,
+              actor_loss_critics_fwd_dx=2 * 2 * q * batch, actor_bwd=2 * actor * batch)
+    return dict(bytes=by, bytes_total=sum(by.values()), flops=fl, flops_total=sum(fl.values()))
 
 
 def launch_ranks(args) -> int:
@@ -370,6 +447,7 @@ def launch_ranks(args) -> int:
     Nothing here touches the GPU (`torch.cuda.device_count()` only counts devices) and nothing re-execs this process."""
     import socket
     import subprocess
+    import tempfile
 
     n = args.gpus
     single = os.environ.get("CSTR_BENCH_SINGLE_DEVICE") == "1"  # rehearsal: N ranks on cuda:0 (gloo transport)
@@ -382,13 +460,42 @@ def launch_ranks(args) -> int:
         port = sk.getsockname()[1]
     env = dict(os.environ, WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0",
                OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "4"), CSTR_BENCH_SPAWNED="1")
+    limit = float(os.environ.get("CSTR_BENCH_LAUNCH_TIMEOUT_S", "1500"))  # wall clock for the whole job
+    out0 = tempfile.TemporaryFile()  # rank 0's stdout (ONE line) -- a file, so that nobody blocks on a full pipe while we poll
     procs = []
     for r in range(n):
         renv = dict(env, RANK=str(r), LOCAL_RANK=str(r), LOCAL_WORLD_SIZE=str(n))
-        out = subprocess.PIPE if r == 0 else sys.stderr  # stdout carries ONE line: rank 0's
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=renv, stdout=out))
-    out0, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=renv,
+                                      stdout=out0 if r == 0 else sys.stderr, start_new_session=True))
+    # poll ALL children: the first rank that dies (bad device, out of memory, an exception during start-up) would otherwise leave
+    # the others waiting in the rendezvous / a collective until the backend's timeout. These are fresh children of this
+    # (GPU-free) parent: terminating them is an ordinary signal, nothing is re-exec'ed.
+    t0, failed = time.monotonic(), None
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [r for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad:
+            failed = f"rank {bad[0]} exited with code {codes[bad[0]]}"
+        elif time.monotonic() - t0 > limit:
+            failed = f"no result after {limit:.0f} s"
+        if failed or all(c == 0 for c in codes):
+            break
+        time.sleep(0.05)
+    if failed:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        t1 = time.monotonic()
+        while any(p.poll() is None for p in procs) and time.monotonic() - t1 < 10:
+            time.sleep(0.05)
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        codes = [p.wait() for p in procs]
+        print(f"bench.py: {failed}; siblings terminated; rank exit codes {codes}", file=sys.stderr)
+        return 1
+    out0.seek(0)
+    out0 = out0.read()
     lines = [ln for ln in out0.decode().splitlines() if ln.strip().startswith("{")]
     if any(codes) or len(lines) != 1:
         print(f"bench.py: rank exit codes {codes}, {len(lines)} JSON line(s) from rank 0", file=sys.stderr)
@@ -414,9 +521,15 @@ def main():
 
     # rehearsal knobs (a 1-GPU box): CSTR_DIST_BACKEND=gloo + CSTR_BENCH_SINGLE_DEVICE=1 run N ranks on cuda:0 over gloo, which
     # exercises this file's multi-rank path (RCCL refuses two ranks on one device); the driver's real runs use neither
+    if os.environ.get("CSTR_BENCH_FAIL_RANK") == os.environ.get("RANK", "0") and "WORLD_SIZE" in os.environ:
+        # test knob (tests/test_bench_contract.py): this rank dies during start-up, before the rendezvous
+        print(f"[bench] rank {os.environ.get('RANK')}: injected start-up failure (CSTR_BENCH_FAIL_RANK)", file=sys.stderr)
+        raise SystemExit(7)
     rank, local_rank, world = dist_util.init_from_env(os.environ.get("CSTR_DIST_BACKEND"))
     if os.environ.get("CSTR_BENCH_SINGLE_DEVICE") == "1":
         local_rank = 0
+    if world > 1:
+        print(f"[bench] rank {rank}/{world} on cuda:{local_rank} ok ({th.distributed.get_backend()} process group up)", file=sys.stderr, flush=True)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: refusing to label a {world}-rank run as {args.gpus} GPUs")
     assert th.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
@@ -452,6 +565,7 @@ def main():
         if os.environ.get("CSTR_GRAPH_COLLECTIVES", "auto") == "auto":
             model._graph_collectives = dist_util.graph_collectives_ok(model.device)  # the start-up trial itself
             print(f"[bench] collectives inside the graph: {model._graph_collectives}", file=sys.stderr)
+    env_obs_dim, env_act_dim, ring_rows = env.obs_dim, env.act_dim, model.replay_buffer.buffer_size
     total = (args.warmup + args.steps) * N
     _, callback = model._setup_learn(total, NoopCallback(), True, "bench", False)
     use_graph = bool(args.graph)  # world > 1: graph segments with the RCCL all-reduces between them
@@ -563,48 +677,92 @@ def main():
         "reference_python_env_steps_per_s": {"value": REFERENCE_PYTHON_ENV_STEPS_PER_S, "provenance": "unmodified reference SAC.learn() on "
                                              "DummyVecEnv(4096), survey container, 8 CPU cores, no GPU (SURVEY 6 / BASELINE.md 2); "
                                              "not re-measurable on the GPU box (the reference cannot travel)",
-                                             "speedup": round(value / REFERENCE_PYTHON_ENV_STEPS_PER_S, 1)},
+                                             "cross_machine_ratio": round(value / REFERENCE_PYTHON_ENV_STEPS_PER_S, 1)},
         "config": {"workload": f"{args.algo.upper()} MlpPolicy class defaults on {N} vectorised two-series CSTR envs per GPU "
-                               f"(obs {args.obs_dim}/act 2, {args.integrator}, batch 256, ring 244x{N}, 1 gradient step per vec-step)",
+                               f"(obs {env_obs_dim}/act {env_act_dim}{' twin-train env, 4 agents' if args.algo == 'maddpg' else ''}, {args.integrator}, batch 256, "
+                               f"ring {ring_rows}x{N}, 1 gradient step per vec-step; hipGraph replay, {args.graph_unroll} iterations per graph)",
                    "n_envs_per_gpu": N, "global_batch": B * world, "parallelism": f"dp{world}", "hip_graph": bool(st1["active"]), "hip_graph_requested": use_graph, "hip_graph_segments": st1["segments_per_graph"], "graph_unroll": (model.graph_unroll if (world == 1 and not getattr(model, "_force_segment_boundaries", False)) or st1["graph_collectives"] == "in-graph" else 1) if use_graph else 0, "blas": args.blas,
                    "n_updates": model._n_updates},
     }
     if rank == 0:
+        launches = st1["abi_launches_per_iteration"]
+        n_launch = round(sum(launches.values()) / max(len(launches), 1), 2) if launches else None
         if not args.no_roofline and args.algo != "maddpg":
-            line["roofline"] = roofline_collect(N, args.obs_dim, args.integrator, 500)
-            line["roofline"]["note"] = ("workload size: 4096 envs x 104 B = 426 KB per launch, cache-resident and launch-latency-"
-                                        "bound (duration = issue interval of graph-replayed launches); see roofline_stream for "
-                                        "the bandwidth-bound regime of the same kernel")
+            rc = roofline_collect(N, args.obs_dim, args.integrator, 500)
+            rc["note"] = ("the fused collect kernel ALONE (the eager path's and MADDPG's launch; inside captured SAC / TD3 iterations it is "
+                          "part of rollout_step_kernel): 4096 envs x 104 B = 426 KB per launch, cache-resident and launch-latency-bound; "
+                          "roofline_stream is the bandwidth-bound regime of the same kernel")
+            rc["traffic_source"] = "profiles/r01_collect_pmc.json (committed rocprofv3 --pmc passes; not measured in this run)"
+            line["roofline_collect"] = rc
             line["roofline_stream"] = roofline_collect(1 << 22, args.obs_dim, args.integrator, 30)
+            line["roofline_stream"]["traffic_source"] = rc["traffic_source"]
             line["kernels"] = other_kernels(model, B)
-            pk = line["kernels"]["policy_rows_fwd_kernel"]  # the LONGEST launch of the iteration, matrix-core bound
-            traffic = None  # HBM bytes per launch from the committed PMC passes (tools/pmc_policy.sh), bench shape only
-            if pk["shape"] == [4096, 4, 256, 256, 4]:
-                try:
-                    with open(os.path.join(ROOT, "profiles", "r02_policy_pmc.json")) as fh:
-                        traffic = json.load(fh)["policy_rows_fwd_kernel"]["4096"]["traffic_bytes"]
-                except (OSError, KeyError, ValueError):
-                    pass
-            line["roofline_mfma"] = dict(bound="mfma", kernel="policy_rows_fwd_kernel", achieved=pk["tflops"], peak=F32_MFMA_PEAK_TFLOPS,
-                                         unit="TFLOP/s", frac=pk["frac"], traffic=traffic, launch_us=pk["launch_us"], shape=pk["shape"])
-            rk = line["kernels"].get("rollout_step_kernel")
-            if rk is not None:  # the launch the captured iteration runs: the same matrix work + the env step + the index draw
-                rtraffic = None
-                if rk["shape"] == [4096, 4, 256, 256, 4]:
+            pk = line["kernels"]["policy_rows_fwd_kernel"]  # the stand-alone whole-policy launch (eager path, MADDPG)
+            bench_shape = pk["shape"] == [4096, 4, 256, 256, 4]
+
+            def committed_traffic(fname, *keys):  # HBM bytes per launch from the committed PMC passes, bench shape only
+                if not bench_shape:
+                    return None, None
+                for rnd in ("r03", "r02"):
                     try:
-                        with open(os.path.join(ROOT, "profiles", "r02_rollout_pmc.json")) as fh:
-                            rtraffic = json.load(fh)["traffic_bytes"]
-                    except (OSError, KeyError, ValueError):
-                        pass
-                line["roofline_mfma"]["as_launched"] = dict(kernel="rollout_step_kernel", achieved=rk["tflops"], frac=rk["frac"], launch_us=rk["launch_us"], traffic=rtraffic,
-                                                            note="the policy network's FLOPs over the whole one-launch rollout (policy + collect "
-                                                                 "step of all envs + replay index draw: it replaces policy_rows_fwd_kernel + "
-                                                                 "collect_step_kernel + most of replay_sample_kernel)")
+                        with open(os.path.join(ROOT, "profiles", f"{rnd}_{fname}")) as fh:
+                            v = json.load(fh)
+                        for k in keys:
+                            v = v[k]
+                        return v, f"profiles/{rnd}_{fname} (committed rocprofv3 --pmc passes: FETCH_SIZE x 2 on gfx950 + WRITE_SIZE; not measured in this run)"
+                    except (OSError, KeyError, ValueError, TypeError):
+                        continue
+                return None, None
+
+            traffic, tsrc = committed_traffic("policy_pmc.json", "policy_rows_fwd_kernel", "4096", "traffic_bytes")
+            line["roofline_mfma"] = dict(bound="mfma", kernel="policy_rows_fwd_kernel", achieved=pk["tflops"], peak=F32_MFMA_PEAK_TFLOPS,
+                                         unit="TFLOP/s", frac=pk["frac"], traffic=traffic, traffic_source=tsrc, launch_us=pk["launch_us"], shape=pk["shape"],
+                                         note="the stand-alone whole-policy launch (not in the replayed SAC / TD3 graph; MADDPG's and the eager path's launch)")
+            rk = line["kernels"].get("rollout_step_kernel")
+            if rk is not None:  # THE dominant kernel of the replayed graph: the same matrix work + the env step + the index draw
+                rtraffic, rsrc = committed_traffic("rollout_pmc.json", "traffic_bytes")
+                n_rows, k0, h1, h2, a2 = rk["shape"]
+                flops = 2.0 * n_rows * (k0 * h1 + h1 * h2 + h2 * a2)
+                w_bytes = 4 * (k0 * h1 + h1 + h1 * h2 + h2 + h2 * a2 + a2)
+                env_bytes = n_rows * 2 * (2 * 4 * k0 + 4 * (a2 // 2) + 12)
+                alg_bytes = env_bytes + w_bytes
+                gbs = alg_bytes / rk["launch_us"] / 1e3
+                line["roofline"] = dict(
+                    bound="mfma", kernel="rollout_step_kernel", achieved=rk["tflops"], peak=F32_MFMA_PEAK_TFLOPS, unit="TFLOP/s", frac=rk["frac"],
+                    traffic=rtraffic, traffic_source=rsrc, launch_us=rk["launch_us"], shape=rk["shape"], flops_per_launch=flops,
+                    hbm=dict(algorithmic_bytes_per_launch=alg_bytes, env_and_ring_bytes=env_bytes, weight_bytes=w_bytes, achieved=round(gbs, 2),
+                             peak=HBM_PEAK_GBS, unit="GB/s", frac=round(gbs / HBM_PEAK_GBS, 5),
+                             traffic_over_algorithmic=None if rtraffic is None else round(rtraffic / alg_bytes, 2),
+                             note="104 B per env-step (SURVEY 8d) + the policy weights once; at 4096 envs the launch is matrix-core / latency "
+                                  "bound, the HBM fraction is printed only to say so"),
+                    note="dominant kernel of the replayed graph: policy network (the MFMA work priced here) + fused collect step of all envs + "
+                         "replay index draw in ONE launch; duration = HIP events around graph-replayed back-to-back launches on the launch stream")
+                line["roofline_mfma"]["as_launched"] = dict(kernel="rollout_step_kernel", achieved=rk["tflops"], frac=rk["frac"], launch_us=rk["launch_us"],
+                                                            traffic=rtraffic, traffic_source=rsrc)
+            else:
+                line["roofline"] = rc
+        if args.algo == "sac":
+            n_crit = sum(p.numel() for p in model.critic.parameters())
+            im = iteration_model("sac", N, args.obs_dim, 2, B, (256, 256), n_crit)
+            ms = line["ms_per_step"]
+            gbs, tfl = im["bytes_total"] / ms / 1e6, im["flops_total"] / ms / 1e9
+            line["roofline_iteration"] = dict(
+                algorithmic_bytes=im["bytes_total"], bytes_by_part=im["bytes"], achieved_gbs=round(gbs, 2), hbm_peak_gbs=HBM_PEAK_GBS,
+                hbm_frac=round(gbs / HBM_PEAK_GBS, 5), algorithmic_flops=im["flops_total"], flops_by_part=im["flops"], achieved_tflops=round(tfl, 2),
+                mfma_f32_peak_tflops=F32_MFMA_PEAK_TFLOPS, mfma_frac=round(tfl / F32_MFMA_PEAK_TFLOPS, 4), launches_per_iteration=n_launch,
+                mean_launch_interval_us=None if not n_launch else round(1e3 * ms / n_launch, 3),
+                note="whole iteration / ms_per_step: launch-latency-bound (a chain of dependent sub-10-us launches), far from either roofline; "
+                     "launches = C-ABI launches recorded into the graph per iteration (rocprofv3 cross-check: tools/count_launches.sh)")
+        line["config"]["launches_per_iteration"] = n_launch
         if world == 1 and not args.no_variant and args.algo == "sac" and (args.obs_dim, args.integrator) == (4, "euler"):
             del model, env
             dev = f"cuda:{local_rank}"
-            line["north_star_variant"] = north_star_variant(N, dev, use_graph)
-            line["mlp_on_pytorch_rocm_variant"] = north_star_variant(N, dev, use_graph, 4, "euler", mlp_on_rocblas=True)
+            u = args.graph_unroll
+            line["north_star_variant"] = variant_run(N, dev, use_graph, unroll=u)
+            line["mlp_on_pytorch_rocm_variant"] = variant_run(N, dev, use_graph, 4, "euler", mlp_on_rocblas=True, unroll=u)
+            line["unroll1_variant"] = variant_run(N, dev, use_graph, 4, "euler", unroll=1, steps=320)
+            line["td3_variant"] = variant_run(N, dev, use_graph, 4, "euler", algo="td3", unroll=u, warm=40, steps=320)
+            line["maddpg_variant"] = variant_run(1024, dev, use_graph, 8, "euler", algo="maddpg", unroll=u, warm=40, steps=160)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(N, B, args.cpu_seconds)
             line["speedup_vs_cpu_port"] = round(value / line["cpu_baseline"]["value"], 2)

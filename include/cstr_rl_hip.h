@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define CSTR_ABI_VERSION 4
+#define CSTR_ABI_VERSION 5
 
 #define CSTR_OK 0
 #define CSTR_E_BADARG (-1)      /* null pointer / non-positive size / misaligned buffer */
@@ -506,6 +506,110 @@ int cstr_sac_actor_loss_f32(const float *logp, const float *q1, const float *q2,
 
 /* Deterministic-policy actor loss (core/td3/td3.py:194, core/maddpg/maddpg.py:174): loss = -mean(q), gq = -1/B. */
 int cstr_neg_mean_loss_f32(const float *q, float *gq, float *loss_out, float *loss_sum, int64_t batch, cstr_stream_t stream);
+
+/* ---- row-chain kernels: a gradient step's forward / backward chains with FEWER launch boundaries ------------------------------
+ * A chain of Linear layers is row-local (row r of layer l+1 needs row r of layer l only), but a launch boundary is the cheapest
+ * way on this chip to hand data between workgroups (an in-kernel cross-workgroup barrier costs 4-17 us, an empty dependent launch
+ * 1.6 us: tools/probes/cluster_chain_probe.hip, profiles/r03_notes.md). These kernels cut boundaries WITHOUT any hand-over inside a
+ * launch: a workgroup owns 16 batch rows x one column group of the chain's WIDE layer (one f32-MFMA tile pass over K), RECOMPUTES
+ * the cheap layer in front of it (K = obs_dim (+ act_dim) <= 12 inputs, or an element-wise function of stored activations), and
+ * leaves the NARROW layer behind it (a Q head's H2 -> 1 dot product, the actor head's H2 -> 2A, the first layer's input gradient
+ * H1 -> act_dim) as per-column-group PARTIAL sums that the next launch adds up in a fixed order in its prologue.
+ * SAC.train (core/sac/sac.py:215-287) = 10 launches instead of 20; everything is deterministic (no float atomics).
+ * Networks: create_mlp(in, out, [H1, H2], ReLU) (core/common/torch_layers.py:110-183); H1, H2 multiples of 4, <= 512; batch a
+ * multiple of 16, <= 1024; (obs_dim, act_dim) as the ring's layouts. `tiles` = 16-column tiles per workgroup (1, 2 or 4). */
+#define CSTR_CHAIN_MAX_NETS 4
+#define CSTR_CHAIN_MAX_WIDTH 512
+
+/* One Q network Linear(W, H1)-ReLU-Linear(H1, H2)-ReLU-Linear(H2, 1) (core/common/policies.py:960-987) of a chain launch. */
+typedef struct cstr_chain_net {
+    const float *w1, *b1, *w2, *b2, *w3, *b3; /* [H1][W], [H1], [H2][H1], [H2], [H2], [1] */
+    const float *x;                            /* forward: this network's input rows [batch][W] (ld = W) */
+    float *h1, *h2;                            /* [batch][H1], [batch][H2] post-activation: forward = written when not NULL (kept for
+                                                  the backward); backward = read */
+    float *q_part;                             /* [n_colgroups][batch] partial head sums (forward: out; backward: in) */
+    int32_t role, reserved;                    /* forward, see CSTR_CHAIN_ROLE_* */
+} cstr_chain_net_t;
+#define CSTR_CHAIN_ROLE_PLAIN 0      /* x is complete */
+#define CSTR_CHAIN_ROLE_STORE_PI 1   /* x is complete; the column-group-0 workgroups ALSO finalise the actor head of the pi(obs) rows
+                                        and store x_pi's action columns, params, eps, logp_pi (a side job: nothing here reads them) */
+#define CSTR_CHAIN_ROLE_NEXT 2       /* x = x_next whose ACTION columns are not written yet: every workgroup finalises the actor head
+                                        of its pi(next_obs) rows for itself */
+#define CSTR_CHAIN_ROLE_NEXT_STORE 3 /* ... and the column-group-0 workgroups store them (x_next action columns, logp_next) */
+
+/* SAC actor Linear(D, H1)-ReLU-Linear(H1, H2)-ReLU-[mu | log_std](H2, 2A) (core/sac/policies.py:84-175), heads merged. */
+typedef struct cstr_sac_actor {
+    int32_t obs_dim, act_dim, h1, h2;
+    const float *w1, *b1, *w2, *b2, *hw, *hb; /* hw [2A][H2], hb [2A] */
+} cstr_sac_actor_t;
+
+/* SAC.train's actor passes pi(obs) (core/sac/sac.py:222) and pi(next_obs) (:247) as ONE launch over 2B rows (rows [0, B) = obs,
+ * [B, 2B) = next_obs): ReplayBuffer.sample's gather (sample_idx = the (row, env) pairs drawn by cstr_rollout_step_f32, or NULL:
+ * the observation columns of x_pi / x_next are already filled) + layer 1 (recomputed per workgroup) + layer 2 (one MFMA column
+ * group per workgroup) + PARTIAL head sums head_part [n_colgroups][2B][2A] (n_colgroups = ceil(H2 / (16 * tiles))). With sample_idx
+ * the column-group-0 workgroups also materialise the packed batch (cstr_linear_act_fwd_gather_f32's contract: x_data, the
+ * observation columns of x_pi / x_next, rewards, dones * (1 - timeouts)) and thread 0 performs the control-word updates.
+ * a_h1 [B][H1], a_h2 [B][H2]: the pi(obs) rows' activations, kept for cstr_sac_actor_chain_bwd_f32. */
+int cstr_sac_actor_chain_fwd_f32(const cstr_sac_actor_t *actor, const cstr_ring_t *ring, int64_t *ring_ctl, int advance_ring,
+                                 uint64_t *rollout_rng_ctl, uint64_t rollout_rng_advance, const int32_t *sample_idx, int64_t batch,
+                                 float *x_data, float *x_pi, float *x_next, float *out_done, float *out_rew, float *a_h1, float *a_h2,
+                                 float *head_part, int tiles, cstr_stream_t stream);
+
+/* How a consumer launch turns the actor's head partials into actions (core/common/distributions.py:207-260, the arithmetic of
+ * cstr_gaussian_head_gemm_fwd_f32): params = sum of partials + hb; u = mean + exp(clamp(log_std)) * eps; a = tanh(u); log-prob.
+ * eps: eps_in [2B][A] (teacher-forced) or Philox4x32-10 / Box-Muller with counter = rng_ctl[1] + row (row in [0, 2B): the stream
+ * positions of cstr_gaussian_head_gemm_fwd_f32 on the 2B-row pass). rng_ctl is only READ by the forward chain; the backward chain
+ * launch behind it advances the offset (cstr_chain_root_t.rng_ctl). */
+typedef struct cstr_sac_head_fin {
+    const float *head_part; /* [n_parts][2B][2A] */
+    const float *hb;        /* [2A] */
+    const float *eps_in;    /* [2B][A] or NULL */
+    const uint64_t *rng_ctl;
+    int32_t n_parts, act_dim, obs_dim, reserved;
+    float *x_pi, *x_next;   /* [B][D + A]: action columns written by the STORE roles */
+    float *params, *eps_out, *logp_pi, *logp_next; /* [B][2A], [B][A], [B], [B] */
+} cstr_sac_head_fin_t;
+
+/* Forward of n_nets <= 4 Q networks on `batch` rows each in ONE launch: layer 1 recomputed per workgroup (K = W <= 12), layer 2 one
+ * MFMA column group per workgroup, head as partial sums q_part [n_colgroups][batch]. SAC / TD3 critic step: nets 0, 1 = the critic on
+ * x_data, nets 2, 3 = the target on x_next (core/sac/sac.py:250, :258; core/td3/td3.py:173, :179); actor loss: the critic on x_pi
+ * (:273). `fin` (or NULL): the SAC actor's pending head (roles above). */
+int cstr_q_chain_fwd_f32(const cstr_chain_net_t *nets, int n_nets, int w_in, int h1, int h2, int64_t batch, const cstr_sac_head_fin_t *fin,
+                         int tiles, cstr_stream_t stream);
+
+/* Loss root + backward of the twin Q networks in ONE launch (what cstr_hidden_head_bwd_root_f32 + cstr_linear_bwd_input_f32 did in
+ * two or three): per workgroup q = sum of partials + b3, d(loss)/dq of its 16 rows (cstr_head_root_t's modes and arithmetic:
+ * 1 = TD critic loss, 2 = SAC actor loss, 3 = -mean(Q1)), dz2 = dq * w3 * relu'(h2) recomputed (element-wise), one MFMA column group
+ * of dz1 = (dz2 W2) * relu'(h1), and -- when gact_part is given (the actor loss: the critic is frozen) -- partial sums of
+ * d(loss)/d(action) = dz1 W1[:, obs_dim:], gact_part [n_nets][n_colgroups][batch][A]. ONE extra workgroup does the batch reductions
+ * (logged loss, entropy-coefficient part) and advances the actor's Philox offset. */
+typedef struct cstr_chain_root {
+    int32_t mode, batch;
+    float gamma, scale;
+    const float *q_part[CSTR_CHAIN_MAX_NETS]; /* nets 0, 1: q1 / q2 (the differentiated networks); 2, 3: q1_t / q2_t (mode 1) */
+    const float *b3[CSTR_CHAIN_MAX_NETS];
+    int32_t n_parts, reserved;
+    const float *next_logp, *rew, *done;  /* mode 1 */
+    const float *ent_coef;                /* [1]: mode 1 without alpha part, mode 2 */
+    const float *logp;                    /* mode 2: log pi(a|obs) */
+    float *target_out;                    /* mode 1, [batch] or NULL */
+    float *q_out;                         /* [2][batch] finalised q1 / q2 (mode 3: [1][batch]) or NULL */
+    float *gq_out;                        /* [2][batch] d(loss)/dq (the head's dW3 / db3 operand) or NULL */
+    float *loss_out, *loss_sum;           /* [1] or NULL */
+    cstr_alpha_part_t alpha;              /* mode 1: log_alpha NULL = absent */
+    uint64_t *rng_ctl;                    /* or NULL: rng_ctl[1] += rng_advance by the loss workgroup */
+    uint64_t rng_advance;
+} cstr_chain_root_t;
+int cstr_q_chain_bwd_f32(const cstr_chain_net_t *nets, int n_nets, const cstr_chain_root_t *root, int w_in, int obs_dim, int h1, int h2,
+                         float *dz2, float *dz1, float *gact_part, int tiles, cstr_stream_t stream);
+
+/* Backward of the SAC actor from the critic's action-gradient partials in ONE launch (cstr_gaussian_head_bwd_input_f32 +
+ * cstr_linear_bwd_input_f32): d(loss)/d(action) = sum of gact_part over networks and column groups; d(loss)/d(logp) = ent_coef / B
+ * (core/sac/sac.py:275); the squashed-Gaussian head's analytic backward -> g_params [B][2A]; dz2 = (g_params hw) * relu'(a_h2)
+ * recomputed (2A terms per element); one MFMA column group of dz1 = (dz2 W2) * relu'(a_h1). */
+int cstr_sac_actor_chain_bwd_f32(const cstr_sac_actor_t *actor, const float *gact_part, int n_nets, int n_parts, const float *ent_coef,
+                                 const float *x_pi, const float *params, const float *eps, const float *a_h1, const float *a_h2,
+                                 float *g_params, float *dz2, float *dz1, int64_t batch, int tiles, cstr_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -24,6 +24,7 @@ SYMBOLS = (
     "cstr_td_target_min_f32", "cstr_polyak_f32", "cstr_adam_f32", "cstr_bias_act_fwd_f32", "cstr_bias_act_bwd_f32", "cstr_bias_act_bwd_rows_f32",
     "cstr_squashed_gaussian_fwd_f32", "cstr_squashed_gaussian_bwd_f32", "cstr_sac_alpha_f32", "cstr_twin_q_loss_f32",
     "cstr_sac_actor_loss_f32", "cstr_neg_mean_loss_f32",
+    "cstr_sac_actor_chain_fwd_f32", "cstr_q_chain_fwd_f32", "cstr_q_chain_bwd_f32", "cstr_sac_actor_chain_bwd_f32",
 )
 
 
@@ -83,6 +84,34 @@ class PolicyMlp(C.Structure):
                 ("b2", C.c_void_p), ("w3", C.c_void_p), ("b3", C.c_void_p), ("w2_swizzled", C.c_void_p)]
 
 
+CHAIN_MAX_NETS, CHAIN_MAX_WIDTH = 4, 512
+CHAIN_ROLE_PLAIN, CHAIN_ROLE_STORE_PI, CHAIN_ROLE_NEXT, CHAIN_ROLE_NEXT_STORE = 0, 1, 2, 3
+
+
+class ChainNet(C.Structure):
+    """cstr_chain_net_t"""
+    _fields_ = [(n, C.c_void_p) for n in ("w1", "b1", "w2", "b2", "w3", "b3", "x", "h1", "h2", "q_part")] + [("role", C.c_int32), ("reserved", C.c_int32)]
+
+
+class SacActorNet(C.Structure):
+    """cstr_sac_actor_t"""
+    _fields_ = [(n, C.c_int32) for n in ("obs_dim", "act_dim", "h1", "h2")] + [(n, C.c_void_p) for n in ("w1", "b1", "w2", "b2", "hw", "hb")]
+
+
+class SacHeadFin(C.Structure):
+    """cstr_sac_head_fin_t"""
+    _fields_ = [(n, C.c_void_p) for n in ("head_part", "hb", "eps_in", "rng_ctl")] + [(n, C.c_int32) for n in ("n_parts", "act_dim", "obs_dim", "reserved")] + [
+        (n, C.c_void_p) for n in ("x_pi", "x_next", "params", "eps_out", "logp_pi", "logp_next")]
+
+
+class ChainRoot(C.Structure):
+    """cstr_chain_root_t"""
+    _fields_ = [("mode", C.c_int32), ("batch", C.c_int32), ("gamma", C.c_float), ("scale", C.c_float), ("q_part", C.c_void_p * 4),
+                ("b3", C.c_void_p * 4), ("n_parts", C.c_int32), ("reserved", C.c_int32)] + [
+        (n, C.c_void_p) for n in ("next_logp", "rew", "done", "ent_coef", "logp", "target_out", "q_out", "gq_out", "loss_out", "loss_sum")] + [
+        ("alpha", AlphaPart), ("rng_ctl", C.c_void_p), ("rng_advance", C.c_uint64)]
+
+
 class VecNormCfg(C.Structure):
     """cstr_vecnorm_cfg_t"""
     _fields_ = [("training", C.c_int32), ("norm_obs", C.c_int32), ("norm_reward", C.c_int32), ("obs_dim", C.c_int32),
@@ -115,7 +144,7 @@ def lib() -> C.CDLL:
             raise NativeError(f"{LIB_PATH} does not export {missing}")
         l.cstr_error_string.restype = C.c_char_p
         l.cstr_default_coef.restype = None
-        if l.cstr_abi_version() != 4:
+        if l.cstr_abi_version() != 5:
             raise NativeError("libcstr_rl_hip.so ABI version mismatch")
         _lib = l
     return _lib

@@ -1,0 +1,171 @@
+"""SAC.train's gradient step on the row-chain kernels (csrc/cstr_chain.hip): 10 launches instead of 20.
+
+    reference statement (core/sac/sac.py)                              launch
+    :215 sample (gather) + :222 pi(obs) + :247 pi(next_obs)             cstr_sac_actor_chain_fwd_f32      (head left as partial sums)
+    :250 target critics + :258 critics (actor head finalised inside)    cstr_q_chain_fwd_f32, 4 networks  (Q heads left as partial sums)
+    :230-261 entropy-coefficient loss, TD target, critic loss, critic
+             backward to dz                                             cstr_q_chain_bwd_f32, mode 1
+    :266-267 critic dW / db (6 layers)                                  cstr_linear_bwd_weight_sets_f32
+    :240-243, :268 entropy-coefficient + critic Adam steps              cstr_adam_multi_f32
+    :273 critics on (obs, pi(obs))                                      cstr_q_chain_fwd_f32, 2 networks
+    :275 actor loss + backward through the frozen critics to the action cstr_q_chain_bwd_f32, mode 2      (action gradient as partial sums)
+    :279-280 backward of the squashed-Gaussian head and the actor       cstr_sac_actor_chain_bwd_f32
+    :280 actor dW / db (3 layers)                                       cstr_linear_bwd_weight_sets_f32
+    :281 actor Adam step + :284-287 soft update of the target critics   cstr_adam_multi_f32
+
+The data-parallel all-reduces keep their places (between the dW / db launch and the Adam launch of each arena). Shapes the chain
+kernels do not cover (other activations, widths that are not multiples of 4 or above 512, batches that are not multiples of 16, a
+VecNormalize normaliser, n_critics != 2) stay on the per-layer fused path (core/common/fused.py). CSTR_CHAIN=0 turns this path off.
+"""
+import os
+from typing import Optional
+
+import torch as th
+from torch import nn
+
+from core import _native as nv
+from core.common import fused, hip_ops
+
+USE_CHAIN = os.environ.get("CSTR_CHAIN", "1") != "0"
+# 16-column MFMA tiles per workgroup: actor forward, Q forward (4 networks), Q forward (2 networks), Q backward, actor backward
+TILES = tuple(int(v) for v in os.environ.get("CSTR_CHAIN_TILES", "2,4,2,2,1").split(","))
+
+
+def _q_layers(qnet: nn.Sequential):
+    lin = [m for m in qnet if isinstance(m, nn.Linear)]
+    return tuple((m.weight, m.bias) for m in lin)
+
+
+class SacChain:
+    """Buffers + launch sequence of one SAC gradient step on the chain kernels. Built once per (model, batch size)."""
+
+    @staticmethod
+    def supported(model, batch_size: int) -> bool:
+        if not (USE_CHAIN and fused.USE_FUSED_LINEAR and model.fused_learner and model._use_packed_batch()):
+            return False
+        fa = model._fast_actor
+        layers = fa.latent.layers
+        if len(layers) != 2 or any(act != fused.ACT_RELU for _, act in layers) or fa.head is None or not fa._hw.is_contiguous():
+            return False
+        for q in list(model.critic.q_networks) + list(model.critic_target.q_networks):
+            mods = list(q)
+            if len(mods) != 5 or not all(isinstance(mods[i], nn.Linear) for i in (0, 2, 4)) or not all(isinstance(mods[i], nn.ReLU) for i in (1, 3)):
+                return False
+            if mods[4].out_features != 1:
+                return False
+        (l1, _), (l2, _) = layers
+        c1, c2 = model.critic.q_networks[0][0], model.critic.q_networks[0][2]
+        d, a = l1.in_features, fa.act_dim
+        if (d, a) not in hip_ops.LAYOUTS or c1.in_features != d + a:
+            return False
+        return (hip_ops.chain_supported(l1.out_features, l2.out_features, batch_size) and hip_ops.chain_supported(c1.out_features, c2.out_features, batch_size)
+                and all(p.grad is not None for p in list(model.actor.parameters()) + list(model.critic.parameters())))
+
+    def __init__(self, model, batch_size: int):
+        fa, dev, B = model._fast_actor, model.device, batch_size
+        (l1, _), (l2, _) = fa.latent.layers
+        self.D, self.A, self.B = l1.in_features, fa.act_dim, B
+        self.W = self.D + self.A
+        self.aH1, self.aH2 = l1.out_features, l2.out_features
+        c = model.critic.q_networks[0]
+        self.cH1, self.cH2 = c[0].out_features, c[2].out_features
+        self.t_act, self.t_q4, self.t_q2, self.t_qb, self.t_ab = TILES
+        self.actor = hip_ops.sac_actor_desc(self.D, self.A, l1.weight, l1.bias, l2.weight, l2.bias, fa._hw, fa._hb)
+        self.actor_layers = (l1, l2)
+        self.crit = [_q_layers(q) for q in model.critic.q_networks]
+        self.targ = [_q_layers(q) for q in model.critic_target.q_networks]
+        e = lambda *sh: th.empty(*sh, dtype=th.float32, device=dev)  # noqa: E731
+        A, H1, H2 = self.A, self.aH1, self.aH2
+        self.n_head_parts = hip_ops.chain_colgroups(H2, self.t_act)
+        self.a_h1, self.a_h2, self.head_part = e(B, H1), e(B, H2), e(self.n_head_parts, 2 * B, 2 * A)
+        self.params, self.eps, self.logp_pi, self.logp_next = e(B, 2 * A), e(B, A), e(B), e(B)
+        self.c_h1, self.c_h2 = e(2, B, self.cH1), e(2, B, self.cH2)
+        self.n_q4, self.n_q2 = hip_ops.chain_colgroups(self.cH2, self.t_q4), hip_ops.chain_colgroups(self.cH2, self.t_q2)
+        self.q_part4, self.q_part2 = e(4, self.n_q4, B), e(2, self.n_q2, B)
+        self.q_out, self.qpi_out, self.gq = e(2, B), e(2, B), e(2, B)
+        self.dz2c, self.dz1c = e(2, B, self.cH2), e(2, B, self.cH1)
+        self.n_gact = hip_ops.chain_colgroups(self.cH1, self.t_qb)
+        self.gact_part = e(2, self.n_gact, B, A)
+        self.g_params, self.dz2a, self.dz1a = e(B, 2 * A), e(B, H2), e(B, H1)
+
+    def step(self, model, pb, gather, gradient_step: int) -> None:
+        s, pol, B, W, D, A = model._loss_sums, model.policy, self.B, self.W, self.D, self.A
+        fa = model._fast_actor
+        single = getattr(model, "_single_step", False)
+        acc = (lambda k: None) if single else (lambda k: s[k])
+        sto = (lambda k, other: s[k]) if single else (lambda k, other: other)
+        rd = pb.samples
+        dist = fa.actor.action_dist
+        eps2 = None
+        if dist.eps_queue:  # teacher-forced draws (tests): the pi(obs) tensor was queued first
+            eps2 = th.cat((dist.draw_eps((B, A), model.device), dist.draw_eps((B, A), model.device)), dim=0).contiguous()
+        elif fa.rng_ctl is None:
+            fa.rng_ctl = hip_ops.new_rng_ctl(th.initial_seed(), model.device)
+        # -- pi(obs) and pi(next_obs): gather + layers 1, 2 + head partials
+        if gather is not None:
+            ring, idx, rng_advance, _ = gather
+            hip_ops.sac_actor_chain_fwd(self.actor, B, pb.x_data, pb.x_pi, pb.x_next, rd.dones, rd.rewards, self.a_h1, self.a_h2, self.head_part,
+                                        self.t_act, ring=ring, sample_idx=idx, advance_ring=True, rng_advance=rng_advance)
+        else:
+            hip_ops.sac_actor_chain_fwd(self.actor, B, None, pb.x_pi, pb.x_next, None, None, self.a_h1, self.a_h2, self.head_part, self.t_act)
+        # -- critics on x_data, target critics on x_next (its action columns finalised inside the launch)
+        fin = nv.SacHeadFin(self.head_part.data_ptr(), fa._hb.data_ptr(), None if eps2 is None else eps2.data_ptr(),
+                            None if eps2 is not None else fa.rng_ctl.data_ptr(), self.n_head_parts, A, D, 0, pb.x_pi.data_ptr(), pb.x_next.data_ptr(),
+                            self.params.data_ptr(), self.eps.data_ptr(), self.logp_pi.data_ptr(), self.logp_next.data_ptr())
+        self._keep = eps2  # alive until the launches that read it have been issued (and recorded)
+        nets4 = [hip_ops.chain_net(self.crit[0], pb.x_data, self.c_h1[0], self.c_h2[0], self.q_part4[0], nv.CHAIN_ROLE_STORE_PI),
+                 hip_ops.chain_net(self.crit[1], pb.x_data, self.c_h1[1], self.c_h2[1], self.q_part4[1], nv.CHAIN_ROLE_PLAIN),
+                 hip_ops.chain_net(self.targ[0], pb.x_next, None, None, self.q_part4[2], nv.CHAIN_ROLE_NEXT_STORE),
+                 hip_ops.chain_net(self.targ[1], pb.x_next, None, None, self.q_part4[3], nv.CHAIN_ROLE_NEXT)]
+        hip_ops.q_chain_fwd(nets4, W, self.cH1, self.cH2, B, self.t_q4, fin)
+        # -- entropy-coefficient loss, TD target, critic loss and the critic backward down to dz1
+        if model.ent_coef_optimizer is not None:
+            ent_coef = s["ent_coef"] if single else model._ent_coef_buf
+            alpha = dict(log_alpha=model.log_ent_coef.detach(), logp_pi=self.logp_pi, target_entropy=model.target_entropy,
+                         grad_out=model._ent_arena.grad[0:1], ent_coef_out=ent_coef, loss_out=s["ent_coef_loss"] if single else None,
+                         loss_sum=acc("ent_coef_loss"), ent_coef_sum=acc("ent_coef"))
+        else:
+            ent_coef, alpha = model.ent_coef_tensor.reshape(1), None
+            s["ent_coef"] += ent_coef
+        b3s = [self.crit[0][2][1], self.crit[1][2][1], self.targ[0][2][1], self.targ[1][2][1]]
+        root = hip_ops.chain_root("td", B, [self.q_part4[g] for g in range(4)], b3s, self.n_q4, gamma=model.gamma, scale=0.5,
+                                  next_logp=self.logp_next, rew=rd.rewards, done=rd.dones, ent_coef=ent_coef, target_out=model._target_q,
+                                  q_out=self.q_out, gq_out=self.gq, loss_out=sto("critic", model._loss_now["critic"]), loss_sum=acc("critic"),
+                                  alpha=alpha, rng_advance=None if eps2 is not None else (fa.rng_ctl, 2 * B))
+        back = [hip_ops.chain_net(self.crit[g], None, self.c_h1[g], self.c_h2[g]) for g in range(2)]
+        hip_ops.q_chain_bwd(back, root, W, D, self.cH1, self.cH2, self.t_qb, dz2=self.dz2c, dz1=self.dz1c)
+        sets = []
+        for g in range(2):
+            (w1, b1), (w2, b2), (w3, b3) = self.crit[g]
+            sets += [(self.dz1c[g], pb.x_data, w1.grad, b1.grad), (self.dz2c[g], self.c_h1[g], w2.grad, b2.grad),
+                     (self.gq[g].view(B, 1), self.c_h2[g], w3.grad, b3.grad)]
+        hip_ops.linear_bwd_weight_sets(sets)
+        if model.ent_coef_optimizer is not None and not model._ent_rides_critic:
+            model._allreduce_grads(model._ent_arena)
+            model.ent_coef_optimizer.step()
+        model._allreduce_grads(pol.critic_arena)
+        if model.ent_coef_optimizer is not None and model._ent_rides_critic:
+            model.critic.optimizer.step_with(model.ent_coef_optimizer)
+        else:
+            model.critic.optimizer.step()
+        # -- actor loss through the (updated, frozen) critics
+        nets2 = [hip_ops.chain_net(self.crit[g], pb.x_pi, self.c_h1[g], self.c_h2[g], self.q_part2[g]) for g in range(2)]
+        hip_ops.q_chain_fwd(nets2, W, self.cH1, self.cH2, B, self.t_q2)
+        aroot = hip_ops.chain_root("sac_actor", B, [self.q_part2[0], self.q_part2[1]], b3s[:2], self.n_q2, ent_coef=ent_coef, logp=self.logp_pi,
+                                   q_out=self.qpi_out, loss_out=sto("actor", model._loss_now["actor"]), loss_sum=acc("actor"))
+        hip_ops.q_chain_bwd(back, aroot, W, D, self.cH1, self.cH2, self.t_qb, gact_part=self.gact_part)
+        hip_ops.sac_actor_chain_bwd(self.actor, self.gact_part, 2, self.n_gact, ent_coef, pb.x_pi, self.params, self.eps, self.a_h1, self.a_h2,
+                                    self.g_params, self.dz2a, self.dz1a, B, self.t_ab)
+        l1, l2 = self.actor_layers
+        hip_ops.linear_bwd_weight_sets([(self.dz1a, pb.x_pi[:, :D], l1.weight.grad, l1.bias.grad), (self.dz2a, self.a_h1, l2.weight.grad, l2.bias.grad),
+                                        (self.g_params, self.a_h2, fa._hwg, fa._hbg)])
+        model._allreduce_grads(pol.actor_arena)
+        if gradient_step % model.target_update_interval == 0:  # :281 and :284-287 (disjoint arenas) in one launch
+            model.actor.optimizer.step_with(polyak=(pol.critic_arena, pol.critic_target_arena, model.tau))
+        else:
+            model.actor.optimizer.step()
+        if model.debug_capture:
+            model.last_train_tensors = dict(target_q=model._target_q.clone(), current_q=[self.q_out[0].clone().view(B, 1), self.q_out[1].clone().view(B, 1)],
+                                            critic_loss=sto("critic", model._loss_now["critic"]).clone(),
+                                            actor_loss=sto("actor", model._loss_now["actor"]).clone(),
+                                            ent_coef=ent_coef.detach().clone(), log_prob=self.logp_pi.clone())

@@ -11,6 +11,7 @@ Under hipGraph replay the collectives are recorded into the iteration's graph wh
 capture-and-replay trial on every rank) passes, and stay between graph segments otherwise
 (OffPolicyAlgorithm._capture_segments; CSTR_GRAPH_COLLECTIVES=auto|0|1).
 """
+import datetime
 import os
 import sys
 from typing import Optional, Tuple
@@ -40,11 +41,14 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend is None:
             backend = "nccl" if th.cuda.is_available() else "gloo"
+        # a rank that never shows up (died during start-up) must fail the rendezvous / the first collective in minutes, not
+        # after the backend's default (10 min RCCL, 30 min gloo)
+        timeout = datetime.timedelta(seconds=float(os.environ.get("CSTR_DIST_TIMEOUT_S", "120")))
         if backend == "nccl":
             th.cuda.set_device(local_rank)
-            dist.init_process_group(backend, rank=rank, world_size=world, device_id=th.device("cuda", local_rank))
+            dist.init_process_group(backend, rank=rank, world_size=world, device_id=th.device("cuda", local_rank), timeout=timeout)
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            dist.init_process_group(backend, rank=rank, world_size=world, timeout=timeout)
     return rank, local_rank, world
 
 

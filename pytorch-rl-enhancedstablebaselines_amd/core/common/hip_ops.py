@@ -18,6 +18,8 @@ def _chk(t: th.Tensor, name: str, shape, dtype) -> th.Tensor:
         raise TypeError(f"{name}: expected a torch.Tensor, got {type(t)}")
     if not t.is_cuda:
         raise ValueError(f"{name}: must live in HBM (device tensor); got device {t.device}. No CPU fallback exists.")
+    if t.device.index != th.cuda.current_device():  # a pointer from another GPU must never reach a launch on this one
+        raise ValueError(f"{name}: lives on {t.device}, the current device is cuda:{th.cuda.current_device()}")
     if t.dtype != dtype:
         raise ValueError(f"{name}: dtype {t.dtype}, expected {dtype}")
     if tuple(t.shape) != tuple(shape):
@@ -882,3 +884,93 @@ def neg_mean_loss(q, gq, loss_out=None, loss_sum=None):
     _vec(q, "q", b), _vec(gq, "gq", b)
     check(nv.lib().cstr_neg_mean_loss_f32(ptr(q), ptr(gq), ptr(loss_out), ptr(loss_sum), C.c_int64(b), stream_ptr()),
           "cstr_neg_mean_loss_f32")
+
+
+# ---- row-chain kernels (csrc/cstr_chain.hip, include/cstr_rl_hip.h "row-chain kernels") -------------------------------------------
+def chain_supported(h1: int, h2: int, batch: int) -> bool:
+    return (16 <= h1 <= nv.CHAIN_MAX_WIDTH and 16 <= h2 <= nv.CHAIN_MAX_WIDTH and h1 % 4 == 0 and h2 % 4 == 0
+            and 16 <= batch <= 1024 and batch % 16 == 0)
+
+
+def chain_colgroups(width: int, tiles: int) -> int:
+    return (width + 16 * tiles - 1) // (16 * tiles)
+
+
+def _dp(t):
+    return None if t is None else t.data_ptr()
+
+
+def sac_actor_desc(obs_dim: int, act_dim: int, w1, b1, w2, b2, hw, hb) -> "nv.SacActorNet":
+    h1, h2 = w1.shape[0], w2.shape[0]
+    for t, nm, shape in ((w1, "w1", (h1, obs_dim)), (b1, "b1", (h1,)), (w2, "w2", (h2, h1)), (b2, "b2", (h2,)), (hw, "hw", (2 * act_dim, h2)),
+                         (hb, "hb", (2 * act_dim,))):
+        _chk(t, nm, shape, th.float32)
+    return nv.SacActorNet(obs_dim, act_dim, h1, h2, w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), hw.data_ptr(), hb.data_ptr())
+
+
+def sac_actor_chain_fwd(actor: "nv.SacActorNet", batch: int, x_data, x_pi, x_next, out_done, out_rew, a_h1, a_h2, head_part, tiles: int,
+                        ring: Optional[DeviceRing] = None, sample_idx=None, advance_ring: bool = False, rng_advance=None):
+    """cstr_sac_actor_chain_fwd_f32: gather (or packed observation columns) + layer 1 + layer 2 + head partials of the 2B-row actor pass."""
+    w = actor.obs_dim + actor.act_dim
+    ncg = chain_colgroups(actor.h2, tiles)
+    for t, nm in ((x_pi, "x_pi"), (x_next, "x_next")):
+        if not (t.is_cuda and t.dtype == th.float32 and tuple(t.shape) == (batch, w) and t.stride() == (w, 1)):
+            raise ValueError(f"{nm}: needs a float32 device matrix [{batch}, {w}] with row stride {w}")
+    _chk(a_h1, "a_h1", (batch, actor.h1), th.float32), _chk(a_h2, "a_h2", (batch, actor.h2), th.float32)
+    _chk(head_part, "head_part", (ncg, 2 * batch, 2 * actor.act_dim), th.float32)
+    rc_ptr, adv = (None, 0) if rng_advance is None else (rng_advance[0].data_ptr(), int(rng_advance[1]))
+    if sample_idx is not None:
+        _chk(sample_idx, "sample_idx", (2, batch), th.int32)
+        _chk(x_data, "x_data", (batch, w), th.float32), _chk(out_done, "out_done", (batch, 1), th.float32), _chk(out_rew, "out_rew", (batch, 1), th.float32)
+    check(nv.lib().cstr_sac_actor_chain_fwd_f32(C.byref(actor), None if ring is None else C.byref(ring.c), None if ring is None else ptr(ring.ctl),
+                                                C.c_int(1 if advance_ring else 0), C.c_void_p(rc_ptr), C.c_uint64(adv), ptr(sample_idx),
+                                                C.c_int64(batch), ptr(x_data), ptr(x_pi), ptr(x_next), ptr(out_done), ptr(out_rew), ptr(a_h1),
+                                                ptr(a_h2), ptr(head_part), C.c_int(tiles), stream_ptr()), "cstr_sac_actor_chain_fwd_f32")
+
+
+def chain_net(layers, x=None, h1=None, h2=None, q_part=None, role: int = 0) -> "nv.ChainNet":
+    """layers = ((w1, b1), (w2, b2), (w3, b3)) of one Q network."""
+    (w1, b1), (w2, b2), (w3, b3) = layers
+    return nv.ChainNet(w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), w3.data_ptr(), b3.data_ptr(), _dp(x), _dp(h1), _dp(h2),
+                       _dp(q_part), role, 0)
+
+
+def q_chain_fwd(nets, w_in: int, h1: int, h2: int, batch: int, tiles: int, fin: Optional["nv.SacHeadFin"] = None):
+    """cstr_q_chain_fwd_f32: n_nets Q networks (layer 1 recomputed, layer 2 one MFMA column group per workgroup, head as partials)."""
+    arr = (nv.ChainNet * len(nets))(*nets)
+    check(nv.lib().cstr_q_chain_fwd_f32(arr, C.c_int(len(nets)), C.c_int(w_in), C.c_int(h1), C.c_int(h2), C.c_int64(batch),
+                                        None if fin is None else C.byref(fin), C.c_int(tiles), stream_ptr()), "cstr_q_chain_fwd_f32")
+
+
+def chain_root(mode: str, batch: int, q_parts, b3s, n_parts: int, gamma: float = 0.0, scale: float = 0.0, next_logp=None, rew=None, done=None,
+               ent_coef=None, logp=None, target_out=None, q_out=None, gq_out=None, loss_out=None, loss_sum=None, alpha: Optional[dict] = None,
+               rng_advance=None) -> "nv.ChainRoot":
+    part = nv.AlphaPart()
+    if alpha is not None:
+        part = nv.AlphaPart(alpha["log_alpha"].data_ptr(), alpha["logp_pi"].data_ptr(), float(alpha["target_entropy"]), alpha["grad_out"].data_ptr(),
+                            alpha["ent_coef_out"].data_ptr(), *(_dp(alpha.get(k)) for k in ("loss_out", "loss_sum", "ent_coef_sum")))
+    qp, bb = (C.c_void_p * 4)(), (C.c_void_p * 4)()
+    for i, (q, b) in enumerate(zip(q_parts, b3s)):
+        qp[i], bb[i] = q.data_ptr(), b.data_ptr()
+    rc_ptr, adv = (None, 0) if rng_advance is None else (rng_advance[0].data_ptr(), int(rng_advance[1]))
+    return nv.ChainRoot({"td": 1, "sac_actor": 2, "neg_mean": 3}[mode], batch, float(gamma), float(scale), qp, bb, n_parts, 0, _dp(next_logp), _dp(rew),
+                        _dp(done), None if alpha is not None else _dp(ent_coef), _dp(logp), _dp(target_out), _dp(q_out), _dp(gq_out), _dp(loss_out),
+                        _dp(loss_sum), part, rc_ptr, adv)
+
+
+def q_chain_bwd(nets, root: "nv.ChainRoot", w_in: int, obs_dim: int, h1: int, h2: int, tiles: int, dz2=None, dz1=None, gact_part=None):
+    """cstr_q_chain_bwd_f32: loss root + dz2 (recomputed) + one column group of dz1 (+ partial action gradients)."""
+    arr = (nv.ChainNet * len(nets))(*nets)
+    check(nv.lib().cstr_q_chain_bwd_f32(arr, C.c_int(len(nets)), C.byref(root), C.c_int(w_in), C.c_int(obs_dim), C.c_int(h1), C.c_int(h2), ptr(dz2),
+                                        ptr(dz1), ptr(gact_part), C.c_int(tiles), stream_ptr()), "cstr_q_chain_bwd_f32")
+
+
+def sac_actor_chain_bwd(actor: "nv.SacActorNet", gact_part, n_nets: int, n_parts: int, ent_coef, x_pi, params, eps, a_h1, a_h2, g_params, dz2, dz1,
+                        batch: int, tiles: int):
+    """cstr_sac_actor_chain_bwd_f32: action gradient from the critic's partials, Gaussian head backward, dz2 (recomputed), dz1 column group."""
+    _chk(gact_part, "gact_part", (n_nets, n_parts, batch, actor.act_dim), th.float32)
+    _chk(g_params, "g_params", (batch, 2 * actor.act_dim), th.float32), _chk(dz2, "dz2", (batch, actor.h2), th.float32)
+    _chk(dz1, "dz1", (batch, actor.h1), th.float32)
+    check(nv.lib().cstr_sac_actor_chain_bwd_f32(C.byref(actor), ptr(gact_part), C.c_int(n_nets), C.c_int(n_parts), ptr(ent_coef), ptr(x_pi), ptr(params),
+                                                ptr(eps), ptr(a_h1), ptr(a_h2), ptr(g_params), ptr(dz2), ptr(dz1), C.c_int64(batch), C.c_int(tiles),
+                                                stream_ptr()), "cstr_sac_actor_chain_bwd_f32")

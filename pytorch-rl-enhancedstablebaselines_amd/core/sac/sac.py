@@ -174,6 +174,13 @@ class SAC(OffPolicyAlgorithm):
         acc = (lambda k: None) if single else (lambda k: s[k])  # accumulate into the sums ...
         sto = (lambda k, other: s[k]) if single else (lambda k, other: other)  # ... or store straight into them
         pb, gather = None, None
+        chain = self._chain_for(batch_size)
+        if chain is not None:  # the row-chain kernels (core/common/chain.py): 10 launches instead of 20
+            pb = self._packed_batch(batch_size)
+            gather = self.replay_buffer.take_predrawn(pb) if fused.USE_GATHER_IN_FIRST_LAYER else None
+            if gather is None:
+                self.replay_buffer.sample_packed_into(pb)  # :215 + the critics' cat([obs, act])
+            return chain.step(self, pb, gather, gradient_step)
         if self._use_packed_batch():
             pb = self._packed_batch(batch_size)
             if fused.USE_GATHER_IN_FIRST_LAYER and self._fast_actor.pair_supported(pb):
@@ -278,6 +285,18 @@ class SAC(OffPolicyAlgorithm):
                                            critic_loss=sto("critic", self._loss_now["critic"]).clone(),
                                            actor_loss=sto("actor", self._loss_now["actor"]).clone(),
                                            ent_coef=ent_coef.detach().clone(), log_prob=log_prob.detach().clone())
+
+    def _chain_for(self, batch_size: int):
+        """The row-chain form of the gradient step for this batch size (core/common/chain.py), or None: per-layer fused path."""
+        from core.common import chain
+
+        cache = self.__dict__.setdefault("_chain_cache", {})
+        key = (batch_size, chain.USE_CHAIN, fused.USE_FUSED_LINEAR)
+        if key not in cache:
+            cache[key] = chain.SacChain(self, batch_size) if chain.SacChain.supported(self, batch_size) else None
+        if cache[key] is not None and len(self.actor.action_dist.eps_queue) not in (0, 2):
+            return None
+        return cache[key]
 
     def _gradient_step_aten(self, batch_size: int, gradient_step: int) -> None:
         """Stock-ATen evaluation of the step (nn.Module forwards, autograd losses): the fallback for configurations the

@@ -19,6 +19,7 @@
 #include "cstr_device.h"
 #include "cstr_env_device.h"
 #include "cstr_mt_device.h"
+#include "cstr_rng_device.h"
 
 namespace {
 
@@ -782,31 +783,6 @@ __global__ void squashed_gaussian_bwd_kernel(const float *__restrict__ g_action,
 // -> Box-Muller, so no ATen generator launch (and none of the two generator-state fills PyTorch issues before every replay
 // of a graph that captured torch.randn). rng_ctl = {seed, offset, ticket, -} lives in HBM; the last workgroup advances the
 // offset, so graph replays continue the stream. `action` may be a column block of a wider row (the critic's input buffer).
-__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t out[4])
-{
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
-        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
-        c1 = (uint32_t)p1; c3 = (uint32_t)p0; c0 = n0; c2 = n2;
-        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-    }
-    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
-}
-
-__device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float &z0, float &z1)
-{
-    const float u1 = ((float)(a >> 8) + 0.5f) * (1.0f / 16777216.0f);  // (0, 1): 24 random bits, never 0
-    const float u2 = ((float)(b >> 8) + 0.5f) * (1.0f / 16777216.0f);
-    // cos / sin(2 pi u2) through sincospif: one shared, exact argument reduction (the angle is given in half-turns) instead of two
-    // full-range reductions of 2 pi u2 -- the same distribution, a shorter dependent chain (the rollout's noise is drawn by ONE wave)
-    const float r = sqrtf(-2.0f * logf(u1));
-    float sn, cs;
-    sincospif(2.0f * u2, &sn, &cs);
-    z0 = r * cs;
-    z1 = r * sn;
-}
-
 __global__ __launch_bounds__(64) void gaussian_head_fwd_kernel(float *__restrict__ params, const float *__restrict__ bias,
                                                                float *__restrict__ eps, uint64_t *__restrict__ rng_ctl,
                                                                float *__restrict__ action, const int64_t action_stride,

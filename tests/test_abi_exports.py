@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/cstr_rl_hip.h but not exported"
     assert sorted(nv.SYMBOLS) == declared
-    assert lib.cstr_abi_version() == 4
+    assert lib.cstr_abi_version() == 5
 
 
 def test_error_strings():

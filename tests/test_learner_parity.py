@@ -103,16 +103,25 @@ def _make_env(n=4):
     return CSTRVecEnv(n)
 
 
-@pytest.mark.parametrize("fused_path", [True, "rocblas", False])
+@pytest.mark.parametrize("fused_path", ["chain", True, "rocblas", False])
 @pytest.mark.parametrize("tag", ["small", "default"])
 def test_sac_train_teacher_forced(golden, tag, fused_path, monkeypatch):
-    """fused_path: True = the default (hand-written MFMA Linear kernels + HIP glue); "rocblas" = the same fused glue with every
-    GEMM left to PyTorch-ROCm / rocBLAS (CSTR_FUSED_LINEAR=0); False = stock-ATen evaluation of the same statements."""
-    from core.common import fused, legacy_rng
+    """fused_path: "chain" = the default (row-chain kernels, core/common/chain.py: 10 launches per gradient step); True = the per-layer
+    fused path (hand-written MFMA Linear kernels + HIP glue, CSTR_CHAIN=0); "rocblas" = the same fused glue with every GEMM left to
+    PyTorch-ROCm / rocBLAS (CSTR_FUSED_LINEAR=0); False = stock-ATen evaluation of the same statements."""
+    from core.common import chain, fused, legacy_rng
     from core.sac import SAC
 
+    chain_calls = []
+    if fused_path == "chain":
+        assert chain.USE_CHAIN
+        orig_step = chain.SacChain.step
+        monkeypatch.setattr(chain.SacChain, "step", lambda self, *a, **k: (chain_calls.append(1), orig_step(self, *a, **k))[1])
+    else:
+        monkeypatch.setattr(chain, "USE_CHAIN", False)
     if fused_path == "rocblas":
         monkeypatch.setattr(fused, "USE_FUSED_LINEAR", False)
+    if fused_path in ("rocblas", "chain"):
         fused_path = True
 
     g = golden(f"sac_train_kat_{tag}.npz")
@@ -142,14 +151,14 @@ def test_sac_train_teacher_forced(golden, tag, fused_path, monkeypatch):
             np.testing.assert_array_equal(getattr(b, name).cpu().numpy(), g[f"step{k}/batch_{name}"], err_msg=f"step {k} batch {name}")
         t = model.last_train_tensors
         # Q-values and TD targets: 1e-5 relative (north_star)
-        lab = f"sac_{tag}_{fused_path if fused_path is not True else ('rocblas' if not fused.USE_FUSED_LINEAR else 'fused')}"
+        lab = f"sac_{tag}_{fused_path if fused_path is not True else ('rocblas' if not fused.USE_FUSED_LINEAR else 'chain' if chain_calls else 'fused')}"
         assert q_err(t["target_q"].cpu().numpy(), g[f"step{k}/target_q"], lab) < 1e-5, f"target_q step {k}"
         assert q_err(t["current_q"][0].cpu().numpy(), g[f"step{k}/current_q1"], lab) < 1e-5, f"q1 step {k}"
         assert q_err(t["current_q"][1].cpu().numpy(), g[f"step{k}/current_q2"], lab) < 1e-5, f"q2 step {k}"
         lv = model.logger.name_to_value
         for key in ("critic_loss", "actor_loss", "ent_coef_loss", "ent_coef"):
             assert rel_err(float(lv[f"train/{key}"]), float(g[f"step{k}/{key}"]), 1e-3) < 1e-5, f"{key} step {k}"
-    assert model._n_updates == n_steps
+    assert model._n_updates == n_steps and len(chain_calls) == (n_steps if chain.USE_CHAIN else 0)
     _check_weights(model, g, "after", mods, digest=(tag == "default"))
     assert abs(float(model.log_ent_coef.detach()) - float(g["after/log_ent_coef"][0])) < 1e-6
     assert model.actor.optimizer.step_count == n_steps and model.critic.optimizer.step_count == n_steps
