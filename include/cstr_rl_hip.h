@@ -516,7 +516,7 @@ int cstr_neg_mean_loss_f32(const float *q, float *gq, float *loss_out, float *lo
  * leaves the NARROW layer behind it (a Q head's H2 -> 1 dot product, the actor head's H2 -> 2A, the first layer's input gradient
  * H1 -> act_dim) as per-column-group PARTIAL sums that the next launch adds up in a fixed order in its prologue.
  * SAC.train (core/sac/sac.py:215-287) = 10 launches instead of 20; everything is deterministic (no float atomics).
- * Networks: create_mlp(in, out, [H1, H2], ReLU) (core/common/torch_layers.py:110-183); H1, H2 multiples of 4, <= 512; batch a
+ * Networks: create_mlp(in, out, [H1, H2], ReLU) (core/common/torch_layers.py:110-183); H1, H2 multiples of 16, <= 512; batch a
  * multiple of 16, <= 1024; (obs_dim, act_dim) as the ring's layouts. `tiles` = 16-column tiles per workgroup (1, 2 or 4). */
 #define CSTR_CHAIN_MAX_NETS 4
 #define CSTR_CHAIN_MAX_WIDTH 512
@@ -532,7 +532,7 @@ typedef struct cstr_chain_net {
 } cstr_chain_net_t;
 #define CSTR_CHAIN_ROLE_PLAIN 0      /* x is complete */
 #define CSTR_CHAIN_ROLE_STORE_PI 1   /* x is complete; the column-group-0 workgroups ALSO finalise the actor head of the pi(obs) rows
-                                        and store x_pi's action columns, params, eps, logp_pi (a side job: nothing here reads them) */
+                                        and store x_pi's action columns, params, logp_pi (a side job: nothing here reads them) */
 #define CSTR_CHAIN_ROLE_NEXT 2       /* x = x_next whose ACTION columns are not written yet: every workgroup finalises the actor head
                                         of its pi(next_obs) rows for itself */
 #define CSTR_CHAIN_ROLE_NEXT_STORE 3 /* ... and the column-group-0 workgroups store them (x_next action columns, logp_next) */
@@ -549,33 +549,34 @@ typedef struct cstr_sac_actor {
  * group per workgroup) + PARTIAL head sums head_part [n_colgroups][2B][2A] (n_colgroups = ceil(H2 / (16 * tiles))). With sample_idx
  * the column-group-0 workgroups also materialise the packed batch (cstr_linear_act_fwd_gather_f32's contract: x_data, the
  * observation columns of x_pi / x_next, rewards, dones * (1 - timeouts)) and thread 0 performs the control-word updates.
- * a_h1 [B][H1], a_h2 [B][H2]: the pi(obs) rows' activations, kept for cstr_sac_actor_chain_bwd_f32. */
+ * a_h1 [B][H1], a_h2 [B][H2]: the pi(obs) rows' activations, kept for cstr_sac_actor_chain_bwd_f32.
+ * eps_all [2B][A] (or NULL): the sampling head's noise, drawn HERE by an otherwise idle wave (Philox4x32-10 / Box-Muller, key =
+ * head_rng_ctl[0], counter = head_rng_ctl[1] + row, row in [0, 2B): the stream positions of cstr_gaussian_head_gemm_fwd_f32 on the
+ * 2B-row pass) -- it does not depend on the network, and the launch that finalises the head has a long enough prologue without it.
+ * head_rng_ctl is only read; the backward chain launch advances the offset (cstr_chain_root_t.rng_ctl). */
 int cstr_sac_actor_chain_fwd_f32(const cstr_sac_actor_t *actor, const cstr_ring_t *ring, int64_t *ring_ctl, int advance_ring,
                                  uint64_t *rollout_rng_ctl, uint64_t rollout_rng_advance, const int32_t *sample_idx, int64_t batch,
                                  float *x_data, float *x_pi, float *x_next, float *out_done, float *out_rew, float *a_h1, float *a_h2,
-                                 float *head_part, int tiles, cstr_stream_t stream);
+                                 float *head_part, const uint64_t *head_rng_ctl, float *eps_all, int tiles, cstr_stream_t stream);
 
 /* How a consumer launch turns the actor's head partials into actions (core/common/distributions.py:207-260, the arithmetic of
  * cstr_gaussian_head_gemm_fwd_f32): params = sum of partials + hb; u = mean + exp(clamp(log_std)) * eps; a = tanh(u); log-prob.
- * eps: eps_in [2B][A] (teacher-forced) or Philox4x32-10 / Box-Muller with counter = rng_ctl[1] + row (row in [0, 2B): the stream
- * positions of cstr_gaussian_head_gemm_fwd_f32 on the 2B-row pass). rng_ctl is only READ by the forward chain; the backward chain
- * launch behind it advances the offset (cstr_chain_root_t.rng_ctl). */
+ * eps [2B][A]: the actor chain launch's eps_all, or teacher-forced draws. */
 typedef struct cstr_sac_head_fin {
     const float *head_part; /* [n_parts][2B][2A] */
     const float *hb;        /* [2A] */
-    const float *eps_in;    /* [2B][A] or NULL */
-    const uint64_t *rng_ctl;
+    const float *eps;       /* [2B][A] */
     int32_t n_parts, act_dim, obs_dim, reserved;
     float *x_pi, *x_next;   /* [B][D + A]: action columns written by the STORE roles */
-    float *params, *eps_out, *logp_pi, *logp_next; /* [B][2A], [B][A], [B], [B] */
+    float *params, *logp_pi, *logp_next; /* [B][2A], [B], [B] */
 } cstr_sac_head_fin_t;
 
 /* Forward of n_nets <= 4 Q networks on `batch` rows each in ONE launch: layer 1 recomputed per workgroup (K = W <= 12), layer 2 one
  * MFMA column group per workgroup, head as partial sums q_part [n_colgroups][batch]. SAC / TD3 critic step: nets 0, 1 = the critic on
  * x_data, nets 2, 3 = the target on x_next (core/sac/sac.py:250, :258; core/td3/td3.py:173, :179); actor loss: the critic on x_pi
  * (:273). `fin` (or NULL): the SAC actor's pending head (roles above). */
-int cstr_q_chain_fwd_f32(const cstr_chain_net_t *nets, int n_nets, int w_in, int h1, int h2, int64_t batch, const cstr_sac_head_fin_t *fin,
-                         int tiles, cstr_stream_t stream);
+int cstr_q_chain_fwd_f32(const cstr_chain_net_t *nets, int n_nets, int w_in, int obs_dim, int h1, int h2, int64_t batch,
+                         const cstr_sac_head_fin_t *fin, int tiles, cstr_stream_t stream);
 
 /* Loss root + backward of the twin Q networks in ONE launch (what cstr_hidden_head_bwd_root_f32 + cstr_linear_bwd_input_f32 did in
  * two or three): per workgroup q = sum of partials + b3, d(loss)/dq of its 16 rows (cstr_head_root_t's modes and arithmetic:

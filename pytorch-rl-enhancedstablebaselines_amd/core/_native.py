@@ -100,8 +100,8 @@ class SacActorNet(C.Structure):
 
 class SacHeadFin(C.Structure):
     """cstr_sac_head_fin_t"""
-    _fields_ = [(n, C.c_void_p) for n in ("head_part", "hb", "eps_in", "rng_ctl")] + [(n, C.c_int32) for n in ("n_parts", "act_dim", "obs_dim", "reserved")] + [
-        (n, C.c_void_p) for n in ("x_pi", "x_next", "params", "eps_out", "logp_pi", "logp_next")]
+    _fields_ = [(n, C.c_void_p) for n in ("head_part", "hb", "eps")] + [(n, C.c_int32) for n in ("n_parts", "act_dim", "obs_dim", "reserved")] + [
+        (n, C.c_void_p) for n in ("x_pi", "x_next", "params", "logp_pi", "logp_next")]
 
 
 class ChainRoot(C.Structure):

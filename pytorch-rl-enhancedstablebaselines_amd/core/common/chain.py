@@ -78,7 +78,7 @@ class SacChain:
         A, H1, H2 = self.A, self.aH1, self.aH2
         self.n_head_parts = hip_ops.chain_colgroups(H2, self.t_act)
         self.a_h1, self.a_h2, self.head_part = e(B, H1), e(B, H2), e(self.n_head_parts, 2 * B, 2 * A)
-        self.params, self.eps, self.logp_pi, self.logp_next = e(B, 2 * A), e(B, A), e(B), e(B)
+        self.params, self.eps_all, self.logp_pi, self.logp_next = e(B, 2 * A), e(2 * B, A), e(B), e(B)
         self.c_h1, self.c_h2 = e(2, B, self.cH1), e(2, B, self.cH2)
         self.n_q4, self.n_q2 = hip_ops.chain_colgroups(self.cH2, self.t_q4), hip_ops.chain_colgroups(self.cH2, self.t_q2)
         self.q_part4, self.q_part2 = e(4, self.n_q4, B), e(2, self.n_q2, B)
@@ -102,22 +102,23 @@ class SacChain:
         elif fa.rng_ctl is None:
             fa.rng_ctl = hip_ops.new_rng_ctl(th.initial_seed(), model.device)
         # -- pi(obs) and pi(next_obs): gather + layers 1, 2 + head partials
+        noise = {} if eps2 is not None else dict(head_rng_ctl=fa.rng_ctl, eps_all=self.eps_all)  # drawn by the actor launch unless given
+        eps = self.eps_all if eps2 is None else eps2
         if gather is not None:
             ring, idx, rng_advance, _ = gather
             hip_ops.sac_actor_chain_fwd(self.actor, B, pb.x_data, pb.x_pi, pb.x_next, rd.dones, rd.rewards, self.a_h1, self.a_h2, self.head_part,
-                                        self.t_act, ring=ring, sample_idx=idx, advance_ring=True, rng_advance=rng_advance)
+                                        self.t_act, ring=ring, sample_idx=idx, advance_ring=True, rng_advance=rng_advance, **noise)
         else:
-            hip_ops.sac_actor_chain_fwd(self.actor, B, None, pb.x_pi, pb.x_next, None, None, self.a_h1, self.a_h2, self.head_part, self.t_act)
+            hip_ops.sac_actor_chain_fwd(self.actor, B, None, pb.x_pi, pb.x_next, None, None, self.a_h1, self.a_h2, self.head_part, self.t_act, **noise)
         # -- critics on x_data, target critics on x_next (its action columns finalised inside the launch)
-        fin = nv.SacHeadFin(self.head_part.data_ptr(), fa._hb.data_ptr(), None if eps2 is None else eps2.data_ptr(),
-                            None if eps2 is not None else fa.rng_ctl.data_ptr(), self.n_head_parts, A, D, 0, pb.x_pi.data_ptr(), pb.x_next.data_ptr(),
-                            self.params.data_ptr(), self.eps.data_ptr(), self.logp_pi.data_ptr(), self.logp_next.data_ptr())
+        fin = nv.SacHeadFin(self.head_part.data_ptr(), fa._hb.data_ptr(), eps.data_ptr(), self.n_head_parts, A, D, 0, pb.x_pi.data_ptr(),
+                            pb.x_next.data_ptr(), self.params.data_ptr(), self.logp_pi.data_ptr(), self.logp_next.data_ptr())
         self._keep = eps2  # alive until the launches that read it have been issued (and recorded)
         nets4 = [hip_ops.chain_net(self.crit[0], pb.x_data, self.c_h1[0], self.c_h2[0], self.q_part4[0], nv.CHAIN_ROLE_STORE_PI),
                  hip_ops.chain_net(self.crit[1], pb.x_data, self.c_h1[1], self.c_h2[1], self.q_part4[1], nv.CHAIN_ROLE_PLAIN),
                  hip_ops.chain_net(self.targ[0], pb.x_next, None, None, self.q_part4[2], nv.CHAIN_ROLE_NEXT_STORE),
                  hip_ops.chain_net(self.targ[1], pb.x_next, None, None, self.q_part4[3], nv.CHAIN_ROLE_NEXT)]
-        hip_ops.q_chain_fwd(nets4, W, self.cH1, self.cH2, B, self.t_q4, fin)
+        hip_ops.q_chain_fwd(nets4, W, D, self.cH1, self.cH2, B, self.t_q4, fin)
         # -- entropy-coefficient loss, TD target, critic loss and the critic backward down to dz1
         if model.ent_coef_optimizer is not None:
             ent_coef = s["ent_coef"] if single else model._ent_coef_buf
@@ -150,11 +151,11 @@ class SacChain:
             model.critic.optimizer.step()
         # -- actor loss through the (updated, frozen) critics
         nets2 = [hip_ops.chain_net(self.crit[g], pb.x_pi, self.c_h1[g], self.c_h2[g], self.q_part2[g]) for g in range(2)]
-        hip_ops.q_chain_fwd(nets2, W, self.cH1, self.cH2, B, self.t_q2)
+        hip_ops.q_chain_fwd(nets2, W, D, self.cH1, self.cH2, B, self.t_q2)
         aroot = hip_ops.chain_root("sac_actor", B, [self.q_part2[0], self.q_part2[1]], b3s[:2], self.n_q2, ent_coef=ent_coef, logp=self.logp_pi,
                                    q_out=self.qpi_out, loss_out=sto("actor", model._loss_now["actor"]), loss_sum=acc("actor"))
         hip_ops.q_chain_bwd(back, aroot, W, D, self.cH1, self.cH2, self.t_qb, gact_part=self.gact_part)
-        hip_ops.sac_actor_chain_bwd(self.actor, self.gact_part, 2, self.n_gact, ent_coef, pb.x_pi, self.params, self.eps, self.a_h1, self.a_h2,
+        hip_ops.sac_actor_chain_bwd(self.actor, self.gact_part, 2, self.n_gact, ent_coef, pb.x_pi, self.params, eps, self.a_h1, self.a_h2,
                                     self.g_params, self.dz2a, self.dz1a, B, self.t_ab)
         l1, l2 = self.actor_layers
         hip_ops.linear_bwd_weight_sets([(self.dz1a, pb.x_pi[:, :D], l1.weight.grad, l1.bias.grad), (self.dz2a, self.a_h1, l2.weight.grad, l2.bias.grad),

@@ -888,8 +888,8 @@ def neg_mean_loss(q, gq, loss_out=None, loss_sum=None):
 
 # ---- row-chain kernels (csrc/cstr_chain.hip, include/cstr_rl_hip.h "row-chain kernels") -------------------------------------------
 def chain_supported(h1: int, h2: int, batch: int) -> bool:
-    return (16 <= h1 <= nv.CHAIN_MAX_WIDTH and 16 <= h2 <= nv.CHAIN_MAX_WIDTH and h1 % 4 == 0 and h2 % 4 == 0
-            and 16 <= batch <= 1024 and batch % 16 == 0)
+    return (16 <= h1 <= 384 and 16 <= h2 <= nv.CHAIN_MAX_WIDTH and h1 % 16 == 0 and h2 % 16 == 0
+            and 16 <= batch <= 1024 and batch % 16 == 0)  # h1: panel + staged W1 within 64 KB of LDS
 
 
 def chain_colgroups(width: int, tiles: int) -> int:
@@ -909,7 +909,8 @@ def sac_actor_desc(obs_dim: int, act_dim: int, w1, b1, w2, b2, hw, hb) -> "nv.Sa
 
 
 def sac_actor_chain_fwd(actor: "nv.SacActorNet", batch: int, x_data, x_pi, x_next, out_done, out_rew, a_h1, a_h2, head_part, tiles: int,
-                        ring: Optional[DeviceRing] = None, sample_idx=None, advance_ring: bool = False, rng_advance=None):
+                        ring: Optional[DeviceRing] = None, sample_idx=None, advance_ring: bool = False, rng_advance=None, head_rng_ctl=None,
+                        eps_all=None):
     """cstr_sac_actor_chain_fwd_f32: gather (or packed observation columns) + layer 1 + layer 2 + head partials of the 2B-row actor pass."""
     w = actor.obs_dim + actor.act_dim
     ncg = chain_colgroups(actor.h2, tiles)
@@ -918,6 +919,7 @@ def sac_actor_chain_fwd(actor: "nv.SacActorNet", batch: int, x_data, x_pi, x_nex
             raise ValueError(f"{nm}: needs a float32 device matrix [{batch}, {w}] with row stride {w}")
     _chk(a_h1, "a_h1", (batch, actor.h1), th.float32), _chk(a_h2, "a_h2", (batch, actor.h2), th.float32)
     _chk(head_part, "head_part", (ncg, 2 * batch, 2 * actor.act_dim), th.float32)
+    _opt(eps_all, "eps_all", (2 * batch, actor.act_dim), th.float32), _opt(head_rng_ctl, "head_rng_ctl", (nv.RNG_CTL_WORDS,), th.int64)
     rc_ptr, adv = (None, 0) if rng_advance is None else (rng_advance[0].data_ptr(), int(rng_advance[1]))
     if sample_idx is not None:
         _chk(sample_idx, "sample_idx", (2, batch), th.int32)
@@ -925,7 +927,8 @@ def sac_actor_chain_fwd(actor: "nv.SacActorNet", batch: int, x_data, x_pi, x_nex
     check(nv.lib().cstr_sac_actor_chain_fwd_f32(C.byref(actor), None if ring is None else C.byref(ring.c), None if ring is None else ptr(ring.ctl),
                                                 C.c_int(1 if advance_ring else 0), C.c_void_p(rc_ptr), C.c_uint64(adv), ptr(sample_idx),
                                                 C.c_int64(batch), ptr(x_data), ptr(x_pi), ptr(x_next), ptr(out_done), ptr(out_rew), ptr(a_h1),
-                                                ptr(a_h2), ptr(head_part), C.c_int(tiles), stream_ptr()), "cstr_sac_actor_chain_fwd_f32")
+                                                ptr(a_h2), ptr(head_part), ptr(head_rng_ctl), ptr(eps_all), C.c_int(tiles), stream_ptr()),
+          "cstr_sac_actor_chain_fwd_f32")
 
 
 def chain_net(layers, x=None, h1=None, h2=None, q_part=None, role: int = 0) -> "nv.ChainNet":
@@ -935,10 +938,10 @@ def chain_net(layers, x=None, h1=None, h2=None, q_part=None, role: int = 0) -> "
                        _dp(q_part), role, 0)
 
 
-def q_chain_fwd(nets, w_in: int, h1: int, h2: int, batch: int, tiles: int, fin: Optional["nv.SacHeadFin"] = None):
+def q_chain_fwd(nets, w_in: int, obs_dim: int, h1: int, h2: int, batch: int, tiles: int, fin: Optional["nv.SacHeadFin"] = None):
     """cstr_q_chain_fwd_f32: n_nets Q networks (layer 1 recomputed, layer 2 one MFMA column group per workgroup, head as partials)."""
     arr = (nv.ChainNet * len(nets))(*nets)
-    check(nv.lib().cstr_q_chain_fwd_f32(arr, C.c_int(len(nets)), C.c_int(w_in), C.c_int(h1), C.c_int(h2), C.c_int64(batch),
+    check(nv.lib().cstr_q_chain_fwd_f32(arr, C.c_int(len(nets)), C.c_int(w_in), C.c_int(obs_dim), C.c_int(h1), C.c_int(h2), C.c_int64(batch),
                                         None if fin is None else C.byref(fin), C.c_int(tiles), stream_ptr()), "cstr_q_chain_fwd_f32")
 
 

@@ -35,7 +35,7 @@ constexpr int SM_RED = SM_PART + 3 * 64 * 4;        // red[4 tiles][16 rows][8]:
 constexpr int SM_XS = SM_RED + 4 * 16 * 8;          // xs[16][16]: the row group's input rows
 constexpr int SM_GS = SM_XS + 16 * 16;              // gs[16][8]: per-row gradients of the prologue
 constexpr int SM_PANEL = SM_GS + 16 * 8;            // panel[16][K + 4]: A operand of the wide layer
-static size_t chain_lds_bytes(int k) { return (size_t)(SM_PANEL + 16 * (k + 4)) * sizeof(float); }
+static size_t chain_lds_bytes(int k, bool with_w1) { return (size_t)(SM_PANEL + 16 * (k + 4) + (with_w1 ? 16 * k : 0)) * sizeof(float); }
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc_of(const float *base, const int64_t floats)
 {
@@ -53,13 +53,23 @@ __device__ __forceinline__ float ld32(const __amdgpu_buffer_rsrc_t rs, const int
     return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, byte_off, 0, 0));
 }
 
-// sum over the 16 lanes that share lane >> 4 (the 16 columns of an MFMA C/D tile row): xor butterfly, every lane gets the total
+// LDS-only workgroup barrier: waits for this wave's LDS traffic (lgkmcnt), NOT for its outstanding global loads / stores -- the
+// chain kernels keep operand loads in flight across their phase boundaries and issue their global stores at the very end.
+__device__ __forceinline__ void lds_barrier()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+// sum over the 16 lanes that share lane >> 4 (the 16 columns of an MFMA C/D tile row): four DPP row rotations (full-rate VALU, no
+// LDS crossbar); every lane ends with the total of its row
 __device__ __forceinline__ float rowsum16(float v)
 {
-    v += __shfl_xor(v, 1, 64);
-    v += __shfl_xor(v, 2, 64);
-    v += __shfl_xor(v, 4, 64);
-    v += __shfl_xor(v, 8, 64);
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, false));  // row_ror:8
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124, 0xf, 0xf, false));  // row_ror:4
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x122, 0xf, 0xf, false));  // row_ror:2
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x121, 0xf, 0xf, false));  // row_ror:1
     return v;
 }
 
@@ -119,14 +129,14 @@ __device__ __forceinline__ f32x4 tile_mma(const float *panel, const int ld, cons
 }
 
 // split-K combine: wave = tile + T * ks; the ks > 0 waves park their partial tile in LDS, the ks == 0 wave of the tile adds them in
-// ks order. Every wave of the workgroup calls this (one barrier).
+// ks order. Every wave of the workgroup calls this (one LDS barrier).
 __device__ __forceinline__ f32x4 combine_split_k(f32x4 acc, float *smem, const int T, const int S)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     f32x4 *part = reinterpret_cast<f32x4 *>(smem + SM_PART);
     if (S > 1) {
         if (wave >= T) part[(wave - T) * 64 + lane] = acc;
-        __syncthreads();
+        lds_barrier();
         if (wave < T) {
             for (int v = 1; v < S; ++v) acc += part[(wave + T * v - T) * 64 + lane];
         }
@@ -134,48 +144,61 @@ __device__ __forceinline__ f32x4 combine_split_k(f32x4 acc, float *smem, const i
     return acc;
 }
 
-// The SAC head's sampling arithmetic for ONE row (gaussian_head_gemm_fwd_kernel's expressions): p[0..A) = mean, p[A..2A) = raw
-// log_std; eps given or Philox4x32-10 / Box-Muller at counter `ctr`.
-struct HeadRow { float a[MAX_A], e[MAX_A], lp; };
-__device__ __forceinline__ HeadRow sample_head_row(const float (&p)[2 * MAX_A], const int act_dim, const float *eps_row, const bool philox,
-                                                   const uint64_t seed, const uint64_t ctr)
+// The SAC head's sampling arithmetic for ONE (row, action) (gaussian_head_gemm_fwd_kernel's expressions): mean, raw log_std, eps ->
+// action and this action's log-prob term (Normal log-pdf minus the tanh correction)
+__device__ __forceinline__ void sample_action(const float mu, const float raw, const float e, float &a, float &lp_term)
 {
     const float half_log_2pi = 0.91893853320467274178f;
-    HeadRow o;
-    float lp = 0.0f, corr = 0.0f;
+    const float ls = fminf(fmaxf(raw, LOG_STD_MIN), LOG_STD_MAX);
+    const float sd = expf(ls);
+    const float u = mu + sd * e;
+    a = tanhf(u);
+    const float d = u - mu, var = sd * sd;
+    lp_term = (-(d * d) / (2.0f * var) - logf(sd) - half_log_2pi) - logf(1.0f - a * a + 1e-6f);
+}
+
+// ---- first layer of a chain on the matrix cores -----------------------------------------------------------------------------------
+// h1 = relu(x W1^T + b1) for the row group's 16 rows, K = KIN <= 12 inputs: ONE 16-wide k chunk. The inputs sit in xs[16][16]
+// (LDS; column KIN holds 1.0, the rest zeros) and W1 is staged as w1s[H1][16] with b1 in column KIN, so the bias rides in the k
+// chain and a 16 x 16 tile is 4 MFMAs + 4 ReLU + 4 LDS stores; the wave takes the tiles wave, wave + 4, ...
+template <int KIN>
+__device__ __forceinline__ void stage_w1(float *w1s, const float *w1, const float *b1, const int h1)
+{
+    for (int c = threadIdx.x; c < h1; c += CH_THREADS) {
+        float w[16];
 #pragma unroll
-    for (int j0 = 0; j0 < MAX_A; j0 += 2) {
-        if (j0 >= act_dim) break;
-        float e[2] = {0.0f, 0.0f};
-        if (philox) {
-            uint32_t rr[4];
-            philox4x32_10((uint32_t)ctr, (uint32_t)(ctr >> 32), (uint32_t)(j0 >> 1), 0u, (uint32_t)seed, (uint32_t)(seed >> 32), rr);
-            box_muller(rr[0], rr[1], e[0], e[1]);
-        }
+        for (int k = 0; k < 16; ++k) w[k] = k < KIN ? w1[(int64_t)c * KIN + k] : 0.0f;
+        w[KIN] = b1[c];
 #pragma unroll
-        for (int jj = 0; jj < 2; ++jj) {
-            const int j = j0 + jj;
-            if (j >= act_dim) break;
-            if (!philox) e[jj] = eps_row[j];
-            float mu = 0.0f, raw = 0.0f;
-#pragma unroll
-            for (int q = 0; q < 2 * MAX_A; ++q) {  // selects with static register indices
-                if (q == j) mu = p[q];
-                if (q == act_dim + j) raw = p[q];
-            }
-            const float ls = fminf(fmaxf(raw, LOG_STD_MIN), LOG_STD_MAX);
-            const float sd = expf(ls);
-            const float u = mu + sd * e[jj];
-            const float a = tanhf(u);
-            const float d = u - mu, var = sd * sd;
-            lp += -(d * d) / (2.0f * var) - logf(sd) - half_log_2pi;
-            corr += logf(1.0f - a * a + 1e-6f);
-            o.a[j] = a;
-            o.e[j] = e[jj];
-        }
+        for (int q = 0; q < 4; ++q) *reinterpret_cast<float4 *>(w1s + c * 16 + 4 * q) = make_float4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
     }
-    o.lp = lp - corr;
-    return o;
+}
+
+__device__ __forceinline__ void layer1_mfma(const float *xs, const float *w1s, float *panel, const int ld, const int h1)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, h = lane >> 4;
+    const float4 xa = *reinterpret_cast<const float4 *>(xs + r * 16 + 4 * h);
+    for (int tl = wave; tl < h1 / 16; tl += CH_WAVES) {
+        const float4 wb = *reinterpret_cast<const float4 *>(w1s + (16 * tl + r) * 16 + 4 * h);
+        f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.x, wb.x, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.y, wb.y, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.z, wb.z, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.w, wb.w, acc1, 0, 0, 0);
+        const f32x4 acc = acc0 + acc1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) panel[(4 * h + e) * ld + 16 * tl + r] = fmaxf(acc[e], 0.0f);
+    }
+}
+
+// the 16 x width panel (LDS) -> out[(m0 + row)][c]: the chain's "keep for the backward" store, issued at the END (16-byte quads)
+__device__ __forceinline__ void store_panel(const float *panel, const int ld, float *out, const int width, const int m0)
+{
+    const int qpr = width / 4;
+    for (int i = threadIdx.x; i < 16 * qpr; i += CH_THREADS) {
+        const int row = i / qpr, q = i % qpr;
+        *reinterpret_cast<float4 *>(out + (int64_t)(m0 + row) * width + 4 * q) = *reinterpret_cast<const float4 *>(panel + row * ld + 4 * q);
+    }
 }
 
 // ---- SAC actor, forward chain -------------------------------------------------------------------------------------------------
@@ -184,45 +207,50 @@ struct ActorFwdArgs {
     cstr_ring_t ring; int64_t *ring_ctl; int advance_ring; uint64_t *rng_ctl; uint64_t rng_advance;
     const int32_t *idx; int batch, tiles;
     float *x_data, *x_pi, *x_next, *out_done, *out_rew, *a_h1, *a_h2, *head_part;
+    const uint64_t *head_rng_ctl; float *eps_all;
 };
 
-template <int NQ>
+template <int D, int A, int NQ>
 __global__ __launch_bounds__(CH_THREADS) void sac_actor_chain_fwd_kernel(const ActorFwdArgs a)
 {
     extern __shared__ __align__(16) float smem[];
+    constexpr int W = D + A, QPR = D / 4;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, r = lane & 15, h = lane >> 4;
     const int T = a.tiles, S = CH_WAVES / T, tile = wave % T, ks = wave / T;
-    const int D = a.net.obs_dim, A = a.net.act_dim, W = D + A, H1 = a.net.h1, H2 = a.net.h2, B = a.batch, M = 2 * B;
+    const int H1 = a.net.h1, H2 = a.net.h2, B = a.batch, M = 2 * B;
     const int n0 = (blockIdx.x * T + tile) * 16, m0 = blockIdx.y * 16;
     float *xs = smem + SM_XS, *red = smem + SM_RED, *panel = smem + SM_PANEL;
     const int ld = H1 + 4;
-    // (a) the wide layer's B operand does not depend on anything: requested first
+    float *w1s = panel + 16 * ld;
+    const bool tile_ok = n0 < H2;
+    // (a) everything that depends on nothing is requested NOW: the wide layer's B operand, the epilogue's bias and head weights, W1
     float4 bq[NQ];
     load_b_fwd<NQ>(bq, a.net.w2, H2, H1, n0, ks, S);
-    const int col = n0 + r;
-    const float bv = a.net.b2[min(col, H2 - 1)];
+    const int col = min(n0 + r, H2 - 1);
+    const float bv = a.net.b2[col];
+    float hwv[2 * A];
+#pragma unroll
+    for (int j = 0; j < 2 * A; ++j) hwv[j] = a.net.hw[(int64_t)j * H2 + col];
+    stage_w1<D>(w1s, a.net.w1, a.net.b1, H1);
     // (b) the row group's 16 input rows: ReplayBuffer.sample's gather (buffers.py:316-323) or the already packed observation columns
-    const int qpr = D / 4;  // 16-byte quads per row
-    if (t < 16 * qpr) {
-        const int row = t / qpr, qd = t % qpr, m = min(m0 + row, M - 1);
-        const bool next = m >= B;
-        const int b = next ? m - B : m;
-        float4 v;
+    const bool mat = a.idx != nullptr && blockIdx.x == 0;  // this workgroup also materialises the packed batch (stores at the end)
+    float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    float actv[A], dn = 0.0f, to = 0.0f, rw = 0.0f;
+#pragma unroll
+    for (int j = 0; j < A; ++j) actv[j] = 0.0f;
+    int b = 0;
+    bool next = false;
+    if (t < 16 * QPR) {
+        const int row = t / QPR, qd = t % QPR, m = m0 + row;
+        next = m >= B;
+        b = next ? m - B : m;
         if (a.idx) {
             const int64_t o = (int64_t)a.idx[b] * a.ring.n_envs + a.idx[B + b];
             v = *reinterpret_cast<const float4 *>((next ? a.ring.next_obs : a.ring.obs) + o * D + 4 * qd);
-            if (blockIdx.x == 0 && m0 + row < M) {  // materialise the packed batch for the launches behind this one
-                float *xo = (next ? a.x_next : a.x_pi) + (int64_t)b * W + 4 * qd;
-                reinterpret_cast<float2 *>(xo)[0] = make_float2(v.x, v.y); reinterpret_cast<float2 *>(xo)[1] = make_float2(v.z, v.w);
-                if (!next) {
-                    float *xd = a.x_data + (int64_t)b * W;
-                    reinterpret_cast<float2 *>(xd + 4 * qd)[0] = make_float2(v.x, v.y); reinterpret_cast<float2 *>(xd + 4 * qd)[1] = make_float2(v.z, v.w);
-                    if (qd == 0) {
-                        for (int j = 0; j < A; ++j) xd[D + j] = a.ring.act[o * A + j];
-                        a.out_done[b] = a.ring.done[o] * (1.0f - a.ring.timeout[o]);  // buffers.py:322
-                        a.out_rew[b] = a.ring.rew[o];
-                    }
-                }
+            if (mat && !next && qd == 0) {
+#pragma unroll
+                for (int j = 0; j < A; ++j) actv[j] = a.ring.act[o * A + j];
+                dn = a.ring.done[o]; to = a.ring.timeout[o]; rw = a.ring.rew[o];
             }
         } else {
             const float2 *src = reinterpret_cast<const float2 *>((next ? a.x_next : a.x_pi) + (int64_t)b * W + 4 * qd);
@@ -230,6 +258,76 @@ __global__ __launch_bounds__(CH_THREADS) void sac_actor_chain_fwd_kernel(const A
             v = make_float4(lo.x, lo.y, hi.x, hi.y);
         }
         *reinterpret_cast<float4 *>(xs + row * 16 + 4 * qd) = v;
+    } else if (t >= 64 && t < 64 + 16 * (4 - QPR)) {  // the padding quads of xs: 1.0 in column D (the bias input), zeros behind it
+        const int i = t - 64, row = i / (4 - QPR), qd = QPR + i % (4 - QPR);
+        *reinterpret_cast<float4 *>(xs + row * 16 + 4 * qd) = make_float4(qd == QPR ? 1.0f : 0.0f, 0.0f, 0.0f, 0.0f);
+    }
+    // the noise of the row group's sampling head: counter-based, independent of the network -- drawn by an otherwise idle wave while the
+    // gather is in flight, consumed by the Q chain launch that finalises the head (counter = offset + row of the 2B-row pass)
+    constexpr int PAIRS = (A + 1) / 2;
+    float e0 = 0.0f, e1 = 0.0f;
+    const bool noise = a.eps_all != nullptr && blockIdx.x == 0 && wave == 3 && lane < 16 * PAIRS;
+    if (noise) {
+        const int row = lane / PAIRS, pr = lane % PAIRS;
+        const uint64_t seed = a.head_rng_ctl[0], ctr = a.head_rng_ctl[1] + (uint64_t)(m0 + row);
+        uint32_t rr[4];
+        philox4x32_10((uint32_t)ctr, (uint32_t)(ctr >> 32), (uint32_t)pr, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), rr);
+        box_muller(rr[0], rr[1], e0, e1);
+    }
+    lds_barrier();
+    // (c) layer 1, recomputed by every workgroup of the row group -> panel
+    layer1_mfma(xs, w1s, panel, ld, H1);
+    lds_barrier();
+    // (d) layer 2: this wave's 16 x 16 tile (its share of K), (e) split-K combine
+    f32x4 acc = tile_mma<NQ>(panel, ld, H1, bq, ks, S);
+    acc = combine_split_k(acc, smem, T, S);
+    // (f) epilogue of the tile's first wave: bias + ReLU, head partials over these 16 columns
+    float hv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (wave < T) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) hv[e] = tile_ok ? fmaxf(acc[e] + bv, 0.0f) : 0.0f;
+#pragma unroll
+        for (int j = 0; j < 2 * A; ++j) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float s = rowsum16(hv[e] * hwv[j]);
+                if (r == 0) red[(tile * 16 + 4 * h + e) * 8 + j] = s;
+            }
+        }
+    }
+    lds_barrier();
+    if (t < 16 * 2 * A) {
+        const int row = t / (2 * A), j = t % (2 * A);
+        float s = red[row * 8 + j];
+        for (int tl = 1; tl < T; ++tl) s += red[(tl * 16 + row) * 8 + j];
+        a.head_part[((int64_t)blockIdx.x * M + m0 + row) * (2 * A) + j] = s;
+    }
+    // ---- global stores, all behind the last barrier ----
+    if (wave < T && tile_ok && a.a_h2 && m0 < B) {  // the pi(obs) rows' activations, kept for the backward
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a.a_h2[(int64_t)(m0 + 4 * h + e) * H2 + n0 + r] = hv[e];
+    }
+    if (blockIdx.x == 0 && a.a_h1 && m0 < B) store_panel(panel, ld, a.a_h1, H1, m0);
+    if (noise) {
+        const int row = lane / PAIRS, pr = lane % PAIRS;
+        float *eo = a.eps_all + (int64_t)(m0 + row) * A + 2 * pr;
+        eo[0] = e0;
+        if (2 * pr + 1 < A) eo[1] = e1;
+    }
+    if (mat && t < 16 * QPR) {  // the packed batch for the launches behind this one (cstr_linear_act_fwd_gather_f32's contract)
+        const int qd = t % QPR;
+        float *xo = (next ? a.x_next : a.x_pi) + (int64_t)b * W + 4 * qd;
+        reinterpret_cast<float2 *>(xo)[0] = make_float2(v.x, v.y); reinterpret_cast<float2 *>(xo)[1] = make_float2(v.z, v.w);
+        if (!next) {
+            float *xd = a.x_data + (int64_t)b * W;
+            reinterpret_cast<float2 *>(xd + 4 * qd)[0] = make_float2(v.x, v.y); reinterpret_cast<float2 *>(xd + 4 * qd)[1] = make_float2(v.z, v.w);
+            if (qd == 0) {
+#pragma unroll
+                for (int j = 0; j < A; ++j) xd[D + j] = actv[j];
+                a.out_done[b] = dn * (1.0f - to);  // buffers.py:322
+                a.out_rew[b] = rw;
+            }
+        }
     }
     if (blockIdx.x == 0 && blockIdx.y == 0 && t == 0 && a.idx) {  // nobody reads these words in this launch
         if (a.advance_ring) {  // ReplayBuffer.add's epilogue (buffers.py:280-283), left over by the rollout launch
@@ -240,168 +338,105 @@ __global__ __launch_bounds__(CH_THREADS) void sac_actor_chain_fwd_kernel(const A
         }
         if (a.rng_ctl) a.rng_ctl[1] += a.rng_advance;
     }
-    __syncthreads();
-    // (c) layer 1, recomputed by every workgroup of the row group: h1 = relu(x W1^T + b1) -> panel (k ascending fma chain, then + bias)
-    for (int c = t; c < H1; c += CH_THREADS) {
-        float w[8];
-        const float4 w0 = *reinterpret_cast<const float4 *>(a.net.w1 + (int64_t)c * D);
-        w[0] = w0.x; w[1] = w0.y; w[2] = w0.z; w[3] = w0.w;
-        if (D == 8) {
-            const float4 w1v = *reinterpret_cast<const float4 *>(a.net.w1 + (int64_t)c * D + 4);
-            w[4] = w1v.x; w[5] = w1v.y; w[6] = w1v.z; w[7] = w1v.w;
-        }
-        const float bb = a.net.b1[c];
-        const bool keep = blockIdx.x == 0 && a.a_h1 != nullptr;
-#pragma unroll 4
-        for (int row = 0; row < 16; ++row) {
-            float acc = 0.0f;
-#pragma unroll
-            for (int k = 0; k < 8; ++k)
-                if (k < D) acc = __fmaf_rn(xs[row * 16 + k], w[k], acc);
-            const float v = fmaxf(acc + bb, 0.0f);
-            panel[row * ld + c] = v;
-            if (keep && m0 + row < B) a.a_h1[(int64_t)(m0 + row) * H1 + c] = v;
-        }
-    }
-    __syncthreads();
-    // (d) layer 2: this wave's 16 x 16 tile (its share of K), (e) split-K combine
-    f32x4 acc = tile_mma<NQ>(panel, ld, H1, bq, ks, S);
-    acc = combine_split_k(acc, smem, T, S);
-    // (f) epilogue of the tile's first wave: bias + ReLU, keep the pi(obs) rows for the backward, head partials over these 16 columns
-    if (wave < T) {
-        float v[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            v[e] = col < H2 ? fmaxf(acc[e] + bv, 0.0f) : 0.0f;
-            const int m = m0 + 4 * h + e;
-            if (col < H2 && m < B && a.a_h2) a.a_h2[(int64_t)m * H2 + col] = v[e];
-        }
-        for (int j = 0; j < 2 * A; ++j) {
-            const float wv = col < H2 ? a.net.hw[(int64_t)j * H2 + col] : 0.0f;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float s = rowsum16(v[e] * wv);
-                if (r == 0) red[(tile * 16 + 4 * h + e) * 8 + j] = s;
-            }
-        }
-    }
-    __syncthreads();
-    if (t < 16 * 2 * A) {
-        const int row = t / (2 * A), j = t % (2 * A);
-        float s = red[row * 8 + j];
-        for (int tl = 1; tl < T; ++tl) s += red[(tl * 16 + row) * 8 + j];
-        if (m0 + row < M) a.head_part[((int64_t)blockIdx.x * M + m0 + row) * (2 * A) + j] = s;
-    }
 }
 
 // ---- Q networks, forward chain ------------------------------------------------------------------------------------------------
 struct QFwdArgs {
     cstr_chain_net_t nets[CSTR_CHAIN_MAX_NETS];
     cstr_sac_head_fin_t fin;
-    int n_nets, w_in, h1, h2, batch, tiles, has_fin;
+    int n_nets, h1, h2, batch, tiles, has_fin;
 };
 
-template <int NQ>
+template <int D, int A, int NQ>
 __global__ __launch_bounds__(CH_THREADS) void q_chain_fwd_kernel(const QFwdArgs a)
 {
     extern __shared__ __align__(16) float smem[];
+    constexpr int W = D + A;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, r = lane & 15, h = lane >> 4;
     const int T = a.tiles, S = CH_WAVES / T, tile = wave % T, ks = wave / T;
     const cstr_chain_net_t &net = a.nets[blockIdx.z];
-    const int W = a.w_in, H1 = a.h1, H2 = a.h2, B = a.batch;
+    const int H1 = a.h1, H2 = a.h2, B = a.batch;
     const int n0 = (blockIdx.x * T + tile) * 16, m0 = blockIdx.y * 16;
     float *xs = smem + SM_XS, *red = smem + SM_RED, *panel = smem + SM_PANEL;
     const int ld = H1 + 4;
+    float *w1s = panel + 16 * ld;
+    const bool tile_ok = n0 < H2;
+    // (a) requests that depend on nothing
     float4 bq[NQ];
     load_b_fwd<NQ>(bq, net.w2, H2, H1, n0, ks, S);
-    const int col = n0 + r;
-    const float bv = net.b2[min(col, H2 - 1)];
-    const float w3v = col < H2 ? net.w3[col] : 0.0f;
+    const int col = min(n0 + r, H2 - 1);
+    const float bv = net.b2[col];
+    const float w3v = net.w3[col];
+    stage_w1<W>(w1s, net.w1, net.b1, H1);
     const int role = a.has_fin ? net.role : CSTR_CHAIN_ROLE_PLAIN;
-    const int D = a.has_fin ? a.fin.obs_dim : W;
-    // (b) input rows; with a pending actor head the action columns of the pi(next_obs) rows are finalised HERE (every workgroup of
-    //     the row group for itself), and the column-group-0 workgroups store what later launches need
-    if (t < 16 * W) {
-        const int row = t / W, k = t % W;
-        if (!(role >= CSTR_CHAIN_ROLE_NEXT && k >= D)) xs[row * 16 + k] = net.x[(int64_t)min(m0 + row, B - 1) * W + k];
+    // (b) input rows (16 floats per row in LDS: the inputs, 1.0 = the bias input, zeros); with a pending actor head the action columns
+    //     of the pi(next_obs) rows are finalised HERE (every workgroup of the row group for itself: a lane per (row, action)), and the
+    //     column-group-0 workgroups store what later launches need
+    const bool nxt = role >= CSTR_CHAIN_ROLE_NEXT;
+    {
+        const int row = t >> 4, k = t & 15;  // 256 threads = 16 x 16
+        float xv = k == W ? 1.0f : 0.0f;
+        if (k < W && !(nxt && k >= D)) xv = net.x[(int64_t)(m0 + row) * W + k];
+        if (!(nxt && k >= D && k < W)) xs[row * 16 + k] = xv;
     }
-    const bool fin_rows = role >= CSTR_CHAIN_ROLE_NEXT || (role == CSTR_CHAIN_ROLE_STORE_PI && blockIdx.x == 0);
-    if (fin_rows && t >= 64 && t < 80) {  // 16 lanes of wave 1, a row each (wave 0's low lanes load the inputs)
-        const int row = t - 64, b = min(m0 + row, B - 1), A = a.fin.act_dim;
-        const bool nxt = role >= CSTR_CHAIN_ROLE_NEXT;
-        const int64_t i = (nxt ? B : 0) + b;  // row of the 2B-row actor pass
-        float p[2 * MAX_A];
-#pragma unroll
-        for (int j = 0; j < 2 * MAX_A; ++j) {
-            p[j] = 0.0f;
-            if (j < 2 * A) {
-                float s = a.fin.head_part[i * (2 * A) + j];
-                for (int part = 1; part < a.fin.n_parts; ++part) s += a.fin.head_part[((int64_t)part * 2 * B + i) * (2 * A) + j];
-                p[j] = s + a.fin.hb[j];
-            }
+    const bool fin_rows = nxt || (role == CSTR_CHAIN_ROLE_STORE_PI && blockIdx.x == 0);
+    const bool fin_lane = fin_rows && t < 16 * A;  // a lane per (row, action) in wave 0
+    float f_mu = 0.0f, f_raw = 0.0f, f_a = 0.0f, f_lp = 0.0f;
+    const int f_row = t / A, f_j = t % A;
+    if (fin_lane) {
+        const int64_t i = (nxt ? B : 0) + m0 + f_row;  // row of the 2B-row actor pass
+        const float *hp = a.fin.head_part + i * (2 * A);
+        const int64_t pstride = (int64_t)2 * B * 2 * A;
+        float s_mu = hp[f_j], s_raw = hp[A + f_j];
+        for (int part = 1; part < a.fin.n_parts; ++part) {
+            s_mu += hp[part * pstride + f_j];
+            s_raw += hp[part * pstride + A + f_j];
         }
-        const bool philox = a.fin.eps_in == nullptr;
-        const uint64_t seed = philox ? a.fin.rng_ctl[0] : 0ull, base = philox ? a.fin.rng_ctl[1] : 0ull;
-        const HeadRow o = sample_head_row(p, A, philox ? nullptr : a.fin.eps_in + i * A, philox, seed, base + (uint64_t)i);
-        const bool store = blockIdx.x == 0 && m0 + row < B && role != CSTR_CHAIN_ROLE_NEXT;
-#pragma unroll
-        for (int j = 0; j < MAX_A; ++j) {
-            if (j >= A) break;
-            if (nxt) xs[row * 16 + D + j] = o.a[j];
-            if (store) {
-                (nxt ? a.fin.x_next : a.fin.x_pi)[(int64_t)b * W + D + j] = o.a[j];
-                if (!nxt) {
-                    float mu = 0.0f, raw = 0.0f;
-#pragma unroll
-                    for (int q = 0; q < 2 * MAX_A; ++q) {
-                        if (q == j) mu = p[q];
-                        if (q == A + j) raw = p[q];
-                    }
-                    a.fin.params[(int64_t)b * 2 * A + j] = mu;
-                    a.fin.params[(int64_t)b * 2 * A + A + j] = raw;
-                    a.fin.eps_out[(int64_t)b * A + j] = o.e[j];
-                }
-            }
-        }
-        if (store) (nxt ? a.fin.logp_next : a.fin.logp_pi)[b] = o.lp;
+        f_mu = s_mu + a.fin.hb[f_j];
+        f_raw = s_raw + a.fin.hb[A + f_j];
+        float term;
+        sample_action(f_mu, f_raw, a.fin.eps[i * A + f_j], f_a, term);
+        // log-prob of the row = sum of its actions' terms: the A lanes of a row are adjacent
+        f_lp = term;
+        if (A >= 2) f_lp += __shfl_xor(f_lp, 1, 64);
+        if (A == 4) f_lp += __shfl_xor(f_lp, 2, 64);
+        if (nxt) xs[f_row * 16 + D + f_j] = f_a;
     }
-    __syncthreads();
-    // (c) layer 1 recomputed: K = W <= 12 inputs
-    for (int c = t; c < H1; c += CH_THREADS) {
-        float w[12];
-#pragma unroll
-        for (int k = 0; k < 12; ++k) w[k] = k < W ? net.w1[(int64_t)c * W + k] : 0.0f;
-        const float bb = net.b1[c];
-        const bool keep = blockIdx.x == 0 && net.h1 != nullptr;
-#pragma unroll 4
-        for (int row = 0; row < 16; ++row) {
-            float acc = 0.0f;
-#pragma unroll
-            for (int k = 0; k < 12; ++k)
-                if (k < W) acc = __fmaf_rn(xs[row * 16 + k], w[k], acc);
-            const float v = fmaxf(acc + bb, 0.0f);
-            panel[row * ld + c] = v;
-            if (keep && m0 + row < B) net.h1[(int64_t)(m0 + row) * H1 + c] = v;
-        }
-    }
-    __syncthreads();
+    lds_barrier();
+    // (c) layer 1 recomputed on the matrix cores
+    layer1_mfma(xs, w1s, panel, ld, H1);
+    lds_barrier();
     f32x4 acc = tile_mma<NQ>(panel, ld, H1, bq, ks, S);
     acc = combine_split_k(acc, smem, T, S);
+    float hv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     if (wave < T) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const float v = col < H2 ? fmaxf(acc[e] + bv, 0.0f) : 0.0f;
-            const int m = m0 + 4 * h + e;
-            if (col < H2 && m < B && net.h2) net.h2[(int64_t)m * H2 + col] = v;
-            const float s = rowsum16(v * w3v);
+            hv[e] = tile_ok ? fmaxf(acc[e] + bv, 0.0f) : 0.0f;
+            const float s = rowsum16(hv[e] * w3v);
             if (r == 0) red[(tile * 16 + 4 * h + e) * 8] = s;
         }
     }
-    __syncthreads();
-    if (t < 16 && m0 + t < B) {
+    lds_barrier();
+    if (t < 16) {
         float s = red[t * 8];
         for (int tl = 1; tl < T; ++tl) s += red[(tl * 16 + t) * 8];
         net.q_part[(int64_t)blockIdx.x * B + m0 + t] = s;
+    }
+    // ---- global stores, all behind the last barrier ----
+    if (wave < T && tile_ok && net.h2) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) net.h2[(int64_t)(m0 + 4 * h + e) * H2 + n0 + r] = hv[e];
+    }
+    if (blockIdx.x == 0 && net.h1) store_panel(panel, ld, net.h1, H1, m0);
+    if (fin_lane && blockIdx.x == 0 && role != CSTR_CHAIN_ROLE_NEXT) {
+        const int bb = m0 + f_row;
+        (nxt ? a.fin.x_next : a.fin.x_pi)[(int64_t)bb * W + D + f_j] = f_a;
+        if (!nxt) {
+            a.fin.params[(int64_t)bb * 2 * A + f_j] = f_mu;
+            a.fin.params[(int64_t)bb * 2 * A + A + f_j] = f_raw;
+        }
+        if (f_j == 0) (nxt ? a.fin.logp_next : a.fin.logp_pi)[bb] = f_lp;
     }
 }
 
@@ -409,7 +444,7 @@ __global__ __launch_bounds__(CH_THREADS) void q_chain_fwd_kernel(const QFwdArgs 
 struct QBwdArgs {
     cstr_chain_net_t nets[2];
     cstr_chain_root_t root;
-    int n_nets, w_in, obs_dim, h1, h2, tiles;
+    int n_nets, h1, h2, tiles;
     float *dz2, *dz1, *gact_part;
 };
 
@@ -496,13 +531,14 @@ __device__ void chain_loss_workgroup(const cstr_chain_root_t &rt, float *sm)
     if (tid == 0 && rt.rng_ctl) rt.rng_ctl[1] += rt.rng_advance;  // nobody reads the offset in this launch
 }
 
-template <int NQ>
+template <int D, int A, int NQ>
 __global__ __launch_bounds__(CH_THREADS) void q_chain_bwd_kernel(const QBwdArgs a)
 {
     extern __shared__ __align__(16) float smem[];
+    constexpr int W = D + A;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, r = lane & 15, h = lane >> 4;
     const cstr_chain_root_t &rt = a.root;
-    const int B = rt.batch, H1 = a.h1, H2 = a.h2, W = a.w_in;
+    const int B = rt.batch, H1 = a.h1, H2 = a.h2;
     const int g = blockIdx.z;
     if ((int)blockIdx.y == B / 16) {  // the loss workgroup
         if (g == 0 && blockIdx.x == 0) chain_loss_workgroup(rt, smem + SM_RED);
@@ -510,96 +546,128 @@ __global__ __launch_bounds__(CH_THREADS) void q_chain_bwd_kernel(const QBwdArgs 
     }
     const int T = a.tiles, S = CH_WAVES / T, tile = wave % T, ks = wave / T;
     const cstr_chain_net_t &net = a.nets[g];
-    const int k0 = (blockIdx.x * T + tile) * 16, m0 = blockIdx.y * 16, col = k0 + r;
+    const int k0 = (blockIdx.x * T + tile) * 16, m0 = blockIdx.y * 16;
+    const bool tile_ok = k0 < H1;
+    const int col = min(k0 + r, H1 - 1);
     float *red = smem + SM_RED, *gs = smem + SM_GS, *panel = smem + SM_PANEL;
     const int ld = H2 + 4;
-    // (a) operands that depend on nothing: the tile's B operand (W2 read along n) and the epilogue's relu'(h1) mask values
+    // (a) operands that depend on nothing: the tile's B operand (W2 read along n), the epilogue's relu'(h1) mask values and first-layer
+    //     action columns, and this thread's columns of the h2 panel + w3 for the dz2 recompute
     float4 bq[NQ];
     load_b_bwd<NQ>(bq, net.w2, H2, H1, k0, ks, S);
     float ty[4];
-    {
-        const __amdgpu_buffer_rsrc_t rh = rsrc_of(net.h1, (int64_t)B * H1);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) ty[e] = ld32(rh, col < H1 ? 4 * ((m0 + 4 * h + e) * H1 + col) : BUF_OOB);
+    for (int e = 0; e < 4; ++e) ty[e] = net.h1[(int64_t)(m0 + 4 * h + e) * H1 + col];
+    float w1a[A];
+#pragma unroll
+    for (int j = 0; j < A; ++j) w1a[j] = a.gact_part ? net.w1[(int64_t)col * W + D + j] : 0.0f;
+    float y[2][16], w3c[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int c = min(t + CH_THREADS * i, H2 - 1);
+        w3c[i] = 0.0f;
+#pragma unroll
+        for (int row = 0; row < 16; ++row) y[i][row] = 0.0f;
+        if (i == 0 || H2 > CH_THREADS) {  // (uniform)
+            w3c[i] = net.w3[c];
+#pragma unroll
+            for (int row = 0; row < 16; ++row) y[i][row] = net.h2[(int64_t)(m0 + row) * H2 + c];
+        }
     }
     // (b) d(loss)/dq of this network for the row group's 16 rows (cstr_head_root_t's expressions)
+    float o_q = 0.0f, o_gq = 0.0f, o_tq = 0.0f;
     if (t < 16) {
         const int row = m0 + t, P = rt.n_parts;
         const bool with_alpha = rt.mode == 1 && rt.alpha.log_alpha != nullptr;
         const float ec = with_alpha ? expf(rt.alpha.log_alpha[0]) : (rt.ent_coef ? rt.ent_coef[0] : 0.0f);
         const float kq = rt.scale * 2.0f / (float)B, inv = 1.0f / (float)B;
-        float gqv, qown = 0.0f;
         if (rt.mode == 1) {
             float q = fminf(q_from_parts(rt.q_part[2], rt.b3[2], P, B, row), q_from_parts(rt.q_part[3], rt.b3[3], P, B, row));
             if (rt.next_logp) q = q - ec * rt.next_logp[row];
-            const float tq = rt.rew[row] + (1.0f - rt.done[row]) * rt.gamma * q;
-            qown = q_from_parts(rt.q_part[g], rt.b3[g], P, B, row);
-            gqv = kq * (qown - tq);
-            if (g == 0 && blockIdx.x == 0 && rt.target_out) rt.target_out[row] = tq;
+            o_tq = rt.rew[row] + (1.0f - rt.done[row]) * rt.gamma * q;
+            o_q = q_from_parts(rt.q_part[g], rt.b3[g], P, B, row);
+            o_gq = kq * (o_q - o_tq);
         } else if (rt.mode == 3) {
-            qown = q_from_parts(rt.q_part[0], rt.b3[0], P, B, row);
-            gqv = -inv;
+            o_q = q_from_parts(rt.q_part[0], rt.b3[0], P, B, row);
+            o_gq = -inv;
         } else {
             const float q1 = q_from_parts(rt.q_part[0], rt.b3[0], P, B, row), q2 = q_from_parts(rt.q_part[1], rt.b3[1], P, B, row);
             const bool first = q1 <= q2;
-            qown = g == 0 ? q1 : q2;
-            gqv = (first == (g == 0)) ? -inv : 0.0f;
+            o_q = g == 0 ? q1 : q2;
+            o_gq = (first == (g == 0)) ? -inv : 0.0f;
         }
-        gs[t] = gqv;
-        if (blockIdx.x == 0) {
-            if (rt.q_out) rt.q_out[(int64_t)g * B + row] = qown;
-            if (rt.gq_out) rt.gq_out[(int64_t)g * B + row] = gqv;
-        }
+        gs[t] = o_gq;
     }
-    __syncthreads();
-    // (c) dz2 = dq * w3 * relu'(h2), recomputed by every workgroup of the row group into the panel; each stores its share of columns
+    lds_barrier();
+    // (c) dz2 = dq * w3 * relu'(h2), recomputed by every workgroup of the row group into the panel (values kept for the store at the end)
     {
-        const int cpg = (H2 + gridDim.x - 1) / gridDim.x;
-        for (int c = t; c < H2; c += CH_THREADS) {
-            const float wv = net.w3[c];
-            const bool mine = a.dz2 != nullptr && c / cpg == (int)blockIdx.x;
-            float y[16];
+        float gq[16];
 #pragma unroll
-            for (int row = 0; row < 16; ++row) y[row] = net.h2[(int64_t)(m0 + row) * H2 + c];
+        for (int q = 0; q < 4; ++q) {
+            const float4 g4 = *reinterpret_cast<const float4 *>(gs + 4 * q);
+            gq[4 * q] = g4.x; gq[4 * q + 1] = g4.y; gq[4 * q + 2] = g4.z; gq[4 * q + 3] = g4.w;
+        }
 #pragma unroll
-            for (int row = 0; row < 16; ++row) {
-                const float d = y[row] > 0.0f ? gs[row] * wv : 0.0f;
-                panel[row * ld + c] = d;
-                if (mine) a.dz2[((int64_t)g * B + m0 + row) * H2 + c] = d;
+        for (int i = 0; i < 2; ++i) {
+            const int c = t + CH_THREADS * i;
+            if (c < H2) {
+#pragma unroll
+                for (int row = 0; row < 16; ++row) {
+                    y[i][row] = y[i][row] > 0.0f ? gq[row] * w3c[i] : 0.0f;
+                    panel[row * ld + c] = y[i][row];
+                }
             }
         }
     }
-    __syncthreads();
+    lds_barrier();
     // (d) dz1 tile = (dz2 W2)[rows][k0 .. k0 + 15], (e) split-K combine, (f) * relu'(h1); partial action gradient
     f32x4 acc = tile_mma<NQ>(panel, ld, H2, bq, ks, S);
     acc = combine_split_k(acc, smem, T, S);
-    const int A = W - a.obs_dim;
+    float d[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     if (wave < T) {
-        float d[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            d[e] = (col < H1 && ty[e] > 0.0f) ? acc[e] : 0.0f;
-            if (a.dz1 && col < H1) a.dz1[((int64_t)g * B + m0 + 4 * h + e) * H1 + col] = d[e];
-        }
+        for (int e = 0; e < 4; ++e) d[e] = (tile_ok && ty[e] > 0.0f) ? acc[e] : 0.0f;
         if (a.gact_part) {
+#pragma unroll
             for (int j = 0; j < A; ++j) {
-                const float wv = col < H1 ? net.w1[(int64_t)col * W + a.obs_dim + j] : 0.0f;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float s = rowsum16(d[e] * wv);
+                    const float s = rowsum16(d[e] * w1a[j]);
                     if (r == 0) red[(tile * 16 + 4 * h + e) * 8 + j] = s;
                 }
             }
         }
     }
     if (a.gact_part) {
-        __syncthreads();
+        lds_barrier();
         if (t < 16 * A) {
             const int row = t / A, j = t % A;
             float s = red[row * 8 + j];
             for (int tl = 1; tl < T; ++tl) s += red[(tl * 16 + row) * 8 + j];
             a.gact_part[(((int64_t)g * gridDim.x + blockIdx.x) * B + m0 + row) * A + j] = s;
         }
+    }
+    // ---- global stores, all behind the last barrier ----
+    if (a.dz1 && wave < T && tile_ok) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a.dz1[((int64_t)g * B + m0 + 4 * h + e) * H1 + k0 + r] = d[e];
+    }
+    if (a.dz2) {  // each workgroup of the row group stores its share of the columns
+        const int cpg = (H2 + gridDim.x - 1) / gridDim.x;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int c = t + CH_THREADS * i;
+            if (c < H2 && c / cpg == (int)blockIdx.x) {
+#pragma unroll
+                for (int row = 0; row < 16; ++row) a.dz2[((int64_t)g * B + m0 + row) * H2 + c] = y[i][row];
+            }
+        }
+    }
+    if (t < 16 && blockIdx.x == 0) {
+        const int row = m0 + t;
+        if (rt.q_out) rt.q_out[(int64_t)g * B + row] = o_q;
+        if (rt.gq_out) rt.gq_out[(int64_t)g * B + row] = o_gq;
+        if (rt.mode == 1 && g == 0 && rt.target_out) rt.target_out[row] = o_tq;
     }
 }
 
@@ -612,26 +680,27 @@ struct ActorBwdArgs {
     int batch, tiles;
 };
 
-template <int NQ>
+template <int D, int A, int NQ>
 __global__ __launch_bounds__(CH_THREADS) void sac_actor_chain_bwd_kernel(const ActorBwdArgs a)
 {
     extern __shared__ __align__(16) float smem[];
+    constexpr int W = D + A;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, r = lane & 15, h = lane >> 4;
     const int T = a.tiles, S = CH_WAVES / T, tile = wave % T, ks = wave / T;
-    const int D = a.net.obs_dim, A = a.net.act_dim, W = D + A, H1 = a.net.h1, H2 = a.net.h2, B = a.batch;
-    const int k0 = (blockIdx.x * T + tile) * 16, m0 = blockIdx.y * 16, col = k0 + r;
+    const int H1 = a.net.h1, H2 = a.net.h2, B = a.batch;
+    const int k0 = (blockIdx.x * T + tile) * 16, m0 = blockIdx.y * 16;
+    const bool tile_ok = k0 < H1;
+    const int col = min(k0 + r, H1 - 1);
     float *gs = smem + SM_GS, *panel = smem + SM_PANEL;
     const int ld = H2 + 4;
     float4 bq[NQ];
     load_b_bwd<NQ>(bq, a.net.w2, H2, H1, k0, ks, S);
     float ty[4];
-    {
-        const __amdgpu_buffer_rsrc_t rh = rsrc_of(a.a_h1, (int64_t)B * H1);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) ty[e] = ld32(rh, col < H1 ? 4 * ((m0 + 4 * h + e) * H1 + col) : BUF_OOB);
-    }
+    for (int e = 0; e < 4; ++e) ty[e] = a.a_h1[(int64_t)(m0 + 4 * h + e) * H1 + col];
     // (b) d(loss)/d(action) from the critic's partial sums, then the squashed-Gaussian head's backward (gaussian_head_bwd_kernel's
-    //     expressions): g_params[row] = (d/d mean | d/d log_std)
+    //     expressions): g_params[row] = (d/d mean | d/d log_std) -> gs[16][8] (zero-padded: the k chunk of the dz2 MFMA)
+    float o_gu = 0.0f, o_gls = 0.0f;
     if (t < 16 * A) {
         const int row = t / A, j = t % A, b = m0 + row;
         float ga = 0.0f;
@@ -641,68 +710,82 @@ __global__ __launch_bounds__(CH_THREADS) void sac_actor_chain_bwd_kernel(const A
         const float av = a.x_pi[(int64_t)b * W + D + j], raw = a.params[(int64_t)b * 2 * A + A + j];
         const float s = expf(fminf(fmaxf(raw, LOG_STD_MIN), LOG_STD_MAX));
         const float one_m = 1.0f - av * av;
-        const float gu = ga * one_m + gl * (2.0f * av * one_m / (one_m + 1e-6f));
-        const float gls = (raw >= LOG_STD_MIN && raw <= LOG_STD_MAX) ? gu * a.eps[(int64_t)b * A + j] * s - gl : 0.0f;
-        gs[row * 8 + j] = gu;
-        gs[row * 8 + A + j] = gls;
-        if (blockIdx.x == 0) {
-            a.g_params[(int64_t)b * 2 * A + j] = gu;
-            a.g_params[(int64_t)b * 2 * A + A + j] = gls;
-        }
+        o_gu = ga * one_m + gl * (2.0f * av * one_m / (one_m + 1e-6f));
+        o_gls = (raw >= LOG_STD_MIN && raw <= LOG_STD_MAX) ? o_gu * a.eps[(int64_t)b * A + j] * s - gl : 0.0f;
+        gs[row * 8 + j] = o_gu;
+        gs[row * 8 + A + j] = o_gls;
     }
-    __syncthreads();
-    // (c) dz2 = (g_params hw) * relu'(a_h2): 2A terms per element, j ascending (gaussian_head_bwd_input_kernel's chain)
+    lds_barrier();
+    // (c) dz2 = (g_params hw) * relu'(a_h2) on the matrix cores: K = 2A is one (A = 2) or two (A = 4) MFMA steps per 16 x 16 tile;
+    //     A operand = g_params[r][h] (LDS), B operand = hw[h][column] straight from L2; the wave takes the tiles wave, wave + 4, ...
     {
+        const float ga0 = gs[r * 8 + h], ga1 = A == 4 ? gs[r * 8 + 4 + h] : 0.0f;
         const int cpg = (H2 + gridDim.x - 1) / gridDim.x;
-        for (int c = t; c < H2; c += CH_THREADS) {
-            float wq[2 * MAX_A];
+        for (int tl = wave; tl < H2 / 16; tl += CH_WAVES) {
+            const int c = 16 * tl + r;
+            const float hb0 = a.net.hw[(int64_t)h * H2 + c], hb1 = A == 4 ? a.net.hw[(int64_t)(4 + h) * H2 + c] : 0.0f;
+            float m[4];
 #pragma unroll
-            for (int j = 0; j < 2 * MAX_A; ++j) wq[j] = j < 2 * A ? a.net.hw[(int64_t)j * H2 + c] : 0.0f;
-            const bool mine = c / cpg == (int)blockIdx.x;
-            float y[16];
+            for (int e = 0; e < 4; ++e) m[e] = a.a_h2[(int64_t)(m0 + 4 * h + e) * H2 + c];
+            f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ga0, hb0, acc, 0, 0, 0);
+            if (A == 4) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ga1, hb1, acc, 0, 0, 0);
+            const bool mine = c / cpg == (int)blockIdx.x;  // this workgroup's share of the dz2 columns (stored now: nothing waits for it)
 #pragma unroll
-            for (int row = 0; row < 16; ++row) y[row] = a.a_h2[(int64_t)(m0 + row) * H2 + c];
-#pragma unroll
-            for (int row = 0; row < 16; ++row) {
-                float acc = 0.0f;
-#pragma unroll
-                for (int j = 0; j < 2 * MAX_A; ++j)
-                    if (j < 2 * A) acc = __fmaf_rn(gs[row * 8 + j], wq[j], acc);
-                const float d = y[row] > 0.0f ? acc : 0.0f;
-                panel[row * ld + c] = d;
-                if (mine) a.dz2[(int64_t)(m0 + row) * H2 + c] = d;
+            for (int e = 0; e < 4; ++e) {
+                const float dv = m[e] > 0.0f ? acc[e] : 0.0f;
+                panel[(4 * h + e) * ld + c] = dv;
+                if (mine) a.dz2[(int64_t)(m0 + 4 * h + e) * H2 + c] = dv;
             }
         }
     }
-    __syncthreads();
+    lds_barrier();
     f32x4 acc = tile_mma<NQ>(panel, ld, H2, bq, ks, S);
     acc = combine_split_k(acc, smem, T, S);
-    if (wave < T && col < H1) {
+    // ---- global stores ----
+    if (wave < T && tile_ok) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) a.dz1[(int64_t)(m0 + 4 * h + e) * H1 + col] = ty[e] > 0.0f ? acc[e] : 0.0f;
+        for (int e = 0; e < 4; ++e) a.dz1[(int64_t)(m0 + 4 * h + e) * H1 + k0 + r] = ty[e] > 0.0f ? acc[e] : 0.0f;
+    }
+    if (t < 16 * A && blockIdx.x == 0) {
+        const int row = t / A, j = t % A, b = m0 + row;
+        a.g_params[(int64_t)b * 2 * A + j] = o_gu;
+        a.g_params[(int64_t)b * 2 * A + A + j] = o_gls;
     }
 }
 
-// chunks of 16 along the reduction a wave owns, rounded up to an instantiated size
+// chunks of 16 along the reduction a wave owns, rounded up to an instantiated size (0: not covered)
 static int nq_for(int kdim, int tiles)
 {
     const int s = CH_WAVES / tiles, nch = (kdim + 15) / 16, per = (nch + s - 1) / s;
-    return per <= 4 ? 4 : per <= 8 ? 8 : per <= 16 ? 16 : 32;
+    return per <= 4 ? 4 : per <= 8 ? 8 : per <= 16 ? 16 : 0;
 }
 
 static bool chain_dims_ok(int h1, int h2, int64_t batch, int tiles)
 {
-    return h1 >= 16 && h2 >= 16 && h1 <= CSTR_CHAIN_MAX_WIDTH && h2 <= CSTR_CHAIN_MAX_WIDTH && h1 % 4 == 0 && h2 % 4 == 0 && batch >= 16 &&
+    return h1 >= 16 && h2 >= 16 && h1 <= CSTR_CHAIN_MAX_WIDTH && h2 <= CSTR_CHAIN_MAX_WIDTH && h1 % 16 == 0 && h2 % 16 == 0 && batch >= 16 &&
            batch <= 1024 && batch % 16 == 0 && (tiles == 1 || tiles == 2 || tiles == 4);
 }
 
-#define CHAIN_DISPATCH(KERNEL, NQV, GRID, LDS, STREAM, ARGS)                                   \
-    do {                                                                                       \
-        if ((NQV) == 4) KERNEL<4><<<GRID, CH_THREADS, LDS, STREAM>>>(ARGS);                    \
-        else if ((NQV) == 8) KERNEL<8><<<GRID, CH_THREADS, LDS, STREAM>>>(ARGS);               \
-        else if ((NQV) == 16) KERNEL<16><<<GRID, CH_THREADS, LDS, STREAM>>>(ARGS);             \
-        else KERNEL<32><<<GRID, CH_THREADS, LDS, STREAM>>>(ARGS);                              \
+static int chain_layout(int obs_dim, int act_dim)
+{
+    return (obs_dim == 4 && act_dim == 2) ? 0 : (obs_dim == 8 && act_dim == 2) ? 1 : (obs_dim == 8 && act_dim == 4) ? 2 : -1;
+}
+
+#define CHAIN_NQ(KERNEL, D_, A_, NQV, GRID, LDS, STREAM, ARGS)                                     \
+    do {                                                                                           \
+        if ((NQV) == 4) KERNEL<D_, A_, 4><<<GRID, CH_THREADS, LDS, STREAM>>>(ARGS);                \
+        else if ((NQV) == 8) KERNEL<D_, A_, 8><<<GRID, CH_THREADS, LDS, STREAM>>>(ARGS);           \
+        else KERNEL<D_, A_, 16><<<GRID, CH_THREADS, LDS, STREAM>>>(ARGS);                          \
     } while (0)
+#define CHAIN_DISPATCH(KERNEL, LAY, NQV, GRID, LDS, STREAM, ARGS)                                  \
+    do {                                                                                           \
+        if ((LAY) == 0) CHAIN_NQ(KERNEL, 4, 2, NQV, GRID, LDS, STREAM, ARGS);                      \
+        else if ((LAY) == 1) CHAIN_NQ(KERNEL, 8, 2, NQV, GRID, LDS, STREAM, ARGS);                 \
+        else CHAIN_NQ(KERNEL, 8, 4, NQV, GRID, LDS, STREAM, ARGS);                                 \
+    } while (0)
+
+constexpr size_t CHAIN_LDS_LIMIT = 64 * 1024;
 
 }  // namespace
 
@@ -719,11 +802,12 @@ static int check_actor(const cstr_sac_actor_t *n)
 extern "C" int cstr_sac_actor_chain_fwd_f32(const cstr_sac_actor_t *actor, const cstr_ring_t *ring, int64_t *ring_ctl, int advance_ring,
                                             uint64_t *rollout_rng_ctl, uint64_t rollout_rng_advance, const int32_t *sample_idx, int64_t batch,
                                             float *x_data, float *x_pi, float *x_next, float *out_done, float *out_rew, float *a_h1,
-                                            float *a_h2, float *head_part, int tiles, cstr_stream_t stream)
+                                            float *a_h2, float *head_part, const uint64_t *head_rng_ctl, float *eps_all, int tiles,
+                                            cstr_stream_t stream)
 {
     const int rc = check_actor(actor);
     if (rc) return rc;
-    if (!x_pi || !x_next || !head_part) return CSTR_E_BADARG;
+    if (!x_pi || !x_next || !head_part || (eps_all && !head_rng_ctl)) return CSTR_E_BADARG;
     if (!chain_dims_ok(actor->h1, actor->h2, batch, tiles)) return CSTR_E_UNSUPPORTED;
     if (!aligned8(x_pi) || !aligned8(x_next)) return CSTR_E_BADARG;
     ActorFwdArgs a = {};
@@ -740,19 +824,20 @@ extern "C" int cstr_sac_actor_chain_fwd_f32(const cstr_sac_actor_t *actor, const
     a.ring_ctl = ring_ctl; a.advance_ring = advance_ring; a.rng_ctl = rollout_rng_ctl; a.rng_advance = rollout_rng_advance;
     a.idx = sample_idx; a.batch = (int)batch; a.tiles = tiles;
     a.x_data = x_data; a.x_pi = x_pi; a.x_next = x_next; a.out_done = out_done; a.out_rew = out_rew;
-    a.a_h1 = a_h1; a.a_h2 = a_h2; a.head_part = head_part;
+    a.a_h1 = a_h1; a.a_h2 = a_h2; a.head_part = head_part; a.head_rng_ctl = head_rng_ctl; a.eps_all = eps_all;
     const dim3 grid((unsigned)((actor->h2 + 16 * tiles - 1) / (16 * tiles)), (unsigned)(2 * batch / 16));
-    const size_t lds = chain_lds_bytes(actor->h1);
-    const int nq = nq_for(actor->h1, tiles);
+    const size_t lds = chain_lds_bytes(actor->h1, true);
+    const int nq = nq_for(actor->h1, tiles), lay = chain_layout(actor->obs_dim, actor->act_dim);
+    if (!nq || lds > CHAIN_LDS_LIMIT) return CSTR_E_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
-    CHAIN_DISPATCH(sac_actor_chain_fwd_kernel, nq, grid, lds, s, a);
+    CHAIN_DISPATCH(sac_actor_chain_fwd_kernel, lay, nq, grid, lds, s, a);
     return (int)hipGetLastError();
 }
 
-extern "C" int cstr_q_chain_fwd_f32(const cstr_chain_net_t *nets, int n_nets, int w_in, int h1, int h2, int64_t batch,
+extern "C" int cstr_q_chain_fwd_f32(const cstr_chain_net_t *nets, int n_nets, int w_in, int obs_dim, int h1, int h2, int64_t batch,
                                     const cstr_sac_head_fin_t *fin, int tiles, cstr_stream_t stream)
 {
-    if (!nets || n_nets < 1 || n_nets > CSTR_CHAIN_MAX_NETS || w_in < 1 || w_in > 12) return CSTR_E_BADARG;
+    if (!nets || n_nets < 1 || n_nets > CSTR_CHAIN_MAX_NETS || w_in < 1 || w_in > 12 || obs_dim < 1 || obs_dim >= w_in) return CSTR_E_BADARG;
     if (!chain_dims_ok(h1, h2, batch, tiles)) return CSTR_E_UNSUPPORTED;
     QFwdArgs a = {};
     for (int g = 0; g < n_nets; ++g) {
@@ -762,19 +847,19 @@ extern "C" int cstr_q_chain_fwd_f32(const cstr_chain_net_t *nets, int n_nets, in
         a.nets[g] = n;
     }
     if (fin) {
-        if (!fin->head_part || !fin->hb || fin->n_parts < 1 || fin->act_dim < 1 || fin->act_dim > MAX_A || fin->obs_dim + fin->act_dim != w_in)
+        if (!fin->head_part || !fin->hb || fin->n_parts < 1 || fin->act_dim < 1 || fin->act_dim > MAX_A || fin->obs_dim != obs_dim || fin->obs_dim + fin->act_dim != w_in)
             return CSTR_E_BADARG;
-        if (!fin->eps_in && !fin->rng_ctl) return CSTR_E_BADARG;
-        if (!fin->x_pi || !fin->x_next || !fin->params || !fin->eps_out || !fin->logp_pi || !fin->logp_next) return CSTR_E_BADARG;
+        if (!fin->eps || !fin->x_pi || !fin->x_next || !fin->params || !fin->logp_pi || !fin->logp_next) return CSTR_E_BADARG;
         a.fin = *fin;
         a.has_fin = 1;
     }
-    a.n_nets = n_nets; a.w_in = w_in; a.h1 = h1; a.h2 = h2; a.batch = (int)batch; a.tiles = tiles;
+    a.n_nets = n_nets; a.h1 = h1; a.h2 = h2; a.batch = (int)batch; a.tiles = tiles;
     const dim3 grid((unsigned)((h2 + 16 * tiles - 1) / (16 * tiles)), (unsigned)(batch / 16), (unsigned)n_nets);
-    const size_t lds = chain_lds_bytes(h1);
-    const int nq = nq_for(h1, tiles);
+    const size_t lds = chain_lds_bytes(h1, true);
+    const int nq = nq_for(h1, tiles), lay = chain_layout(obs_dim, w_in - obs_dim);
+    if (!nq || lay < 0 || lds > CHAIN_LDS_LIMIT) return CSTR_E_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
-    CHAIN_DISPATCH(q_chain_fwd_kernel, nq, grid, lds, s, a);
+    CHAIN_DISPATCH(q_chain_fwd_kernel, lay, nq, grid, lds, s, a);
     return (int)hipGetLastError();
 }
 
@@ -785,8 +870,7 @@ extern "C" int cstr_q_chain_bwd_f32(const cstr_chain_net_t *nets, int n_nets, co
     if (root->mode < 1 || root->mode > 3 || root->n_parts < 1) return CSTR_E_BADARG;
     if ((root->mode == 3) != (n_nets == 1)) return CSTR_E_BADARG;
     if (!chain_dims_ok(h1, h2, root->batch, tiles)) return CSTR_E_UNSUPPORTED;
-    if (w_in - obs_dim > MAX_A && gact_part) return CSTR_E_UNSUPPORTED;
-    QBwdArgs a = {};
+        QBwdArgs a = {};
     for (int g = 0; g < n_nets; ++g) {
         const cstr_chain_net_t &n = nets[g];
         if (!n.w1 || !n.w2 || !n.w3 || !n.h1 || !n.h2) return CSTR_E_BADARG;
@@ -799,13 +883,14 @@ extern "C" int cstr_q_chain_bwd_f32(const cstr_chain_net_t *nets, int n_nets, co
     if (root->mode == 2 && (!root->logp || !root->ent_coef)) return CSTR_E_BADARG;
     if (root->mode == 1 && root->alpha.log_alpha && (!root->alpha.logp_pi || !root->alpha.grad_out || !root->alpha.ent_coef_out)) return CSTR_E_BADARG;
     a.root = *root;
-    a.n_nets = n_nets; a.w_in = w_in; a.obs_dim = obs_dim; a.h1 = h1; a.h2 = h2; a.tiles = tiles;
+    a.n_nets = n_nets; a.h1 = h1; a.h2 = h2; a.tiles = tiles;
     a.dz2 = dz2; a.dz1 = dz1; a.gact_part = gact_part;
     const dim3 grid((unsigned)((h1 + 16 * tiles - 1) / (16 * tiles)), (unsigned)(root->batch / 16 + 1), (unsigned)n_nets);
-    const size_t lds = chain_lds_bytes(h2);
-    const int nq = nq_for(h2, tiles);
+    const size_t lds = chain_lds_bytes(h2, false);
+    const int nq = nq_for(h2, tiles), lay = chain_layout(obs_dim, w_in - obs_dim);
+    if (!nq || lay < 0 || lds > CHAIN_LDS_LIMIT) return CSTR_E_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
-    CHAIN_DISPATCH(q_chain_bwd_kernel, nq, grid, lds, s, a);
+    CHAIN_DISPATCH(q_chain_bwd_kernel, lay, nq, grid, lds, s, a);
     return (int)hipGetLastError();
 }
 
@@ -825,9 +910,10 @@ extern "C" int cstr_sac_actor_chain_bwd_f32(const cstr_sac_actor_t *actor, const
     a.x_pi = x_pi; a.params = params; a.eps = eps; a.a_h1 = a_h1; a.a_h2 = a_h2;
     a.g_params = g_params; a.dz2 = dz2; a.dz1 = dz1; a.batch = (int)batch; a.tiles = tiles;
     const dim3 grid((unsigned)((actor->h1 + 16 * tiles - 1) / (16 * tiles)), (unsigned)(batch / 16));
-    const size_t lds = chain_lds_bytes(actor->h2);
-    const int nq = nq_for(actor->h2, tiles);
+    const size_t lds = chain_lds_bytes(actor->h2, false);
+    const int nq = nq_for(actor->h2, tiles), lay = chain_layout(actor->obs_dim, actor->act_dim);
+    if (!nq || lds > CHAIN_LDS_LIMIT) return CSTR_E_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
-    CHAIN_DISPATCH(sac_actor_chain_bwd_kernel, nq, grid, lds, s, a);
+    CHAIN_DISPATCH(sac_actor_chain_bwd_kernel, lay, nq, grid, lds, s, a);
     return (int)hipGetLastError();
 }
