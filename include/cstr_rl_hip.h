@@ -507,6 +507,31 @@ int cstr_sac_actor_loss_f32(const float *logp, const float *q1, const float *q2,
 /* Deterministic-policy actor loss (core/td3/td3.py:194, core/maddpg/maddpg.py:174): loss = -mean(q), gq = -1/B. */
 int cstr_neg_mean_loss_f32(const float *q, float *gq, float *loss_out, float *loss_sum, int64_t batch, cstr_stream_t stream);
 
+/* cstr_linear_bwd_weight_sets_f32 with the OPTIMISER STEP inside (single-GPU training: no collective sits between a gradient and
+ * its Adam step; torch.optim.Adam's arithmetic, core/sac/sac.py:266-268, :279-281): the workgroup that has reduced a 16 x 16 tile of
+ * dW (and db) applies Adam to exactly those parameters -- parameter / moment quads requested at entry, one launch instead of two.
+ * dw / db are still written (the gradient arena stays inspectable). `flat` (n_flat <= 4): segments WITHOUT a weight-gradient tile
+ * in the same launch -- Adam over a flat range (SAC's entropy coefficient, whose gradient an earlier launch wrote) or a soft target
+ * update (polyak_source set) of parameters this launch does not change.
+ * Every step counter must have been advanced by an EARLIER launch (cstr_chain_root_t.adam_advance: state["step"] += 1 and the
+ * running beta powers): this launch only reads adam_ctl and writes no control word (no last-workgroup ticket). m > 32 rows. */
+typedef struct cstr_adam_opt {
+    const int64_t *adam_ctl; /* {step, ticket, beta1^step, beta2^step (f64 bits)} AFTER this step's increment */
+    const double *lr;        /* [1] */
+    double beta1, beta2, eps;
+    float grad_scale;
+    int32_t reserved;
+} cstr_adam_opt_t;
+typedef struct cstr_wgrad_adam_set {
+    cstr_wgrad_set_t g;      /* the gradient part: dz, x, ldx, dw, db, m, n, k */
+    float *w, *w_m, *w_v;    /* the weight [n][k] and its exp_avg / exp_avg_sq */
+    float *b, *b_m, *b_v;    /* the bias [n] and its moments (with g.db) */
+    float *shadow;           /* tile-major copy of w kept current (cstr_policy_swizzle_f32's layout) or NULL */
+    int32_t opt, reserved;   /* index into opts */
+} cstr_wgrad_adam_set_t;
+int cstr_linear_bwd_weight_adam_sets_f32(const cstr_wgrad_adam_set_t *sets, int n_sets, const cstr_adam_opt_t *opts, int n_opts,
+                                         const cstr_adam_seg_t *flat, int n_flat, cstr_stream_t stream);
+
 /* ---- row-chain kernels: a gradient step's forward / backward chains with FEWER launch boundaries ------------------------------
  * A chain of Linear layers is row-local (row r of layer l+1 needs row r of layer l only), but a launch boundary is the cheapest
  * way on this chip to hand data between workgroups (an in-kernel cross-workgroup barrier costs 4-17 us, an empty dependent launch
@@ -600,6 +625,10 @@ typedef struct cstr_chain_root {
     cstr_alpha_part_t alpha;              /* mode 1: log_alpha NULL = absent */
     uint64_t *rng_ctl;                    /* or NULL: rng_ctl[1] += rng_advance by the loss workgroup */
     uint64_t rng_advance;
+    /* Adam control words the loss workgroup advances on behalf of the optimiser launch behind this one (state["step"] += 1,
+     * beta^step *= beta: cstr_linear_bwd_weight_adam_sets_f32 reads them pre-advanced); NULL = none */
+    int64_t *adam_advance[2];
+    double adam_beta1[2], adam_beta2[2];
 } cstr_chain_root_t;
 int cstr_q_chain_bwd_f32(const cstr_chain_net_t *nets, int n_nets, const cstr_chain_root_t *root, int w_in, int obs_dim, int h1, int h2,
                          float *dz2, float *dz1, float *gact_part, int tiles, cstr_stream_t stream);

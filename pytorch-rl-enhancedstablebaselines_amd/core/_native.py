@@ -25,6 +25,7 @@ SYMBOLS = (
     "cstr_squashed_gaussian_fwd_f32", "cstr_squashed_gaussian_bwd_f32", "cstr_sac_alpha_f32", "cstr_twin_q_loss_f32",
     "cstr_sac_actor_loss_f32", "cstr_neg_mean_loss_f32",
     "cstr_sac_actor_chain_fwd_f32", "cstr_q_chain_fwd_f32", "cstr_q_chain_bwd_f32", "cstr_sac_actor_chain_bwd_f32",
+    "cstr_linear_bwd_weight_adam_sets_f32",
 )
 
 
@@ -109,7 +110,19 @@ class ChainRoot(C.Structure):
     _fields_ = [("mode", C.c_int32), ("batch", C.c_int32), ("gamma", C.c_float), ("scale", C.c_float), ("q_part", C.c_void_p * 4),
                 ("b3", C.c_void_p * 4), ("n_parts", C.c_int32), ("reserved", C.c_int32)] + [
         (n, C.c_void_p) for n in ("next_logp", "rew", "done", "ent_coef", "logp", "target_out", "q_out", "gq_out", "loss_out", "loss_sum")] + [
-        ("alpha", AlphaPart), ("rng_ctl", C.c_void_p), ("rng_advance", C.c_uint64)]
+        ("alpha", AlphaPart), ("rng_ctl", C.c_void_p), ("rng_advance", C.c_uint64), ("adam_advance", C.c_void_p * 2),
+        ("adam_beta1", C.c_double * 2), ("adam_beta2", C.c_double * 2)]
+
+
+class AdamOpt(C.Structure):
+    """cstr_adam_opt_t"""
+    _fields_ = [("adam_ctl", C.c_void_p), ("lr", C.c_void_p), ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double),
+                ("grad_scale", C.c_float), ("reserved", C.c_int32)]
+
+
+class WgradAdamSet(C.Structure):
+    """cstr_wgrad_adam_set_t"""
+    _fields_ = [("g", WgradSet)] + [(n, C.c_void_p) for n in ("w", "w_m", "w_v", "b", "b_m", "b_v", "shadow")] + [("opt", C.c_int32), ("reserved", C.c_int32)]
 
 
 class VecNormCfg(C.Structure):

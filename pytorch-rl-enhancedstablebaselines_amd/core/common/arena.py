@@ -171,6 +171,11 @@ class FlatAdam:
             hip_ops.adam(self.arena.flat, self.arena.grad, self.exp_avg, self.exp_avg_sq, self.ctl, self.lr_dev,
                          g["betas"][0], g["betas"][1], g["eps"], self.grad_scale)
 
+    def moments_of(self, param: nn.Parameter):
+        """(exp_avg, exp_avg_sq) views of one parameter of this arena (the fused weight-gradient + Adam launch updates them per tile)."""
+        o = self.arena.offset_of[id(param)]
+        return self.exp_avg[o:o + param.numel()], self.exp_avg_sq[o:o + param.numel()]
+
     def _segment(self) -> tuple:
         g = self.param_groups[0]
         seg = (self.arena.flat, self.arena.grad, self.exp_avg, self.exp_avg_sq, self.ctl, self.lr_dev, g["betas"][0], g["betas"][1],

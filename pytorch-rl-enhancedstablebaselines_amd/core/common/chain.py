@@ -27,6 +27,8 @@ from core import _native as nv
 from core.common import fused, hip_ops
 
 USE_CHAIN = os.environ.get("CSTR_CHAIN", "1") != "0"
+# single GPU: the dW / db launch applies the Adam step to the tiles it has reduced (cstr_linear_bwd_weight_adam_sets_f32): 8 launches
+USE_WGRAD_ADAM = os.environ.get("CSTR_WGRAD_ADAM", "1") != "0"
 # 16-column MFMA tiles per workgroup: actor forward, Q forward (4 networks), Q forward (2 networks), Q backward, actor backward
 TILES = tuple(int(v) for v in os.environ.get("CSTR_CHAIN_TILES", "2,4,2,2,1").split(","))
 
@@ -87,6 +89,16 @@ class SacChain:
         self.n_gact = hip_ops.chain_colgroups(self.cH1, self.t_qb)
         self.gact_part = e(2, self.n_gact, B, A)
         self.g_params, self.dz2a, self.dz1a = e(B, 2 * A), e(B, H2), e(B, H1)
+        # the merged (mu | log_std) head as (values, gradient, exp_avg, exp_avg_sq) views for the fused dW + Adam launch
+        self._head_params = None
+        aopt = model.actor.optimizer
+        off = getattr(getattr(aopt, "arena", None), "offset_of", {})
+        mu, ls = fa.actor.mu, fa.actor.log_std
+        if id(mu.weight) in off and id(mu.bias) in off and hasattr(aopt, "exp_avg"):
+            ow, ob, nw, nb = off[id(mu.weight)], off[id(mu.bias)], 2 * A * H2, 2 * A
+            if off.get(id(ls.weight)) == ow + A * H2 and off.get(id(ls.bias)) == ob + A:
+                self._head_params = ((fa._hw, fa._hwg, aopt.exp_avg[ow:ow + nw], aopt.exp_avg_sq[ow:ow + nw]),
+                                     (fa._hb, fa._hbg, aopt.exp_avg[ob:ob + nb], aopt.exp_avg_sq[ob:ob + nb]))
 
     def step(self, model, pb, gather, gradient_step: int) -> None:
         s, pol, B, W, D, A = model._loss_sums, model.policy, self.B, self.W, self.D, self.A
@@ -129,42 +141,69 @@ class SacChain:
             ent_coef, alpha = model.ent_coef_tensor.reshape(1), None
             s["ent_coef"] += ent_coef
         b3s = [self.crit[0][2][1], self.crit[1][2][1], self.targ[0][2][1], self.targ[1][2][1]]
+        # one GPU: no collective between a gradient and its optimiser step -> the dW / db launch applies Adam to its tiles; the step
+        # counters are advanced by the loss workgroup of the launch in front of it
+        fuse_opt = USE_WGRAD_ADAM and model.world_size == 1 and B > 32 and not getattr(model, "_force_segment_boundaries", False)
+        ent_opt = model.ent_coef_optimizer
         root = hip_ops.chain_root("td", B, [self.q_part4[g] for g in range(4)], b3s, self.n_q4, gamma=model.gamma, scale=0.5,
                                   next_logp=self.logp_next, rew=rd.rewards, done=rd.dones, ent_coef=ent_coef, target_out=model._target_q,
                                   q_out=self.q_out, gq_out=self.gq, loss_out=sto("critic", model._loss_now["critic"]), loss_sum=acc("critic"),
-                                  alpha=alpha, rng_advance=None if eps2 is not None else (fa.rng_ctl, 2 * B))
+                                  alpha=alpha, rng_advance=None if eps2 is not None else (fa.rng_ctl, 2 * B),
+                                  adam_advance=([model.critic.optimizer] + ([ent_opt] if ent_opt is not None else [])) if fuse_opt else ())
         back = [hip_ops.chain_net(self.crit[g], None, self.c_h1[g], self.c_h2[g]) for g in range(2)]
         hip_ops.q_chain_bwd(back, root, W, D, self.cH1, self.cH2, self.t_qb, dz2=self.dz2c, dz1=self.dz1c)
-        sets = []
-        for g in range(2):
-            (w1, b1), (w2, b2), (w3, b3) = self.crit[g]
-            sets += [(self.dz1c[g], pb.x_data, w1.grad, b1.grad), (self.dz2c[g], self.c_h1[g], w2.grad, b2.grad),
-                     (self.gq[g].view(B, 1), self.c_h2[g], w3.grad, b3.grad)]
-        hip_ops.linear_bwd_weight_sets(sets)
-        if model.ent_coef_optimizer is not None and not model._ent_rides_critic:
-            model._allreduce_grads(model._ent_arena)
-            model.ent_coef_optimizer.step()
-        model._allreduce_grads(pol.critic_arena)
-        if model.ent_coef_optimizer is not None and model._ent_rides_critic:
-            model.critic.optimizer.step_with(model.ent_coef_optimizer)
+        if fuse_opt:
+            sets = []
+            for g in range(2):
+                (w1, b1), (w2, b2), (w3, b3) = self.crit[g]
+                sets += [(self.dz1c[g], pb.x_data, w1, b1, 0, None), (self.dz2c[g], self.c_h1[g], w2, b2, 0, None),
+                         (self.gq[g].view(B, 1), self.c_h2[g], w3, b3, 0, None)]
+            hip_ops.linear_bwd_weight_adam_sets(sets, [model.critic.optimizer], [ent_opt._segment()] if ent_opt is not None else [])
         else:
-            model.critic.optimizer.step()
+            sets = []
+            for g in range(2):
+                (w1, b1), (w2, b2), (w3, b3) = self.crit[g]
+                sets += [(self.dz1c[g], pb.x_data, w1.grad, b1.grad), (self.dz2c[g], self.c_h1[g], w2.grad, b2.grad),
+                         (self.gq[g].view(B, 1), self.c_h2[g], w3.grad, b3.grad)]
+            hip_ops.linear_bwd_weight_sets(sets)
+            if model.ent_coef_optimizer is not None and not model._ent_rides_critic:
+                model._allreduce_grads(model._ent_arena)
+                model.ent_coef_optimizer.step()
+            model._allreduce_grads(pol.critic_arena)
+            if model.ent_coef_optimizer is not None and model._ent_rides_critic:
+                model.critic.optimizer.step_with(model.ent_coef_optimizer)
+            else:
+                model.critic.optimizer.step()
         # -- actor loss through the (updated, frozen) critics
         nets2 = [hip_ops.chain_net(self.crit[g], pb.x_pi, self.c_h1[g], self.c_h2[g], self.q_part2[g]) for g in range(2)]
         hip_ops.q_chain_fwd(nets2, W, D, self.cH1, self.cH2, B, self.t_q2)
         aroot = hip_ops.chain_root("sac_actor", B, [self.q_part2[0], self.q_part2[1]], b3s[:2], self.n_q2, ent_coef=ent_coef, logp=self.logp_pi,
-                                   q_out=self.qpi_out, loss_out=sto("actor", model._loss_now["actor"]), loss_sum=acc("actor"))
+                                   q_out=self.qpi_out, loss_out=sto("actor", model._loss_now["actor"]), loss_sum=acc("actor"),
+                                   adam_advance=[model.actor.optimizer] if fuse_opt else ())
         hip_ops.q_chain_bwd(back, aroot, W, D, self.cH1, self.cH2, self.t_qb, gact_part=self.gact_part)
         hip_ops.sac_actor_chain_bwd(self.actor, self.gact_part, 2, self.n_gact, ent_coef, pb.x_pi, self.params, eps, self.a_h1, self.a_h2,
                                     self.g_params, self.dz2a, self.dz1a, B, self.t_ab)
         l1, l2 = self.actor_layers
-        hip_ops.linear_bwd_weight_sets([(self.dz1a, pb.x_pi[:, :D], l1.weight.grad, l1.bias.grad), (self.dz2a, self.a_h1, l2.weight.grad, l2.bias.grad),
-                                        (self.g_params, self.a_h2, fa._hwg, fa._hbg)])
-        model._allreduce_grads(pol.actor_arena)
-        if gradient_step % model.target_update_interval == 0:  # :281 and :284-287 (disjoint arenas) in one launch
-            model.actor.optimizer.step_with(polyak=(pol.critic_arena, pol.critic_target_arena, model.tau))
+        soft = gradient_step % model.target_update_interval == 0
+        if fuse_opt and self._head_params is not None:
+            aopt = model.actor.optimizer
+            sh = aopt.shadow
+            hw_p, hb_p = self._head_params
+            sets = [(self.dz1a, pb.x_pi[:, :D], l1.weight, l1.bias, 0, sh[0] if sh is not None and sh[4] is l1.weight else None),
+                    (self.dz2a, self.a_h1, l2.weight, l2.bias, 0, sh[0] if sh is not None and sh[4] is l2.weight else None),
+                    (self.g_params, self.a_h2, hw_p, hb_p, 0, None)]
+            if not pol.critic_target_arena.same_layout(pol.critic_arena):
+                raise ValueError("Iterables have different lengths")  # zip_strict's error (utils.py:447)
+            flat = [("polyak", pol.critic_arena.flat, pol.critic_target_arena.flat, model.tau)] if soft else []
+            hip_ops.linear_bwd_weight_adam_sets(sets, [aopt], flat)  # :279-281 and :284-287
         else:
-            model.actor.optimizer.step()
+            hip_ops.linear_bwd_weight_sets([(self.dz1a, pb.x_pi[:, :D], l1.weight.grad, l1.bias.grad), (self.dz2a, self.a_h1, l2.weight.grad, l2.bias.grad),
+                                            (self.g_params, self.a_h2, fa._hwg, fa._hbg)])
+            model._allreduce_grads(pol.actor_arena)
+            if soft:  # :281 and :284-287 (disjoint arenas) in one launch
+                model.actor.optimizer.step_with(polyak=(pol.critic_arena, pol.critic_target_arena, model.tau))
+            else:
+                model.actor.optimizer.step()
         if model.debug_capture:
             model.last_train_tensors = dict(target_q=model._target_q.clone(), current_q=[self.q_out[0].clone().view(B, 1), self.q_out[1].clone().view(B, 1)],
                                             critic_loss=sto("critic", model._loss_now["critic"]).clone(),

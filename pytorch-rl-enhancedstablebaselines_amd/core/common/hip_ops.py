@@ -304,6 +304,14 @@ def adam(param, grad, exp_avg, exp_avg_sq, adam_ctl, lr_dev, beta1=0.9, beta2=0.
                                  C.c_int64(n), stream_ptr()), "cstr_adam_f32")
 
 
+def _adam_segments(segments):
+    """ctypes array of cstr_adam_seg_t from adam_multi's segment tuples."""
+    segs = list(segments)
+    arr = (nv.AdamSeg * max(len(segs), 1))()
+    _fill_adam_segments(arr, segs)
+    return arr, len(segs)
+
+
 def adam_multi(segments):
     """Several flat-arena updates in one launch; `segments` = iterable of adam()'s positional argument tuples (optionally
     followed by a shadow = (tile-major copy tensor, begin, n, k) or None: see policy_swizzle, and by own_target = (target tensor,
@@ -311,6 +319,11 @@ def adam_multi(segments):
     update of parameters no segment changes (<= 4 segments, mutually independent)."""
     segs = list(segments)
     arr = (nv.AdamSeg * len(segs))()
+    _fill_adam_segments(arr, segs)
+    check(nv.lib().cstr_adam_multi_f32(arr, C.c_int(len(segs)), stream_ptr()), "cstr_adam_multi_f32")
+
+
+def _fill_adam_segments(arr, segs) -> None:
     for i, seg in enumerate(segs):
         if seg[0] == "polyak":
             _, source, target, tau = seg
@@ -337,7 +350,6 @@ def adam_multi(segments):
             _chk(own, "own_target", (n,), th.float32)
         arr[i] = nv.AdamSeg(param.data_ptr(), grad.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(), adam_ctl.data_ptr(),
                             lr_dev.data_ptr(), beta1, beta2, eps, grad_scale, n, None, float(tau), *sh, None if own is None else own.data_ptr())
-    check(nv.lib().cstr_adam_multi_f32(arr, C.c_int(len(segs)), stream_ptr()), "cstr_adam_multi_f32")
 
 
 # ---- learner glue around the GEMMs (csrc/cstr_mlp.hip) ------------------------------------------------------------
@@ -945,9 +957,45 @@ def q_chain_fwd(nets, w_in: int, obs_dim: int, h1: int, h2: int, batch: int, til
                                         None if fin is None else C.byref(fin), C.c_int(tiles), stream_ptr()), "cstr_q_chain_fwd_f32")
 
 
+def linear_bwd_weight_adam_sets(sets, opts, flat=()):
+    """cstr_linear_bwd_weight_adam_sets_f32: dW / db of several Linears AND their Adam steps in one launch. `sets`: [(dz [M, N], x [M, K]
+    (row-strided ok), weight parameter, bias parameter, optimiser index, shadow tensor or None)]; the parameters' .grad and moment views
+    are looked up in `opts` = [FlatAdam, ...] (pre-advanced control words: see chain_root's adam_advance). `flat`: adam_multi segments
+    (no shadow) for parameters without a tile and soft target updates."""
+    sets, opts = list(sets), list(opts)
+    arr = (nv.WgradAdamSet * len(sets))()
+    oarr = (nv.AdamOpt * len(opts))()
+    for i, o in enumerate(opts):
+        g = o.param_groups[0]
+        oarr[i] = nv.AdamOpt(o.ctl.data_ptr(), o.lr_dev.data_ptr(), g["betas"][0], g["betas"][1], g["eps"], o.grad_scale, 0)
+    for i, (dz, x, weight, bias, oi, shadow) in enumerate(sets):
+        m, n = dz.shape
+        k = x.shape[-1]
+        _f32c(dz, f"dz[{i}]")
+        if not (x.is_cuda and x.dtype == th.float32 and x.dim() == 2 and x.stride(1) == 1 and x.shape[0] == m):
+            raise ValueError(f"x[{i}]: needs a float32 device matrix with unit inner stride and as many rows as dz")
+        # a parameter of the optimiser's arena, or an explicit (values, gradient, exp_avg, exp_avg_sq) quadruple of views (merged heads)
+        wq = weight if isinstance(weight, tuple) else (weight.detach(), weight.grad, *opts[oi].moments_of(weight))
+        bq = bias if isinstance(bias, tuple) else (bias.detach(), bias.grad, *opts[oi].moments_of(bias))
+        for t in wq:
+            if t is None or _f32c(t, f"weight[{i}]").numel() != n * k:
+                raise ValueError(f"set {i}: weight views do not match dz {tuple(dz.shape)} and x {tuple(x.shape)}")
+        for t in bq:
+            if t is None or _f32c(t, f"bias[{i}]").numel() != n:
+                raise ValueError(f"set {i}: bias views do not match dz {tuple(dz.shape)}")
+        if shadow is not None and _f32c(shadow, "shadow").numel() != swizzled_numel(n, k):
+            raise ValueError("shadow: wrong size")
+        arr[i] = nv.WgradAdamSet(nv.WgradSet(dz.data_ptr(), x.data_ptr(), max(x.stride(0), k), wq[1].data_ptr(), bq[1].data_ptr(), m, n, k),
+                                 wq[0].data_ptr(), wq[2].data_ptr(), wq[3].data_ptr(), bq[0].data_ptr(), bq[2].data_ptr(), bq[3].data_ptr(),
+                                 _dp(shadow), oi, 0)
+    farr, nf = _adam_segments(flat)
+    check(nv.lib().cstr_linear_bwd_weight_adam_sets_f32(arr, C.c_int(len(sets)), oarr, C.c_int(len(opts)), farr, C.c_int(nf), stream_ptr()),
+          "cstr_linear_bwd_weight_adam_sets_f32")
+
+
 def chain_root(mode: str, batch: int, q_parts, b3s, n_parts: int, gamma: float = 0.0, scale: float = 0.0, next_logp=None, rew=None, done=None,
                ent_coef=None, logp=None, target_out=None, q_out=None, gq_out=None, loss_out=None, loss_sum=None, alpha: Optional[dict] = None,
-               rng_advance=None) -> "nv.ChainRoot":
+               rng_advance=None, adam_advance=()) -> "nv.ChainRoot":
     part = nv.AlphaPart()
     if alpha is not None:
         part = nv.AlphaPart(alpha["log_alpha"].data_ptr(), alpha["logp_pi"].data_ptr(), float(alpha["target_entropy"]), alpha["grad_out"].data_ptr(),
@@ -956,9 +1004,12 @@ def chain_root(mode: str, batch: int, q_parts, b3s, n_parts: int, gamma: float =
     for i, (q, b) in enumerate(zip(q_parts, b3s)):
         qp[i], bb[i] = q.data_ptr(), b.data_ptr()
     rc_ptr, adv = (None, 0) if rng_advance is None else (rng_advance[0].data_ptr(), int(rng_advance[1]))
+    actl, ab1, ab2 = (C.c_void_p * 2)(), (C.c_double * 2)(), (C.c_double * 2)()
+    for i, opt in enumerate(adam_advance):  # FlatAdam optimisers whose step counter this launch advances (<= 2)
+        actl[i], (ab1[i], ab2[i]) = opt.ctl.data_ptr(), opt.param_groups[0]["betas"]
     return nv.ChainRoot({"td": 1, "sac_actor": 2, "neg_mean": 3}[mode], batch, float(gamma), float(scale), qp, bb, n_parts, 0, _dp(next_logp), _dp(rew),
                         _dp(done), None if alpha is not None else _dp(ent_coef), _dp(logp), _dp(target_out), _dp(q_out), _dp(gq_out), _dp(loss_out),
-                        _dp(loss_sum), part, rc_ptr, adv)
+                        _dp(loss_sum), part, rc_ptr, adv, actl, ab1, ab2)
 
 
 def q_chain_bwd(nets, root: "nv.ChainRoot", w_in: int, obs_dim: int, h1: int, h2: int, tiles: int, dz2=None, dz1=None, gact_part=None):

@@ -529,6 +529,13 @@ __device__ void chain_loss_workgroup(const cstr_chain_root_t &rt, float *sm)
         }
     }
     if (tid == 0 && rt.rng_ctl) rt.rng_ctl[1] += rt.rng_advance;  // nobody reads the offset in this launch
+    if (tid < 2 && rt.adam_advance[tid]) {  // state["step"] += 1 for the optimiser launch behind this one (adam_body's epilogue)
+        int64_t *ctl = rt.adam_advance[tid];
+        double *pw = reinterpret_cast<double *>(ctl + 2);
+        ctl[0] += 1;
+        pw[0] *= rt.adam_beta1[tid];
+        pw[1] *= rt.adam_beta2[tid];
+    }
 }
 
 template <int D, int A, int NQ>

@@ -20,6 +20,7 @@
 #include "cstr_env_device.h"
 #include "cstr_mt_device.h"
 #include "cstr_rng_device.h"
+#include "cstr_adam_device.h"
 
 namespace {
 
@@ -523,17 +524,40 @@ __global__ __launch_bounds__(64 * WAVES) void linear_bwd_input_kernel(const floa
 // WAVES waves split the rows m; A = dz^T and B = x are both read as 64-byte row segments (lane r takes column n0 + r /
 // k0 + r of row 16c + 4h + e). The workgroups of the first k strip also add up the dz values they load anyway: db needs no
 // extra pass and, being reduced inside one workgroup in a fixed order, stays deterministic.
-template <int WAVES, bool BUF = false>
+// ADAM: the workgroup that has reduced a tile of dW (and db) also applies the optimiser step to exactly those parameters
+// (cstr_linear_bwd_weight_adam_sets_f32): parameter and moment quads are requested at entry, thread 0 turns the (pre-advanced)
+// control words into the step's scalars beside the reduction, the tile's first wave updates p / m / v after the split-M combine.
+struct AdamTile {
+    float *w, *w_m, *w_v, *b, *b_m, *b_v, *shadow;
+    const int64_t *adam_ctl; const double *lr; double beta1, beta2, eps; float gscale;
+};
+
+template <int WAVES, bool BUF = false, bool ADAM = false>
 __device__ __forceinline__ void linear_bwd_weight_tile(const float *__restrict__ dz, const float *__restrict__ x, const int ldx,
                                                        float *__restrict__ dw, float *__restrict__ db, const int M, const int N,
-                                                       const int K, const int64_t g)
+                                                       const int K, const int64_t g, const AdamTile *ad = nullptr)
 {
     __shared__ f32x4 part[WAVES > 1 ? WAVES - 1 : 1][64];
     __shared__ float colpart[WAVES][64];
+    __shared__ AdamScalars adam_sc;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, h = lane >> 4;
     const int k0 = blockIdx.x * 16, n0 = blockIdx.y * 16;
     const bool n_ok = n0 + r < N, k_ok = k0 + r < K;
     const bool want_db = db != nullptr && blockIdx.x == 0;
+    float pw[4] = {0.0f, 0.0f, 0.0f, 0.0f}, pm[4] = {0.0f, 0.0f, 0.0f, 0.0f}, pv[4] = {0.0f, 0.0f, 0.0f, 0.0f}, bw = 0.0f, bm = 0.0f, bvv = 0.0f;
+    if (ADAM) {
+        if (wave == 0 && k_ok) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (n0 + 4 * h + e < N) {
+                    const int64_t i = (int64_t)(n0 + 4 * h + e) * K + k0 + r;
+                    pw[e] = ad->w[i]; pm[e] = ad->w_m[i]; pv[e] = ad->w_v[i];
+                }
+            }
+        }
+        if (wave == 0 && want_db && lane < 16 && n_ok) { bw = ad->b[n0 + lane]; bm = ad->b_m[n0 + lane]; bvv = ad->b_v[n0 + lane]; }
+        if (threadIdx.x == 64 * (WAVES - 1)) adam_sc = adam_scalars_advanced(ad->adam_ctl, ad->lr, ad->beta1, ad->beta2, ad->eps, ad->gscale);
+    }
     f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
     float colsum = 0.0f;
     constexpr int UNROLL = 4;
@@ -585,6 +609,8 @@ __device__ __forceinline__ void linear_bwd_weight_tile(const float *__restrict__
         if (wave > 0) return;
 #pragma unroll
         for (int v = 0; v < WAVES - 1; ++v) acc += part[v][lane];
+    } else if (ADAM) {
+        __syncthreads();
     }
     // tile of dW: column (k) = lane & 15, row (n) = 4 * (lane >> 4) + register
     if (k_ok) {
@@ -592,12 +618,30 @@ __device__ __forceinline__ void linear_bwd_weight_tile(const float *__restrict__
 #pragma unroll
         for (int e = 0; e < 4; ++e)
             if (n0 + 4 * h + e < N) out[(int64_t)e * K] = acc[e];
+        if (ADAM) {
+            const AdamScalars a = adam_sc;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int row = n0 + 4 * h + e, colk = k0 + r;
+                if (row < N) {
+                    const int64_t i = (int64_t)row * K + colk;
+                    adam1(pw[e], acc[e], pm[e], pv[e], a);
+                    ad->w[i] = pw[e]; ad->w_m[i] = pm[e]; ad->w_v[i] = pv[e];
+                    if (ad->shadow)  // the tile-major copy the rollout kernel reads (cstr_policy_swizzle_f32's layout)
+                        ad->shadow[(((int64_t)(row >> 4) * ((K + 15) >> 4) + (colk >> 4)) * 64 + (row & 15) + 16 * ((colk & 15) >> 2)) * 4 + (colk & 3)] = pw[e];
+                }
+            }
+        }
     }
     if (want_db && lane < 16 && n_ok) {
         float sum = 0.0f;
 #pragma unroll
         for (int v = 0; v < WAVES; ++v) sum += (colpart[v][lane] + colpart[v][lane + 16]) + (colpart[v][lane + 32] + colpart[v][lane + 48]);
         db[g * N + n0 + lane] = sum;
+        if (ADAM) {
+            adam1(bw, sum, bm, bvv, adam_sc);
+            ad->b[n0 + lane] = bw; ad->b_m[n0 + lane] = bm; ad->b_v[n0 + lane] = bvv;
+        }
     }
 }
 
@@ -621,6 +665,36 @@ __global__ __launch_bounds__(64 * WAVES) void linear_bwd_weight_sets_kernel(cons
     const cstr_wgrad_set_t &q = sets.s[blockIdx.z];
     if ((int64_t)blockIdx.x * 16 >= q.k || (int64_t)blockIdx.y * 16 >= q.n) return;  // the grid covers the largest set
     linear_bwd_weight_tile<WAVES, BUF>(q.dz, q.x, (int)q.ldx, q.dw, q.db, (int)q.m, (int)q.n, (int)q.k, 0);
+}
+
+// The same launch with the OPTIMISER STEP inside (single-GPU training: nothing sits between a gradient and its Adam step): slices
+// z < n_sets reduce one Linear's dW / db tile and update exactly those parameters; slices z >= n_sets are flat segments
+// (cstr_adam_seg_t: parameters without a weight-gradient tile -- SAC's entropy coefficient -- and soft target updates). Step counters
+// are pre-advanced by an earlier launch (cstr_chain_root_t.adam_advance): no control word is written here, no ticket.
+struct WgradAdamSets {
+    cstr_wgrad_adam_set_t s[CSTR_MAX_LINEAR_SETS];
+    cstr_adam_opt_t o[CSTR_MAX_ADAM_SEGS];
+    cstr_adam_seg_t f[CSTR_MAX_ADAM_SEGS];
+    int n_sets;
+};
+
+template <int WAVES, bool BUF>
+__global__ __launch_bounds__(64 * WAVES) void linear_bwd_weight_adam_sets_kernel(const WgradAdamSets sets)
+{
+    if ((int)blockIdx.z >= sets.n_sets) {
+        const cstr_adam_seg_t &f = sets.f[blockIdx.z - sets.n_sets];
+        const int64_t bid = blockIdx.y * (int64_t)gridDim.x + blockIdx.x, nblk = (int64_t)gridDim.x * gridDim.y;
+        if (f.polyak_source) { polyak_body(f.polyak_source, f.param, (float)f.tau, (float)(1.0 - f.tau), f.n, bid, nblk); return; }
+        if (bid * (int64_t)blockDim.x * 4 >= ((f.n + 3) & ~(int64_t)3)) return;  // small segments: the workgroups with nothing to do leave at once
+        adam_body(f.param, f.grad, f.exp_avg, f.exp_avg_sq, f.adam_ctl, f.lr, f.beta1, f.beta2, f.eps, f.grad_scale, f.n, AdamShadow{nullptr, 0, 0, 4, 1},
+                  f.own_target, (float)f.tau, (float)(1.0 - f.tau), true, bid, nblk);
+        return;
+    }
+    const cstr_wgrad_adam_set_t &q = sets.s[blockIdx.z];
+    if ((int64_t)blockIdx.x * 16 >= q.g.k || (int64_t)blockIdx.y * 16 >= q.g.n) return;  // the grid covers the largest set
+    const cstr_adam_opt_t &o = sets.o[q.opt];
+    const AdamTile ad = {q.w, q.w_m, q.w_v, q.b, q.b_m, q.b_v, q.shadow, o.adam_ctl, o.lr, o.beta1, o.beta2, o.eps, o.grad_scale};
+    linear_bwd_weight_tile<WAVES, BUF, true>(q.g.dz, q.g.x, (int)q.g.ldx, q.g.dw, q.g.db, (int)q.g.m, (int)q.g.n, (int)q.g.k, 0, &ad);
 }
 
 // ---- last hidden layer + scalar head of a Q network ------------------------------------------------------------
@@ -2623,6 +2697,40 @@ extern "C" int cstr_linear_bwd_weight_sets_f32(const cstr_wgrad_set_t *sets, int
     for (int i = 0; i < n_sets; ++i) buf = buf && sets[i].m * sets[i].n < (1 << 28) && sets[i].m * sets[i].ldx < (1 << 28);
     if (m_min > 32) { if (buf) linear_bwd_weight_sets_kernel<4, true><<<grid, 256, 0, s>>>(t); else linear_bwd_weight_sets_kernel<4, false><<<grid, 256, 0, s>>>(t); }
     else { if (buf) linear_bwd_weight_sets_kernel<1, true><<<grid, 64, 0, s>>>(t); else linear_bwd_weight_sets_kernel<1, false><<<grid, 64, 0, s>>>(t); }
+    return (int)hipGetLastError();
+}
+
+extern "C" int cstr_linear_bwd_weight_adam_sets_f32(const cstr_wgrad_adam_set_t *sets, int n_sets, const cstr_adam_opt_t *opts, int n_opts,
+                                                    const cstr_adam_seg_t *flat, int n_flat, cstr_stream_t stream)
+{
+    if (!sets || n_sets <= 0 || !opts || n_opts <= 0 || n_flat < 0 || (n_flat > 0 && !flat)) return CSTR_E_BADARG;
+    if (n_sets > CSTR_MAX_LINEAR_SETS || n_opts > CSTR_MAX_ADAM_SEGS || n_flat > CSTR_MAX_ADAM_SEGS) return CSTR_E_UNSUPPORTED;
+    WgradAdamSets t;
+    t.n_sets = n_sets;
+    int64_t kt = 1, nt = 1;
+    for (int i = 0; i < n_opts; ++i) {
+        if (!opts[i].adam_ctl || !opts[i].lr) return CSTR_E_BADARG;
+        t.o[i] = opts[i];
+    }
+    for (int i = 0; i < n_sets; ++i) {
+        const cstr_wgrad_adam_set_t &q = sets[i];
+        if (!q.g.dz || !q.g.x || !q.g.dw || q.g.m <= 32 || q.g.n <= 0 || q.g.k <= 0 || q.g.ldx < q.g.k) return CSTR_E_BADARG;
+        if (!q.w || !q.w_m || !q.w_v || q.opt < 0 || q.opt >= n_opts || (q.g.db && (!q.b || !q.b_m || !q.b_v))) return CSTR_E_BADARG;
+        if (q.g.m * q.g.n >= (1 << 28) || q.g.m * q.g.ldx >= (1 << 28) || (q.g.n + 15) / 16 > 65535) return CSTR_E_UNSUPPORTED;
+        kt = kt > (q.g.k + 15) / 16 ? kt : (q.g.k + 15) / 16;
+        nt = nt > (q.g.n + 15) / 16 ? nt : (q.g.n + 15) / 16;
+        t.s[i] = q;
+    }
+    for (int i = 0; i < n_flat; ++i) {
+        const cstr_adam_seg_t &f = flat[i];
+        if (!f.param || f.n <= 0) return CSTR_E_BADARG;
+        if (!f.polyak_source && (!f.grad || !f.exp_avg || !f.exp_avg_sq || !f.adam_ctl || !f.lr)) return CSTR_E_BADARG;
+        if (f.shadow) return CSTR_E_UNSUPPORTED;  // a shadowed matrix is updated by its weight-gradient tiles
+        if (!aligned16(f.param) || (f.polyak_source && !aligned16(f.polyak_source))) return CSTR_E_BADARG;
+        t.f[i] = f;
+    }
+    const dim3 grid((unsigned)kt, (unsigned)nt, (unsigned)(n_sets + n_flat));
+    linear_bwd_weight_adam_sets_kernel<4, true><<<grid, 256, 0, (hipStream_t)stream>>>(t);
     return (int)hipGetLastError();
 }
 
