@@ -573,16 +573,18 @@ typedef struct cstr_sac_actor {
  * the observation columns of x_pi / x_next are already filled) + layer 1 (recomputed per workgroup) + layer 2 (one MFMA column
  * group per workgroup) + PARTIAL head sums head_part [n_colgroups][2B][2A] (n_colgroups = ceil(H2 / (16 * tiles))). With sample_idx
  * the column-group-0 workgroups also materialise the packed batch (cstr_linear_act_fwd_gather_f32's contract: x_data, the
- * observation columns of x_pi / x_next, rewards, dones * (1 - timeouts)) and thread 0 performs the control-word updates.
+ * observation columns of x_pi / x_next, rewards, dones * (1 - timeouts)) and thread 0 advances the ring position.
  * a_h1 [B][H1], a_h2 [B][H2]: the pi(obs) rows' activations, kept for cstr_sac_actor_chain_bwd_f32.
  * eps_all [2B][A] (or NULL): the sampling head's noise, drawn HERE by an otherwise idle wave (Philox4x32-10 / Box-Muller, key =
- * head_rng_ctl[0], counter = head_rng_ctl[1] + row, row in [0, 2B): the stream positions of cstr_gaussian_head_gemm_fwd_f32 on the
- * 2B-row pass) -- it does not depend on the network, and the launch that finalises the head has a long enough prologue without it.
- * head_rng_ctl is only read; the backward chain launch advances the offset (cstr_chain_root_t.rng_ctl). */
+ * head_rng_ctl[0], counter = head_rng_ctl[1] + head_rng_offset + row, row in [0, 2B): the stream positions of
+ * cstr_gaussian_head_gemm_fwd_f32 on the 2B-row pass) -- it does not depend on the network, and the launch that finalises the head has
+ * a long enough prologue without it. head_rng_offset: draws of an earlier launch on the same stream whose offset advance is still
+ * pending (cstr_rollout_step_f32 leaves it to the launches behind it). head_rng_ctl is only READ in this launch; the backward chain
+ * launch advances the offset by everything that is pending (cstr_chain_root_t.rng_ctl). */
 int cstr_sac_actor_chain_fwd_f32(const cstr_sac_actor_t *actor, const cstr_ring_t *ring, int64_t *ring_ctl, int advance_ring,
-                                 uint64_t *rollout_rng_ctl, uint64_t rollout_rng_advance, const int32_t *sample_idx, int64_t batch,
-                                 float *x_data, float *x_pi, float *x_next, float *out_done, float *out_rew, float *a_h1, float *a_h2,
-                                 float *head_part, const uint64_t *head_rng_ctl, float *eps_all, int tiles, cstr_stream_t stream);
+                                 const int32_t *sample_idx, int64_t batch, float *x_data, float *x_pi, float *x_next, float *out_done,
+                                 float *out_rew, float *a_h1, float *a_h2, float *head_part, const uint64_t *head_rng_ctl,
+                                 uint64_t head_rng_offset, float *eps_all, int tiles, cstr_stream_t stream);
 
 /* How a consumer launch turns the actor's head partials into actions (core/common/distributions.py:207-260, the arithmetic of
  * cstr_gaussian_head_gemm_fwd_f32): params = sum of partials + hb; u = mean + exp(clamp(log_std)) * eps; a = tanh(u); log-prob.

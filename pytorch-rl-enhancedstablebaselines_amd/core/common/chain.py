@@ -114,12 +114,24 @@ class SacChain:
         elif fa.rng_ctl is None:
             fa.rng_ctl = hip_ops.new_rng_ctl(th.initial_seed(), model.device)
         # -- pi(obs) and pi(next_obs): gather + layers 1, 2 + head partials
-        noise = {} if eps2 is not None else dict(head_rng_ctl=fa.rng_ctl, eps_all=self.eps_all)  # drawn by the actor launch unless given
+        # Philox offset bookkeeping: the rollout launch in front of this step leaves its advance (n_envs draws) to the launches behind it;
+        # the actor launch only READS the offset (its noise lanes add what is pending), the Q backward launch's loss workgroup advances it
+        pending_ctl, pending = (None, 0)
+        if gather is not None and gather[2] is not None:
+            pending_ctl, pending = gather[2]
+        if pending_ctl is not None and eps2 is None and pending_ctl.data_ptr() != fa.rng_ctl.data_ptr():
+            raise RuntimeError("the rollout launch and the sampling head must share one Philox stream")
+        noise = {} if eps2 is not None else dict(head_rng_ctl=fa.rng_ctl, head_rng_offset=pending, eps_all=self.eps_all)
         eps = self.eps_all if eps2 is None else eps2
+        rng_total = None
+        if eps2 is None:
+            rng_total = (fa.rng_ctl, pending + 2 * B)
+        elif pending_ctl is not None:
+            rng_total = (pending_ctl, pending)
         if gather is not None:
-            ring, idx, rng_advance, _ = gather
+            ring, idx, _, _ = gather
             hip_ops.sac_actor_chain_fwd(self.actor, B, pb.x_data, pb.x_pi, pb.x_next, rd.dones, rd.rewards, self.a_h1, self.a_h2, self.head_part,
-                                        self.t_act, ring=ring, sample_idx=idx, advance_ring=True, rng_advance=rng_advance, **noise)
+                                        self.t_act, ring=ring, sample_idx=idx, advance_ring=True, **noise)
         else:
             hip_ops.sac_actor_chain_fwd(self.actor, B, None, pb.x_pi, pb.x_next, None, None, self.a_h1, self.a_h2, self.head_part, self.t_act, **noise)
         # -- critics on x_data, target critics on x_next (its action columns finalised inside the launch)
@@ -148,7 +160,7 @@ class SacChain:
         root = hip_ops.chain_root("td", B, [self.q_part4[g] for g in range(4)], b3s, self.n_q4, gamma=model.gamma, scale=0.5,
                                   next_logp=self.logp_next, rew=rd.rewards, done=rd.dones, ent_coef=ent_coef, target_out=model._target_q,
                                   q_out=self.q_out, gq_out=self.gq, loss_out=sto("critic", model._loss_now["critic"]), loss_sum=acc("critic"),
-                                  alpha=alpha, rng_advance=None if eps2 is not None else (fa.rng_ctl, 2 * B),
+                                  alpha=alpha, rng_advance=rng_total,
                                   adam_advance=([model.critic.optimizer] + ([ent_opt] if ent_opt is not None else [])) if fuse_opt else ())
         back = [hip_ops.chain_net(self.crit[g], None, self.c_h1[g], self.c_h2[g]) for g in range(2)]
         hip_ops.q_chain_bwd(back, root, W, D, self.cH1, self.cH2, self.t_qb, dz2=self.dz2c, dz1=self.dz1c)

@@ -921,7 +921,7 @@ def sac_actor_desc(obs_dim: int, act_dim: int, w1, b1, w2, b2, hw, hb) -> "nv.Sa
 
 
 def sac_actor_chain_fwd(actor: "nv.SacActorNet", batch: int, x_data, x_pi, x_next, out_done, out_rew, a_h1, a_h2, head_part, tiles: int,
-                        ring: Optional[DeviceRing] = None, sample_idx=None, advance_ring: bool = False, rng_advance=None, head_rng_ctl=None,
+                        ring: Optional[DeviceRing] = None, sample_idx=None, advance_ring: bool = False, head_rng_ctl=None, head_rng_offset: int = 0,
                         eps_all=None):
     """cstr_sac_actor_chain_fwd_f32: gather (or packed observation columns) + layer 1 + layer 2 + head partials of the 2B-row actor pass."""
     w = actor.obs_dim + actor.act_dim
@@ -932,14 +932,14 @@ def sac_actor_chain_fwd(actor: "nv.SacActorNet", batch: int, x_data, x_pi, x_nex
     _chk(a_h1, "a_h1", (batch, actor.h1), th.float32), _chk(a_h2, "a_h2", (batch, actor.h2), th.float32)
     _chk(head_part, "head_part", (ncg, 2 * batch, 2 * actor.act_dim), th.float32)
     _opt(eps_all, "eps_all", (2 * batch, actor.act_dim), th.float32), _opt(head_rng_ctl, "head_rng_ctl", (nv.RNG_CTL_WORDS,), th.int64)
-    rc_ptr, adv = (None, 0) if rng_advance is None else (rng_advance[0].data_ptr(), int(rng_advance[1]))
     if sample_idx is not None:
         _chk(sample_idx, "sample_idx", (2, batch), th.int32)
         _chk(x_data, "x_data", (batch, w), th.float32), _chk(out_done, "out_done", (batch, 1), th.float32), _chk(out_rew, "out_rew", (batch, 1), th.float32)
     check(nv.lib().cstr_sac_actor_chain_fwd_f32(C.byref(actor), None if ring is None else C.byref(ring.c), None if ring is None else ptr(ring.ctl),
-                                                C.c_int(1 if advance_ring else 0), C.c_void_p(rc_ptr), C.c_uint64(adv), ptr(sample_idx),
+                                                C.c_int(1 if advance_ring else 0), ptr(sample_idx),
                                                 C.c_int64(batch), ptr(x_data), ptr(x_pi), ptr(x_next), ptr(out_done), ptr(out_rew), ptr(a_h1),
-                                                ptr(a_h2), ptr(head_part), ptr(head_rng_ctl), ptr(eps_all), C.c_int(tiles), stream_ptr()),
+                                                ptr(a_h2), ptr(head_part), ptr(head_rng_ctl), C.c_uint64(int(head_rng_offset)), ptr(eps_all),
+                                                C.c_int(tiles), stream_ptr()),
           "cstr_sac_actor_chain_fwd_f32")
 
 

@@ -204,10 +204,10 @@ __device__ __forceinline__ void store_panel(const float *panel, const int ld, fl
 // ---- SAC actor, forward chain -------------------------------------------------------------------------------------------------
 struct ActorFwdArgs {
     cstr_sac_actor_t net;
-    cstr_ring_t ring; int64_t *ring_ctl; int advance_ring; uint64_t *rng_ctl; uint64_t rng_advance;
+    cstr_ring_t ring; int64_t *ring_ctl; int advance_ring;
     const int32_t *idx; int batch, tiles;
     float *x_data, *x_pi, *x_next, *out_done, *out_rew, *a_h1, *a_h2, *head_part;
-    const uint64_t *head_rng_ctl; float *eps_all;
+    const uint64_t *head_rng_ctl; uint64_t head_rng_offset; float *eps_all;
 };
 
 template <int D, int A, int NQ>
@@ -269,7 +269,7 @@ __global__ __launch_bounds__(CH_THREADS) void sac_actor_chain_fwd_kernel(const A
     const bool noise = a.eps_all != nullptr && blockIdx.x == 0 && wave == 3 && lane < 16 * PAIRS;
     if (noise) {
         const int row = lane / PAIRS, pr = lane % PAIRS;
-        const uint64_t seed = a.head_rng_ctl[0], ctr = a.head_rng_ctl[1] + (uint64_t)(m0 + row);
+        const uint64_t seed = a.head_rng_ctl[0], ctr = a.head_rng_ctl[1] + a.head_rng_offset + (uint64_t)(m0 + row);
         uint32_t rr[4];
         philox4x32_10((uint32_t)ctr, (uint32_t)(ctr >> 32), (uint32_t)pr, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), rr);
         box_muller(rr[0], rr[1], e0, e1);
@@ -336,7 +336,6 @@ __global__ __launch_bounds__(CH_THREADS) void sac_actor_chain_fwd_kernel(const A
             a.ring_ctl[0] = pos;
             a.ring_ctl[3] += 1;
         }
-        if (a.rng_ctl) a.rng_ctl[1] += a.rng_advance;
     }
 }
 
@@ -807,9 +806,9 @@ static int check_actor(const cstr_sac_actor_t *n)
 }
 
 extern "C" int cstr_sac_actor_chain_fwd_f32(const cstr_sac_actor_t *actor, const cstr_ring_t *ring, int64_t *ring_ctl, int advance_ring,
-                                            uint64_t *rollout_rng_ctl, uint64_t rollout_rng_advance, const int32_t *sample_idx, int64_t batch,
-                                            float *x_data, float *x_pi, float *x_next, float *out_done, float *out_rew, float *a_h1,
-                                            float *a_h2, float *head_part, const uint64_t *head_rng_ctl, float *eps_all, int tiles,
+                                            const int32_t *sample_idx, int64_t batch, float *x_data, float *x_pi, float *x_next,
+                                            float *out_done, float *out_rew, float *a_h1, float *a_h2, float *head_part,
+                                            const uint64_t *head_rng_ctl, uint64_t head_rng_offset, float *eps_all, int tiles,
                                             cstr_stream_t stream)
 {
     const int rc = check_actor(actor);
@@ -828,10 +827,10 @@ extern "C" int cstr_sac_actor_chain_fwd_f32(const cstr_sac_actor_t *actor, const
         if (ring->rows >= 0xFFFFFFFFLL || ring->n_envs >= 0xFFFFFFFFLL) return CSTR_E_UNSUPPORTED;
         a.ring = *ring;
     }
-    a.ring_ctl = ring_ctl; a.advance_ring = advance_ring; a.rng_ctl = rollout_rng_ctl; a.rng_advance = rollout_rng_advance;
+    a.ring_ctl = ring_ctl; a.advance_ring = advance_ring;
     a.idx = sample_idx; a.batch = (int)batch; a.tiles = tiles;
     a.x_data = x_data; a.x_pi = x_pi; a.x_next = x_next; a.out_done = out_done; a.out_rew = out_rew;
-    a.a_h1 = a_h1; a.a_h2 = a_h2; a.head_part = head_part; a.head_rng_ctl = head_rng_ctl; a.eps_all = eps_all;
+    a.a_h1 = a_h1; a.a_h2 = a_h2; a.head_part = head_part; a.head_rng_ctl = head_rng_ctl; a.head_rng_offset = head_rng_offset; a.eps_all = eps_all;
     const dim3 grid((unsigned)((actor->h2 + 16 * tiles - 1) / (16 * tiles)), (unsigned)(2 * batch / 16));
     const size_t lds = chain_lds_bytes(actor->h1, true);
     const int nq = nq_for(actor->h1, tiles), lay = chain_layout(actor->obs_dim, actor->act_dim);
