@@ -144,6 +144,27 @@ __device__ __forceinline__ f32x4 combine_split_k(f32x4 acc, float *smem, const i
     return acc;
 }
 
+// Sum of `n` partial values part[p * stride + at], p ascending: ALL loads are requested before the first add (a loop of load / wait /
+// add would serialise n round trips to a freshly written buffer, the longest stretch of these kernels' prologues). n <= 16 takes the
+// branch-free form (lanes beyond n read zeros through the descriptor's range check: x + 0 is exact).
+constexpr int MAX_PARTS = 16;
+__device__ __forceinline__ float sum_parts(const float *part, const int n, const int64_t stride, const int64_t at, const int64_t total_floats)
+{
+    if (n <= MAX_PARTS) {
+        const __amdgpu_buffer_rsrc_t rs = rsrc_of(part, total_floats);
+        float v[MAX_PARTS];
+#pragma unroll
+        for (int p = 0; p < MAX_PARTS; ++p) v[p] = ld32(rs, p < n ? (int)(4 * (p * stride + at)) : BUF_OOB);
+        float s = v[0];
+#pragma unroll
+        for (int p = 1; p < MAX_PARTS; ++p) s += v[p];
+        return s;
+    }
+    float s = part[at];
+    for (int p = 1; p < n; ++p) s += part[p * stride + at];
+    return s;
+}
+
 // The SAC head's sampling arithmetic for ONE (row, action) (gaussian_head_gemm_fwd_kernel's expressions): mean, raw log_std, eps ->
 // action and this action's log-prob term (Normal log-pdf minus the tanh correction)
 __device__ __forceinline__ void sample_action(const float mu, const float raw, const float e, float &a, float &lp_term)
@@ -384,17 +405,12 @@ __global__ __launch_bounds__(CH_THREADS) void q_chain_fwd_kernel(const QFwdArgs 
     const int f_row = t / A, f_j = t % A;
     if (fin_lane) {
         const int64_t i = (nxt ? B : 0) + m0 + f_row;  // row of the 2B-row actor pass
-        const float *hp = a.fin.head_part + i * (2 * A);
-        const int64_t pstride = (int64_t)2 * B * 2 * A;
-        float s_mu = hp[f_j], s_raw = hp[A + f_j];
-        for (int part = 1; part < a.fin.n_parts; ++part) {
-            s_mu += hp[part * pstride + f_j];
-            s_raw += hp[part * pstride + A + f_j];
-        }
-        f_mu = s_mu + a.fin.hb[f_j];
-        f_raw = s_raw + a.fin.hb[A + f_j];
+        const int64_t pstride = (int64_t)2 * B * 2 * A, ptotal = pstride * a.fin.n_parts;
+        const float ev = a.fin.eps[i * A + f_j], hb_mu = a.fin.hb[f_j], hb_raw = a.fin.hb[A + f_j];
+        f_mu = sum_parts(a.fin.head_part, a.fin.n_parts, pstride, i * (2 * A) + f_j, ptotal) + hb_mu;
+        f_raw = sum_parts(a.fin.head_part, a.fin.n_parts, pstride, i * (2 * A) + A + f_j, ptotal) + hb_raw;
         float term;
-        sample_action(f_mu, f_raw, a.fin.eps[i * A + f_j], f_a, term);
+        sample_action(f_mu, f_raw, ev, f_a, term);
         // log-prob of the row = sum of its actions' terms: the A lanes of a row are adjacent
         f_lp = term;
         if (A >= 2) f_lp += __shfl_xor(f_lp, 1, 64);
@@ -449,9 +465,8 @@ struct QBwdArgs {
 
 __device__ __forceinline__ float q_from_parts(const float *part, const float *b3, const int n_parts, const int batch, const int row)
 {
-    float s = part[row];
-    for (int p = 1; p < n_parts; ++p) s += part[(int64_t)p * batch + row];
-    return s + b3[0];
+    const float b = b3[0];
+    return sum_parts(part, n_parts, batch, row, (int64_t)n_parts * batch) + b;
 }
 
 __device__ __forceinline__ float wave_sum64(float v)
@@ -588,10 +603,12 @@ __global__ __launch_bounds__(CH_THREADS) void q_chain_bwd_kernel(const QBwdArgs 
         const float ec = with_alpha ? expf(rt.alpha.log_alpha[0]) : (rt.ent_coef ? rt.ent_coef[0] : 0.0f);
         const float kq = rt.scale * 2.0f / (float)B, inv = 1.0f / (float)B;
         if (rt.mode == 1) {
-            float q = fminf(q_from_parts(rt.q_part[2], rt.b3[2], P, B, row), q_from_parts(rt.q_part[3], rt.b3[3], P, B, row));
-            if (rt.next_logp) q = q - ec * rt.next_logp[row];
-            o_tq = rt.rew[row] + (1.0f - rt.done[row]) * rt.gamma * q;
+            const float nl = rt.next_logp ? rt.next_logp[row] : 0.0f, rw = rt.rew[row], dn = rt.done[row];
+            const float qa = q_from_parts(rt.q_part[2], rt.b3[2], P, B, row), qb = q_from_parts(rt.q_part[3], rt.b3[3], P, B, row);
             o_q = q_from_parts(rt.q_part[g], rt.b3[g], P, B, row);
+            float q = fminf(qa, qb);
+            if (rt.next_logp) q = q - ec * nl;
+            o_tq = rw + (1.0f - dn) * rt.gamma * q;
             o_gq = kq * (o_q - o_tq);
         } else if (rt.mode == 3) {
             o_q = q_from_parts(rt.q_part[0], rt.b3[0], P, B, row);
@@ -709,15 +726,16 @@ __global__ __launch_bounds__(CH_THREADS) void sac_actor_chain_bwd_kernel(const A
     float o_gu = 0.0f, o_gls = 0.0f;
     if (t < 16 * A) {
         const int row = t / A, j = t % A, b = m0 + row;
-        float ga = 0.0f;
-        for (int g = 0; g < a.n_nets; ++g)
-            for (int p = 0; p < a.n_parts; ++p) ga += a.gact_part[(((int64_t)g * a.n_parts + p) * B + b) * A + j];
-        const float gl = a.ent_coef[0] * (1.0f / (float)B);  // d(loss)/d(logp) (sac_actor_loss_kernel)
-        const float av = a.x_pi[(int64_t)b * W + D + j], raw = a.params[(int64_t)b * 2 * A + A + j];
+        const float ecv = a.ent_coef[0], av = a.x_pi[(int64_t)b * W + D + j], raw = a.params[(int64_t)b * 2 * A + A + j];
+        const float epv = a.eps[(int64_t)b * A + j];
+        // networks x column groups are ONE run of partials (stride B * A): summed in (network, group) order
+        const int np = a.n_nets * a.n_parts;
+        const float ga = sum_parts(a.gact_part, np, (int64_t)B * A, (int64_t)b * A + j, (int64_t)np * B * A);
+        const float gl = ecv * (1.0f / (float)B);  // d(loss)/d(logp) (sac_actor_loss_kernel)
         const float s = expf(fminf(fmaxf(raw, LOG_STD_MIN), LOG_STD_MAX));
         const float one_m = 1.0f - av * av;
         o_gu = ga * one_m + gl * (2.0f * av * one_m / (one_m + 1e-6f));
-        o_gls = (raw >= LOG_STD_MIN && raw <= LOG_STD_MAX) ? o_gu * a.eps[(int64_t)b * A + j] * s - gl : 0.0f;
+        o_gls = (raw >= LOG_STD_MIN && raw <= LOG_STD_MAX) ? o_gu * epv * s - gl : 0.0f;
         gs[row * 8 + j] = o_gu;
         gs[row * 8 + A + j] = o_gls;
     }
