@@ -31,6 +31,11 @@ class TwoSeriesCSTREnv:
         self.state = None
         self._vec = None
         self._seed: Optional[int] = None
+        # memory of the zero-weight reward diagnostics (twoseriescstr.py:108-112): they never reach the reward, only `info`
+        self.last_concentration = None
+        self.last_action = None
+        self.stable_counter = 0
+        self.last_error = None
 
     # ctor arguments a batched env must share
     def vec_kwargs(self) -> dict:
@@ -71,6 +76,7 @@ class TwoSeriesCSTREnv:
         if self._seed is not None:
             v.seed(self._seed)
             self._seed = None
+        self.last_concentration, self.last_action, self.stable_counter, self.last_error = None, None, 0, None  # :233-236
         obs = v.reset()[0]
         raw = self.raw_state_low + (obs + 1.0) * (self.raw_state_high - self.raw_state_low) / 2.0
         self.state = obs
@@ -95,11 +101,57 @@ class TwoSeriesCSTREnv:
             v.step_count.fill_(self.max_steps)
         self.state = obs
         reward = float(rew.cpu().numpy()[0])
-        norm_a = np.clip(a[0], -1.0, 1.0)
-        raw_action = self.raw_action_low + (norm_a + 1.0) * (self.raw_action_high - self.raw_action_low) / 2.0
-        info = {"reward": reward, "raw_action": raw_action, "truncated": truncated, "state": obs, "target_C2": self.target_C2,
-                "step": self.current_step}
+        norm_a = np.clip(a[0], -1.0, 1.0).astype(np.float32)
+        raw_action = (self.raw_action_low + (norm_a + 1.0) * (self.raw_action_high - self.raw_action_low) / 2.0).astype(np.float32)
+        if np.isnan(a).any():  # the reference's exception path returns an EMPTY info dict (twoseriescstr.py:413-421)
+            return obs, reward, False, truncated, {}
+        original_state = (self.raw_state_low + (obs + 1.0) * (self.raw_state_high - self.raw_state_low) / 2.0).astype(np.float32)
+        info = {"reward": reward, "raw_action": raw_action, "truncated": truncated, "state": obs, "original_state": original_state,
+                "target_C2": self.target_C2, "step": self.current_step}
+        info.update(self._reward_info(original_state, norm_a))
         return obs, reward, False, truncated, info
+
+    def _reward_info(self, raw_state: np.ndarray, action: np.ndarray) -> dict:
+        """The nine `info` entries of compute_reward (twoseriescstr.py:271-392) for the NEW state. The reward itself comes from the
+        device step (concentration term + 0.5 x temperature penalty); the other five terms carry weight 0.0 in the reference and exist
+        only here, with their per-env memory (last concentration / error / action, stable counter), on the NumPy compatibility face."""
+        f = np.float32
+        C1, T1, C2, T2 = (f(x) for x in raw_state)
+        err = np.abs(C2 - self.target_C2)
+        ne = err / (self.max_concentration - self.min_concentration)
+        conc = -5.0 * (ne ** 2) - 2.0 * ne
+        prox = (1.0 - err / 0.05) if err < 0.05 else 0.0
+        if self.last_concentration is not None and self.last_error is not None:
+            cur, prev = C2 - self.target_C2, self.last_concentration - self.target_C2
+            trend = 0.5 if np.abs(cur) < np.abs(prev) else (-0.2 if np.abs(cur) > np.abs(prev) else 0.0)
+        else:
+            trend = 0.0
+        self.last_concentration, self.last_error = C2, C2 - self.target_C2
+        if err < 0.02:
+            self.stable_counter += 1
+            stab = min(2.0, 0.05 * self.stable_counter)
+        else:
+            self.stable_counter = max(0, self.stable_counter - 1)
+            stab = 0.0
+        temp = 0.0
+        for T in (T1, T2):
+            if T < 280:
+                temp -= 0.2 * ((280 - T) / 280)
+            elif T > 350:
+                temp -= 0.5 * ((T - 350) / 350)
+        if self.last_action is not None:
+            smooth = max(-1.0, -0.05 * np.sum((action - self.last_action) ** 2))
+        else:
+            smooth = 0.0
+        self.last_action = action.copy()
+        extreme = 0.0
+        if C2 < 0.005:
+            extreme -= 1.0 * (1.0 - C2 / 0.005)
+        elif C2 > 0.95 * self.max_concentration:
+            extreme -= 1.0 * ((C2 - 0.95 * self.max_concentration) / (0.05 * self.max_concentration))
+        return {"concentration_reward": conc, "concentration_proximity_reward": prox, "concentration_trend_reward": trend,
+                "stability_reward": stab, "temp_penalty": temp, "action_smoothness_penalty": smooth, "extreme_penalty": extreme,
+                "concentration_error": err, "stable_steps": self.stable_counter}
 
     def render(self):
         if self.render_mode == "human" and self.state is not None:

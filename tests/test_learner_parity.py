@@ -20,19 +20,30 @@ from conftest import rel_err
 pytestmark = pytest.mark.gpu
 
 
-STRICT_Q = {}  # label -> worst per-element relative Q error seen (written to gpurun_out/ at session end, quoted in DESIGN.md)
+STRICT_Q = {}  # label -> [worst per-element relative Q error, elements compared, elements within 1e-5] (gpurun_out/ at session end)
+
+
+def strict_bound(label) -> float:
+    """Per-element |dq_i| / |q_i| each code path is held to (what it meets with margin; profiles/r03_q_strict_rel_err.json): the
+    hand-written paths 5e-5, the rocBLAS GEMM path 6e-5, stock ATen on the GPU against the reference's CPU run 1e-4."""
+    lab = str(label)
+    return 1e-4 if lab.endswith("_False") or lab.endswith("_vs_aten") else 6e-5 if lab.endswith("_rocblas") else 5e-5
 
 
 def q_err(got, want, label=None):
-    """The asserted bound: |dq_i| <= 1e-5 * max(|q_i|, mean|q|). Beside it the STRICT per-element figure |dq_i| / |q_i| (no
-    batch-scale floor; only an absolute 1e-3 floor against division by ~0) is recorded per test and asserted < 1e-4: one f32
-    ulp of a Q-value of magnitude 4 is 4.8e-7, so an element whose |q| is 100x below the batch scale cannot meet 1e-5 of
-    ITSELF under any summation order -- that is what the floor is for."""
+    """The asserted bound (north_star's "1e-5 rel"): |dq_i| <= 1e-5 * max(|q_i|, mean|q|), i.e. 1e-5 of the BATCH'S Q scale. Beside it
+    the STRICT per-element figure |dq_i| / |q_i| (no batch-scale floor; only an absolute 1e-3 floor against division by ~0) is recorded
+    per test with the fraction of elements inside 1e-5 of themselves, and asserted at `strict_bound(label)`: one f32 ulp of a Q-value of
+    magnitude 4 is 4.8e-7, so an element whose |q| is 100x below the batch scale cannot meet 1e-5 of ITSELF under any summation order --
+    that is what the floor is for."""
     want = np.asarray(want, np.float64)
-    strict = rel_err(got, want, 1e-3)
+    got64 = np.asarray(got, np.float64)
+    per = np.abs(got64 - want) / np.maximum(np.abs(want), 1e-3)
+    strict = float(per.max()) if per.size else 0.0
     if label is not None:
-        STRICT_Q[label] = max(STRICT_Q.get(label, 0.0), strict)
-    assert strict < 1e-4, (label, strict)
+        rec = STRICT_Q.setdefault(label, [0.0, 0, 0])
+        rec[0], rec[1], rec[2] = max(rec[0], strict), rec[1] + per.size, rec[2] + int((per <= 1e-5).sum())
+    assert strict < strict_bound(label), (label, strict)
     return rel_err(got, want, float(np.abs(want).mean()))
 
 
@@ -45,7 +56,8 @@ def _dump_strict_q():
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     if STRICT_Q and os.path.isdir(out):
         with open(os.path.join(out, "q_strict_rel_err.json"), "w") as fh:
-            json.dump({k: float(f"{v:.3e}") for k, v in sorted(STRICT_Q.items())}, fh, indent=1)
+            json.dump({k: dict(worst=float(f"{v[0]:.3e}"), elements=v[1], within_1e5=v[2], frac_within_1e5=round(v[2] / max(v[1], 1), 4),
+                               asserted_below=strict_bound(k)) for k, v in sorted(STRICT_Q.items())}, fh, indent=1)
 
 
 def _check_init(model, g, mods):
@@ -1136,3 +1148,40 @@ def test_td3_actor_loss_survives_a_log_read_after_a_critic_only_step(graph):
     assert a != 0.0 and np.isfinite(a) and c > 0.0
     model.learn(N * 1, reset_num_timesteps=False)  # one more update: an actor step -> a fresh value
     assert model._n_updates == 14 and float(model.logger.name_to_value["train/actor_loss"]) != a
+
+
+def test_single_env_info_dict_matches_reference(golden):
+    """The 16-key `info` dict of TwoSeriesCSTREnv.step (reference twoseriescstr.py:441-452) incl. the nine compute_reward entries
+    (:379-389), five of which carry weight 0.0 and per-env memory: an 80-step trajectory written by the reference (a calm stretch
+    near the target -- the stability counter runs up and down --, a reset that clears the memory, an out-of-range action)."""
+    import sys
+
+    from conftest import PKG
+
+    if PKG not in sys.path:
+        sys.path.insert(0, PKG)
+    from twoseriescstr import TwoSeriesCSTREnv
+
+    g = golden("env_info_kat.npz")
+    env = TwoSeriesCSTREnv()
+    keys = ["concentration_reward", "concentration_proximity_reward", "concentration_trend_reward", "stability_reward", "temp_penalty",
+            "action_smoothness_penalty", "extreme_penalty", "concentration_error", "stable_steps"]
+    resets = {int(t): s for t, s in zip(g["reset_at"], g["reset_state"])}
+    for t in range(len(g["actions"])):
+        if t in resets:
+            env.reset(seed=1)
+            env._backend().set_state(resets[t][None], step_count=[0])
+            env.state = resets[t].copy()
+        s, r, te, tr, info = env.step(g["actions"][t])
+        assert set(info) == set(keys) | {"reward", "raw_action", "truncated", "state", "original_state", "target_C2", "step"}
+        assert rel_err(s, g["obs_next"][t], 1.0) < 1e-6 and rel_err(r, g["reward"][t], 1.0) < 4e-6 and not te and not tr
+        assert rel_err(info["original_state"], g["original_state"][t], 1.0) < 1e-4 and info["step"] == int(g["step"][t])
+        np.testing.assert_array_equal(info["raw_action"], g["raw_action"][t])
+        assert info["stable_steps"] == int(g["stable_steps"][t]), t
+        assert info["concentration_trend_reward"] == g["concentration_trend_reward"][t] and info["stability_reward"] == g["stability_reward"][t], t
+        for k in ("concentration_reward", "concentration_proximity_reward", "temp_penalty", "action_smoothness_penalty", "extreme_penalty",
+                  "concentration_error"):
+            assert abs(float(info[k]) - float(g[k][t])) <= 2e-5 * max(1.0, abs(float(g[k][t]))), (k, t, info[k], g[k][t])
+    assert g["stable_steps"].max() >= 10 and (g["concentration_trend_reward"] == -0.2).any() and g["extreme_penalty"].min() < 0
+    obs, r, te, tr, info = env.step(np.array([np.nan, 0.0], np.float32))  # the exception path: empty info (twoseriescstr.py:413-421)
+    assert info == {} and tr and r == -10.0

@@ -121,6 +121,73 @@ def test_rollout_step_equals_the_three_launches(ops, n, d, rows, batch, h1, h2, 
     assert ends > n  # every env finished at least one episode: the reset draws ran inside the fused launch
 
 
+@pytest.mark.parametrize("n,d,integ,h,rows,batch", [(4096, 4, "euler", 256, 5, 256), (2048, 8, "rk4", 256, 4, 256)])
+def test_rollout_step_against_the_oracle_at_the_bench_shape(ops, n, d, integ, h, rows, batch):
+    """the one-launch rollout's env step runs a different instruction stream (`collect_env_quad`: a quad of lanes per
+    env, DPP permutes) than the kernels the other tests pin to the oracle, so it is compared with the ORACLE directly, at the bench shape
+    (4096 envs, obs 4, 256 x 256 SAC head) and at the north_star-literal one (obs 8, RK4): 13 vec-steps, every step on the launch's own
+    actions -- oracle action chain -> oracle vec_step (reference twoseriescstr.py:394-503 restated in C) with reset observations from the
+    oracle's PCG64 reset draw (twoseriescstr.py:187-224) -> oracle ring add (off_policy_algorithm.py:445-508, buffers.py:247-283).
+    Flags, step counters, stored actions and observations, PCG64 states and the ring position: bit-exact; new observations / rewards:
+    1e-6 of the box scale per step (Euler; 2e-6 RK4): single-ulp expf differences."""
+    from core import _native as nv
+    from conftest import rel_err
+    from oracle import cstr_oracle as orc
+
+    max_steps = 9
+    w = _World(ops, n, d, rows, batch, h, h, 0, seed=n + d, max_steps=max_steps)
+    oring = orc.ReplayRing(rows, n, 4, 2)
+    ocoef = orc.default_coef(max_steps=max_steps)
+    states = np.zeros(n, orc.PCG_DTYPE)
+    pcg_h = w.pcg.cpu().numpy().view(np.uint64)
+    for i, f in enumerate(("state_hi", "state_lo", "inc_hi", "inc_lo")):
+        states[f] = pcg_h[:, i]
+    act = th.empty(n, 2, device="cuda")
+    obs_floor = 1.0  # error relative to max(|x|, 1), as in tests/test_hip_kernels.py
+    tol = 1e-6 if integ == "euler" else 2e-6  # DESIGN 3: <= 1e-6 of the box scale per step (numpy / libm / ocml expf differ by <= 2 ulp)
+    episodes = 0
+    for k in range(13):
+        obs_h, steps_h = w.env_obs.cpu().numpy()[:, :4].copy(), w.step_count.cpu().numpy().copy()
+        ops.rollout_step(w.env_obs, *w.w, 1, 0, 0, w.swz, w.rng_ctl, w.coef, integ, w.ring, w.env_obs, w.step_count, 1, w.low, w.high,
+                         pcg_state=w.pcg, reward_out=w.rew, done_out=w.done, ep_return=w.ep_return, ep_stats=w.ep_stats, mt_state=w.mt,
+                         sample_idx=w.idx, action_out=act)
+        ops.replay_gather_packed(w.ring, w.idx, batch, w.x_data, w.x_next, w.x_pi, w.s_done, w.s_rew, w.bi, w.ei, advance_ring=True,
+                                 rng_advance=(w.rng_ctl, n))
+        th.cuda.synchronize()
+        a_h = act.cpu().numpy()
+        assert np.isfinite(a_h).all() and np.abs(a_h).max() <= 1.0
+        buf_a, env_a = orc.action_scale_chain(a_h, True, w.low, w.high)
+        _, _, _, done0, _, _ = orc.vec_step(obs_h, env_a, steps_h, None, integrator=integ, coef=ocoef)
+        reset = orc.reset_draw(states, mask=done0 > 0)  # advances exactly the finished envs' streams, like the launch
+        nxt, after, rew, done, tout, steps2 = orc.vec_step(obs_h, env_a, steps_h, reset, integrator=integ, coef=ocoef)
+        oring.add(obs_h, nxt, buf_a, rew, done, tout)
+        np.testing.assert_array_equal(done, done0)
+        np.testing.assert_array_equal(w.done.cpu().numpy(), done, err_msg=f"step {k}")
+        np.testing.assert_array_equal(w.step_count.cpu().numpy(), steps2, err_msg=f"step {k}")
+        got = w.env_obs.cpu().numpy()
+        fin = done > 0
+        np.testing.assert_array_equal(got[fin, :4], after[fin], err_msg=f"step {k}: reset observations")  # PCG64 draws: bit-exact
+        assert rel_err(got[~fin, :4], after[~fin], obs_floor) < tol, k
+        assert rel_err(w.rew.cpu().numpy(), rew, 1.0) < 4 * tol, k
+        pcg_now = w.pcg.cpu().numpy().view(np.uint64)
+        for i, f in enumerate(("state_hi", "state_lo", "inc_hi", "inc_lo")):
+            np.testing.assert_array_equal(pcg_now[:, i], states[f], err_msg=f"step {k}: PCG64 {f}")
+        episodes += int(fin.sum())
+    r = w.ring
+    np.testing.assert_array_equal(r.actions.cpu().numpy(), oring.actions)
+    np.testing.assert_array_equal(r.dones.cpu().numpy(), oring.dones)
+    np.testing.assert_array_equal(r.timeouts.cpu().numpy(), oring.timeouts)
+    np.testing.assert_array_equal(r.observations.cpu().numpy()[..., :4], oring.observations)
+    assert rel_err(r.next_observations.cpu().numpy()[..., :4], oring.next_observations, obs_floor) < tol
+    assert rel_err(r.rewards.cpu().numpy(), oring.rewards, 1.0) < 4 * tol
+    assert r.ctl.cpu().numpy().tolist() == [13 % rows, 1, 0, 13] and episodes > n  # every env finished at least once
+    if d == 8:  # the raw half of the observation: denormalised new state (twoseriescstr.py:129-150)
+        lo, hi = np.array([0.0, 273.15, 0.0, 273.15], np.float32), np.array([0.7, 400.0, 0.7, 400.0], np.float32)
+        got = w.env_obs.cpu().numpy()
+        raw = np.clip(lo + (got[:, :4] + np.float32(1.0)) * (hi - lo) / np.float32(2.0), lo, hi)
+        assert rel_err(got[:, 4:], raw, 1.0) < 1e-6
+
+
 @pytest.mark.parametrize("rows,n_envs,batch", [(244, 4096, 256), (7, 17, 1024), (3, 1, 100), (100000, 3, 256), (5, 1025, 4000)])
 def test_one_wave_index_draw_is_numpys(ops, rows, n_envs, batch):
     """The rollout launch's index draw against numpy's legacy stream itself: RandomState(seed).randint(0, upper, B) followed by

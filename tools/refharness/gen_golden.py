@@ -717,6 +717,36 @@ def gen_eval():
     save("evaluate_policy_kat.npz", **out)
 
 
+def gen_info():
+    """The 16-key `info` dict of TwoSeriesCSTREnv.step (twoseriescstr.py:441-452) with the nine compute_reward diagnostics (:379-389),
+    five of which carry weight 0.0 and per-env memory: a seeded 80-step trajectory that approaches the target (stability counter runs),
+    leaves it, and is reset in between (memory cleared)."""
+    from twoseriescstr import TwoSeriesCSTREnv
+
+    env = TwoSeriesCSTREnv()
+    rng = np.random.default_rng(77)
+    keys = ["concentration_reward", "concentration_proximity_reward", "concentration_trend_reward", "stability_reward", "temp_penalty",
+            "action_smoothness_penalty", "extreme_penalty", "concentration_error", "stable_steps"]
+    T = 80
+    acts = rng.uniform(-1, 1, (T, 2)).astype(np.float32)
+    acts[0:36] = np.array([0.34522182, 0.3167114], np.float32) + rng.normal(0, 0.01, (36, 2)).astype(np.float32)  # a calm stretch near the target
+    acts[60] = np.array([1.7, -2.0], np.float32)
+    starts = {0: np.array([-0.59437853, 0.23396769, -0.42535093, 0.3727205], np.float32), 45: np.array([0.9, 0.9, 0.95, 0.8], np.float32)}
+    out = {k: np.zeros(T, np.float64) for k in keys}
+    obs_next, rew, raw_next, raw_act, step_no = np.zeros((T, 4), np.float32), np.zeros(T, np.float32), np.zeros((T, 4), np.float32), np.zeros((T, 2), np.float32), np.zeros(T, np.int64)
+    for t in range(T):
+        if t in starts:
+            env.reset(seed=1)
+            env.state = starts[t].copy()
+        s, r, te, tr, info = env.step(acts[t].copy())
+        assert set(info) == set(keys) | {"reward", "raw_action", "truncated", "state", "original_state", "target_C2", "step"}
+        for k in keys:
+            out[k][t] = info[k]
+        obs_next[t], rew[t], raw_next[t], raw_act[t], step_no[t] = s, r, info["original_state"], info["raw_action"], info["step"]
+    save("env_info_kat.npz", actions=acts, reset_at=np.array(sorted(starts), np.int64), reset_state=np.stack([starts[k] for k in sorted(starts)]),
+         obs_next=obs_next, reward=rew, original_state=raw_next, raw_action=raw_act, step=step_no, **out)
+
+
 def gen_init():
     """Initial weights of the reference policies for seed 0 (construction order = RNG order)."""
     from core.sac.sac import SAC
@@ -868,7 +898,7 @@ def gen_vecnorm():
     save("vecnormalize_kat.npz", **out)
 
 
-GENS = {"maddpg_default": gen_maddpg_default, "maddpg4_default": gen_maddpg4_default, "maddpg4": gen_maddpg4, "ddpg": gen_ddpg, "eval": gen_eval, "config1": gen_config1, "env": gen_env, "resets": gen_resets, "vecnorm": gen_vecnorm, "vecenv": gen_vecenv, "sampler": gen_sampler, "replay": gen_replay, "sac": gen_sac,
+GENS = {"maddpg_default": gen_maddpg_default, "maddpg4_default": gen_maddpg4_default, "maddpg4": gen_maddpg4, "ddpg": gen_ddpg, "eval": gen_eval, "info": gen_info, "config1": gen_config1, "env": gen_env, "resets": gen_resets, "vecnorm": gen_vecnorm, "vecenv": gen_vecenv, "sampler": gen_sampler, "replay": gen_replay, "sac": gen_sac,
         "td3": gen_td3, "init": gen_init, "maddpg": gen_maddpg, "iddpg": gen_iddpg, "checkpoint": gen_checkpoint}
 
 if __name__ == "__main__":
