@@ -428,7 +428,13 @@ __global__ __launch_bounds__(CH_THREADS) void q_chain_fwd_kernel(const QFwdArgs 
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             hv[e] = tile_ok ? fmaxf(acc[e] + bv, 0.0f) : 0.0f;
+#ifdef CSTR_HEAD_F64  // experiment: the head's dot product over the workgroup's columns accumulated in f64
+            double sd = (double)hv[e] * (double)w3v;
+            sd += __shfl_xor(sd, 8, 64); sd += __shfl_xor(sd, 4, 64); sd += __shfl_xor(sd, 2, 64); sd += __shfl_xor(sd, 1, 64);
+            const float s = (float)sd;
+#else
             const float s = rowsum16(hv[e] * w3v);
+#endif
             if (r == 0) red[(tile * 16 + 4 * h + e) * 8] = s;
         }
     }
