@@ -293,6 +293,19 @@ def other_kernels(model, batch):
                                           shape=[n_rows, k0, h, h, 2 * a], bound="mfma", tflops=round(flops / us_r / 1e6, 2),
                                           frac=round(flops / us_r / 1e6 / F32_MFMA_PEAK_TFLOPS, 4),
                                           note="policy network (the MFMA work priced here) + fused collect step of all envs + replay index draw")
+    # the SAC gradient step's row-chain launches (csrc/cstr_chain.hip) as the replayed graph issues them, back to back in a graph
+    try:
+        from tools.chain_probe import chain_launches
+
+        if type(model).__name__ == "SAC" and model._chain_for(batch) is not None:
+            for name, (fn, fl) in chain_launches(model, batch).items():
+                fn()
+                us = event_time_us(fn, 200, stream, in_graph=True)
+                out[name] = dict(launch_us=round(us, 3), bound="mfma", tflops=round(fl / us / 1e6, 2), frac=round(fl / us / 1e6 / F32_MFMA_PEAK_TFLOPS, 4),
+                                 note="back-to-back graph replays of ONE launch; in the iteration's graph it follows a different kernel (fresh operands): "
+                                      "profiles/r03_sac_graph_timeline.json")
+    except Exception as exc:  # noqa: BLE001 -- a microbenchmark must never fail the headline line
+        out["chain_kernels_error"] = repr(exc)
     return out
 
 

@@ -528,6 +528,9 @@ typedef struct cstr_wgrad_adam_set {
     float *b, *b_m, *b_v;    /* the bias [n] and its moments (with g.db) */
     float *shadow;           /* tile-major copy of w kept current (cstr_policy_swizzle_f32's layout) or NULL */
     int32_t opt, reserved;   /* index into opts */
+    float *w_target, *b_target; /* these parameters' OWN target (soft update with the values just computed,
+                                   core/common/utils.py:478-481: target = tau * p + (1 - tau) * target) or NULL */
+    float tau, reserved2;
 } cstr_wgrad_adam_set_t;
 int cstr_linear_bwd_weight_adam_sets_f32(const cstr_wgrad_adam_set_t *sets, int n_sets, const cstr_adam_opt_t *opts, int n_opts,
                                          const cstr_adam_seg_t *flat, int n_flat, cstr_stream_t stream);
@@ -541,7 +544,7 @@ int cstr_linear_bwd_weight_adam_sets_f32(const cstr_wgrad_adam_set_t *sets, int 
  * leaves the NARROW layer behind it (a Q head's H2 -> 1 dot product, the actor head's H2 -> 2A, the first layer's input gradient
  * H1 -> act_dim) as per-column-group PARTIAL sums that the next launch adds up in a fixed order in its prologue.
  * SAC.train (core/sac/sac.py:215-287) = 10 launches instead of 20; everything is deterministic (no float atomics).
- * Networks: create_mlp(in, out, [H1, H2], ReLU) (core/common/torch_layers.py:110-183); H1, H2 multiples of 16, <= 512; batch a
+ * Networks: create_mlp(in, out, [H1, H2], ReLU) (core/common/torch_layers.py:110-183); H1, H2 multiples of 4, <= 512; batch a
  * multiple of 16, <= 1024; (obs_dim, act_dim) as the ring's layouts. `tiles` = 16-column tiles per workgroup (1, 2 or 4). */
 #define CSTR_CHAIN_MAX_NETS 4
 #define CSTR_CHAIN_MAX_WIDTH 512
@@ -561,11 +564,20 @@ typedef struct cstr_chain_net {
 #define CSTR_CHAIN_ROLE_NEXT 2       /* x = x_next whose ACTION columns are not written yet: every workgroup finalises the actor head
                                         of its pi(next_obs) rows for itself */
 #define CSTR_CHAIN_ROLE_NEXT_STORE 3 /* ... and the column-group-0 workgroups store them (x_next action columns, logp_next) */
+#define CSTR_CHAIN_ROLE_PI 4         /* x = x_pi whose ACTION columns are not written yet (a deterministic actor's loss pass): finalised
+                                        by every workgroup for itself, stored by the column-group-0 workgroups */
+/* rows of an actor chain pass */
+#define CSTR_CHAIN_ROWS_PAIR 0 /* [obs rows | next_obs rows], 2B rows: SAC's pi(obs) and pi(next_obs) */
+#define CSTR_CHAIN_ROWS_NEXT 1 /* next_obs rows, B rows: a target actor (core/td3/td3.py:171) */
+#define CSTR_CHAIN_ROWS_OBS 2  /* obs rows, B rows, activations kept: the deterministic actors' loss pass (core/td3/td3.py:194) */
+/* head of the actor */
+#define CSTR_CHAIN_HEAD_GAUSSIAN 0      /* [mu | log_std] (H2, 2A) + squashed-Gaussian sampling (core/sac/policies.py:147-175) */
+#define CSTR_CHAIN_HEAD_DETERMINISTIC 1 /* Linear(H2, A) + Tanh (core/td3/policies.py:57-83) */
 
 /* SAC actor Linear(D, H1)-ReLU-Linear(H1, H2)-ReLU-[mu | log_std](H2, 2A) (core/sac/policies.py:84-175), heads merged. */
 typedef struct cstr_sac_actor {
     int32_t obs_dim, act_dim, h1, h2;
-    const float *w1, *b1, *w2, *b2, *hw, *hb; /* hw [2A][H2], hb [2A] */
+    const float *w1, *b1, *w2, *b2, *hw, *hb; /* hw [head_n][H2], hb [head_n]: head_n = 2A (Gaussian) or A (deterministic) */
 } cstr_sac_actor_t;
 
 /* SAC.train's actor passes pi(obs) (core/sac/sac.py:222) and pi(next_obs) (:247) as ONE launch over 2B rows (rows [0, B) = obs,
@@ -584,18 +596,21 @@ typedef struct cstr_sac_actor {
 int cstr_sac_actor_chain_fwd_f32(const cstr_sac_actor_t *actor, const cstr_ring_t *ring, int64_t *ring_ctl, int advance_ring,
                                  const int32_t *sample_idx, int64_t batch, float *x_data, float *x_pi, float *x_next, float *out_done,
                                  float *out_rew, float *a_h1, float *a_h2, float *head_part, const uint64_t *head_rng_ctl,
-                                 uint64_t head_rng_offset, float *eps_all, int tiles, cstr_stream_t stream);
+                                 uint64_t head_rng_offset, float *eps_all, int rows_mode, int head_n, int tiles, cstr_stream_t stream);
 
 /* How a consumer launch turns the actor's head partials into actions (core/common/distributions.py:207-260, the arithmetic of
  * cstr_gaussian_head_gemm_fwd_f32): params = sum of partials + hb; u = mean + exp(clamp(log_std)) * eps; a = tanh(u); log-prob.
  * eps [2B][A]: the actor chain launch's eps_all, or teacher-forced draws. */
 typedef struct cstr_sac_head_fin {
-    const float *head_part; /* [n_parts][2B][2A] */
-    const float *hb;        /* [2A] */
-    const float *eps;       /* [2B][A] */
-    int32_t n_parts, act_dim, obs_dim, reserved;
+    const float *head_part; /* [n_parts][part_rows][head_n] */
+    const float *hb;        /* [head_n] */
+    const float *eps;       /* [part_rows][A] standard normal draws (or teacher-forced noise); deterministic head: may be NULL (no noise) */
+    int32_t n_parts, act_dim, obs_dim, kind; /* kind: CSTR_CHAIN_HEAD_* */
+    int32_t part_rows, next_offset;          /* rows of the actor pass; row of batch element b: pi rows b, next rows next_offset + b */
+    float sigma, clip;      /* deterministic head, next rows: a' = clamp(tanh(.) + clamp(sigma * eps, -clip, clip), -1, 1)
+                               (target policy smoothing, core/td3/td3.py:167-171) */
     float *x_pi, *x_next;   /* [B][D + A]: action columns written by the STORE roles */
-    float *params, *logp_pi, *logp_next; /* [B][2A], [B], [B] */
+    float *params, *logp_pi, *logp_next; /* Gaussian head: [B][2A], [B], [B] */
 } cstr_sac_head_fin_t;
 
 /* Forward of n_nets <= 4 Q networks on `batch` rows each in ONE launch: layer 1 recomputed per workgroup (K = W <= 12), layer 2 one
@@ -638,10 +653,12 @@ int cstr_q_chain_bwd_f32(const cstr_chain_net_t *nets, int n_nets, const cstr_ch
 /* Backward of the SAC actor from the critic's action-gradient partials in ONE launch (cstr_gaussian_head_bwd_input_f32 +
  * cstr_linear_bwd_input_f32): d(loss)/d(action) = sum of gact_part over networks and column groups; d(loss)/d(logp) = ent_coef / B
  * (core/sac/sac.py:275); the squashed-Gaussian head's analytic backward -> g_params [B][2A]; dz2 = (g_params hw) * relu'(a_h2)
- * recomputed (2A terms per element); one MFMA column group of dz1 = (dz2 W2) * relu'(a_h1). */
+ * recomputed (2A terms per element); one MFMA column group of dz1 = (dz2 W2) * relu'(a_h1).
+ * kind = CSTR_CHAIN_HEAD_DETERMINISTIC (core/td3/td3.py:194-199): g_params [B][A] = d(loss)/d(action) * (1 - a^2) (the Tanh); ent_coef,
+ * params and eps are not read. */
 int cstr_sac_actor_chain_bwd_f32(const cstr_sac_actor_t *actor, const float *gact_part, int n_nets, int n_parts, const float *ent_coef,
                                  const float *x_pi, const float *params, const float *eps, const float *a_h1, const float *a_h2,
-                                 float *g_params, float *dz2, float *dz1, int64_t batch, int tiles, cstr_stream_t stream);
+                                 float *g_params, float *dz2, float *dz1, int64_t batch, int kind, int tiles, cstr_stream_t stream);
 
 #ifdef __cplusplus
 }

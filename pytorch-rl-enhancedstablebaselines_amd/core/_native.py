@@ -86,7 +86,9 @@ class PolicyMlp(C.Structure):
 
 
 CHAIN_MAX_NETS, CHAIN_MAX_WIDTH = 4, 512
-CHAIN_ROLE_PLAIN, CHAIN_ROLE_STORE_PI, CHAIN_ROLE_NEXT, CHAIN_ROLE_NEXT_STORE = 0, 1, 2, 3
+CHAIN_ROLE_PLAIN, CHAIN_ROLE_STORE_PI, CHAIN_ROLE_NEXT, CHAIN_ROLE_NEXT_STORE, CHAIN_ROLE_PI = 0, 1, 2, 3, 4
+CHAIN_ROWS_PAIR, CHAIN_ROWS_NEXT, CHAIN_ROWS_OBS = 0, 1, 2
+CHAIN_HEAD_GAUSSIAN, CHAIN_HEAD_DETERMINISTIC = 0, 1
 
 
 class ChainNet(C.Structure):
@@ -101,8 +103,9 @@ class SacActorNet(C.Structure):
 
 class SacHeadFin(C.Structure):
     """cstr_sac_head_fin_t"""
-    _fields_ = [(n, C.c_void_p) for n in ("head_part", "hb", "eps")] + [(n, C.c_int32) for n in ("n_parts", "act_dim", "obs_dim", "reserved")] + [
-        (n, C.c_void_p) for n in ("x_pi", "x_next", "params", "logp_pi", "logp_next")]
+    _fields_ = [(n, C.c_void_p) for n in ("head_part", "hb", "eps")] + [(n, C.c_int32) for n in ("n_parts", "act_dim", "obs_dim", "kind", "part_rows",
+                                                                                                 "next_offset")] + [
+        ("sigma", C.c_float), ("clip", C.c_float)] + [(n, C.c_void_p) for n in ("x_pi", "x_next", "params", "logp_pi", "logp_next")]
 
 
 class ChainRoot(C.Structure):
@@ -122,7 +125,9 @@ class AdamOpt(C.Structure):
 
 class WgradAdamSet(C.Structure):
     """cstr_wgrad_adam_set_t"""
-    _fields_ = [("g", WgradSet)] + [(n, C.c_void_p) for n in ("w", "w_m", "w_v", "b", "b_m", "b_v", "shadow")] + [("opt", C.c_int32), ("reserved", C.c_int32)]
+    _fields_ = [("g", WgradSet)] + [(n, C.c_void_p) for n in ("w", "w_m", "w_v", "b", "b_m", "b_v", "shadow")] + [("opt", C.c_int32), ("reserved", C.c_int32),
+                                                                                                             ("w_target", C.c_void_p), ("b_target", C.c_void_p),
+                                                                                                             ("tau", C.c_float), ("reserved2", C.c_float)]
 
 
 class VecNormCfg(C.Structure):

@@ -135,8 +135,8 @@ class SacChain:
         else:
             hip_ops.sac_actor_chain_fwd(self.actor, B, None, pb.x_pi, pb.x_next, None, None, self.a_h1, self.a_h2, self.head_part, self.t_act, **noise)
         # -- critics on x_data, target critics on x_next (its action columns finalised inside the launch)
-        fin = nv.SacHeadFin(self.head_part.data_ptr(), fa._hb.data_ptr(), eps.data_ptr(), self.n_head_parts, A, D, 0, pb.x_pi.data_ptr(),
-                            pb.x_next.data_ptr(), self.params.data_ptr(), self.logp_pi.data_ptr(), self.logp_next.data_ptr())
+        fin = nv.SacHeadFin(self.head_part.data_ptr(), fa._hb.data_ptr(), eps.data_ptr(), self.n_head_parts, A, D, nv.CHAIN_HEAD_GAUSSIAN, 2 * B, B, 0.0, 0.0,
+                            pb.x_pi.data_ptr(), pb.x_next.data_ptr(), self.params.data_ptr(), self.logp_pi.data_ptr(), self.logp_next.data_ptr())
         self._keep = eps2  # alive until the launches that read it have been issued (and recorded)
         nets4 = [hip_ops.chain_net(self.crit[0], pb.x_data, self.c_h1[0], self.c_h2[0], self.q_part4[0], nv.CHAIN_ROLE_STORE_PI),
                  hip_ops.chain_net(self.crit[1], pb.x_data, self.c_h1[1], self.c_h2[1], self.q_part4[1], nv.CHAIN_ROLE_PLAIN),
@@ -221,3 +221,168 @@ class SacChain:
                                             critic_loss=sto("critic", model._loss_now["critic"]).clone(),
                                             actor_loss=sto("actor", model._loss_now["actor"]).clone(),
                                             ent_coef=ent_coef.detach().clone(), log_prob=self.logp_pi.clone())
+
+
+def _pick_tiles(kdim: int, want: int) -> int:
+    """The largest tile count <= `want` whose per-wave share of a K = kdim reduction fits in registers."""
+    for t in (4, 2, 1):
+        if t <= want and hip_ops.chain_tiles_ok(kdim, t):
+            return t
+    return 1
+
+
+class Td3Chain:
+    """TD3.train's gradient step (core/td3/td3.py:154-211) on the chain kernels:
+
+        critic step (every update)     target actor chain (next_obs rows, head as partial sums) -> Q chain, 4 networks (target actions +
+                                       smoothing noise finalised inside) -> Q backward chain (TD target + critic loss inside) -> dW / db +
+                                       Adam: 4 launches
+        policy step (every 2nd update) actor chain (obs rows) -> Q chain, first critic on (obs, pi(obs)) -> Q backward chain (-mean(Q1))
+                                       to the action -> actor backward chain -> dW / db + Adam + the soft updates of both targets: 5 launches
+    Twin critics and deterministic 3-Linear actors only (DDPG's single critic stays on the per-layer path)."""
+
+    @staticmethod
+    def supported(model, batch_size: int) -> bool:
+        if not (USE_CHAIN and fused.USE_FUSED_LINEAR and model.fused_learner and model._use_packed_batch()):
+            return False
+        if len(model.critic.q_networks) != 2:
+            return False
+        for q in list(model.critic.q_networks) + list(model.critic_target.q_networks):
+            mods = list(q)
+            if len(mods) != 5 or not all(isinstance(mods[i], nn.Linear) for i in (0, 2, 4)) or not all(isinstance(mods[i], nn.ReLU) for i in (1, 3)):
+                return False
+            if mods[4].out_features != 1:
+                return False
+        for actor in (model.actor, model.actor_target):
+            mods = list(actor.mu)
+            if (len(mods) != 6 or not all(isinstance(mods[i], nn.Linear) for i in (0, 2, 4)) or not all(isinstance(mods[i], nn.ReLU) for i in (1, 3))
+                    or not isinstance(mods[5], nn.Tanh)):
+                return False
+        a1, a2, a3 = (model.actor.mu[i] for i in (0, 2, 4))
+        c1, c2 = model.critic.q_networks[0][0], model.critic.q_networks[0][2]
+        d, a = a1.in_features, a3.out_features
+        if (d, a) not in hip_ops.LAYOUTS or c1.in_features != d + a:
+            return False
+        return (hip_ops.chain_supported(a1.out_features, a2.out_features, batch_size) and hip_ops.chain_supported(c1.out_features, c2.out_features, batch_size)
+                and all(p.grad is not None for p in list(model.actor.parameters()) + list(model.critic.parameters())))
+
+    def __init__(self, model, batch_size: int):
+        dev, B = model.device, batch_size
+        a1, a2, a3 = (model.actor.mu[i] for i in (0, 2, 4))
+        t1, t2, t3 = (model.actor_target.mu[i] for i in (0, 2, 4))
+        self.D, self.A, self.B = a1.in_features, a3.out_features, B
+        self.W = self.D + self.A
+        self.aH1, self.aH2 = a1.out_features, a2.out_features
+        c = model.critic.q_networks[0]
+        self.cH1, self.cH2 = c[0].out_features, c[2].out_features
+        t_act, t_q4, t_q2, t_qb, t_ab = TILES
+        self.t_act, self.t_q4, self.t_q1 = _pick_tiles(self.aH1, t_act), _pick_tiles(self.cH1, t_q4), _pick_tiles(self.cH1, t_q2)
+        self.t_qb, self.t_ab = _pick_tiles(self.cH2, t_qb), _pick_tiles(self.aH2, t_ab)
+        self.actor = hip_ops.sac_actor_desc(self.D, self.A, a1.weight, a1.bias, a2.weight, a2.bias, a3.weight, a3.bias)
+        self.tactor = hip_ops.sac_actor_desc(self.D, self.A, t1.weight, t1.bias, t2.weight, t2.bias, t3.weight, t3.bias)
+        self.actor_layers, self.tactor_layers = (a1, a2, a3), (t1, t2, t3)
+        self.crit = [_q_layers(q) for q in model.critic.q_networks]
+        self.targ = [_q_layers(q) for q in model.critic_target.q_networks]
+        e = lambda *sh: th.empty(*sh, dtype=th.float32, device=dev)  # noqa: E731
+        A, H1, H2 = self.A, self.aH1, self.aH2
+        self.n_head = hip_ops.chain_colgroups(H2, self.t_act)
+        self.head_part = e(self.n_head, B, A)
+        self.eps = e(B, A)
+        self.a_h1, self.a_h2 = e(B, H1), e(B, H2)
+        self.c_h1, self.c_h2 = e(2, B, self.cH1), e(2, B, self.cH2)
+        self.n_q4, self.n_q1 = hip_ops.chain_colgroups(self.cH2, self.t_q4), hip_ops.chain_colgroups(self.cH2, self.t_q1)
+        self.q_part4, self.q_part1 = e(4, self.n_q4, B), e(1, self.n_q1, B)
+        self.q_out, self.qpi_out, self.gq = e(2, B), e(1, B), e(2, B)
+        self.dz2c, self.dz1c = e(2, B, self.cH2), e(2, B, self.cH1)
+        self.n_gact = hip_ops.chain_colgroups(self.cH1, self.t_qb)
+        self.gact_part = e(1, self.n_gact, B, A)
+        self.g_params, self.dz2a, self.dz1a = e(B, A), e(B, H2), e(B, H1)
+
+    def step(self, model, pb, gather, n_updates: int) -> None:
+        s, pol, B, W, D, A = model._loss_sums, model.policy, self.B, self.W, self.D, self.A
+        rd = pb.samples
+        single = getattr(model, "_single_step", False)
+        c_out, c_sum = (s["critic"], None) if single else (model._loss_now["critic"], s["critic"])
+        queued = model.noise_queue.pop(0).to(model.device, th.float32).contiguous() if model.noise_queue else None  # teacher-forced, scaled
+        rng = None if queued is not None else model._device_rng()
+        noise = {} if queued is not None else dict(head_rng_ctl=rng, eps_all=self.eps)
+        eps = self.eps if queued is None else queued
+        sigma = model.target_policy_noise if queued is None else 1.0
+        fuse_opt = USE_WGRAD_ADAM and model.world_size == 1 and B > 32 and not getattr(model, "_force_segment_boundaries", False)
+        # -- critic step: target actor on next_obs (:171), four Q networks (:173, :179), TD target + loss + backward (:174-186)
+        kw = dict(rows_mode=nv.CHAIN_ROWS_NEXT, head_n=A, **noise)
+        if gather is not None:
+            ring, idx, pending, _ = gather
+            if pending is not None:
+                raise RuntimeError("a deterministic actor's rollout launch draws nothing: no Philox advance can be pending")
+            hip_ops.sac_actor_chain_fwd(self.tactor, B, pb.x_data, pb.x_pi, pb.x_next, rd.dones, rd.rewards, None, None, self.head_part, self.t_act,
+                                        ring=ring, sample_idx=idx, advance_ring=True, **kw)
+        else:
+            hip_ops.sac_actor_chain_fwd(self.tactor, B, None, None, pb.x_next, None, None, None, None, self.head_part, self.t_act, **kw)
+        t3 = self.tactor_layers[2]
+        fin = nv.SacHeadFin(self.head_part.data_ptr(), t3.bias.data_ptr(), eps.data_ptr(), self.n_head, A, D, nv.CHAIN_HEAD_DETERMINISTIC, B, 0,
+                            float(sigma), float(model.target_noise_clip), pb.x_pi.data_ptr(), pb.x_next.data_ptr(), None, None, None)
+        self._keep = queued
+        nets4 = [hip_ops.chain_net(self.crit[0], pb.x_data, self.c_h1[0], self.c_h2[0], self.q_part4[0], nv.CHAIN_ROLE_PLAIN),
+                 hip_ops.chain_net(self.crit[1], pb.x_data, self.c_h1[1], self.c_h2[1], self.q_part4[1], nv.CHAIN_ROLE_PLAIN),
+                 hip_ops.chain_net(self.targ[0], pb.x_next, None, None, self.q_part4[2], nv.CHAIN_ROLE_NEXT_STORE),
+                 hip_ops.chain_net(self.targ[1], pb.x_next, None, None, self.q_part4[3], nv.CHAIN_ROLE_NEXT)]
+        hip_ops.q_chain_fwd(nets4, W, D, self.cH1, self.cH2, B, self.t_q4, fin)
+        b3s = [self.crit[0][2][1], self.crit[1][2][1], self.targ[0][2][1], self.targ[1][2][1]]
+        root = hip_ops.chain_root("td", B, [self.q_part4[g] for g in range(4)], b3s, self.n_q4, gamma=model.gamma, scale=1.0, rew=rd.rewards,
+                                  done=rd.dones, target_out=model._target_q, q_out=self.q_out, gq_out=self.gq, loss_out=c_out, loss_sum=c_sum,
+                                  rng_advance=None if queued is not None else (rng, B), adam_advance=[model.critic.optimizer] if fuse_opt else ())
+        back = [hip_ops.chain_net(self.crit[g], None, self.c_h1[g], self.c_h2[g]) for g in range(2)]
+        hip_ops.q_chain_bwd(back, root, W, D, self.cH1, self.cH2, self.t_qb, dz2=self.dz2c, dz1=self.dz1c)
+        sets = []
+        for g in range(2):
+            (w1, b1), (w2, b2), (w3, b3) = self.crit[g]
+            if fuse_opt:
+                sets += [(self.dz1c[g], pb.x_data, w1, b1, 0, None), (self.dz2c[g], self.c_h1[g], w2, b2, 0, None),
+                         (self.gq[g].view(B, 1), self.c_h2[g], w3, b3, 0, None)]
+            else:
+                sets += [(self.dz1c[g], pb.x_data, w1.grad, b1.grad), (self.dz2c[g], self.c_h1[g], w2.grad, b2.grad),
+                         (self.gq[g].view(B, 1), self.c_h2[g], w3.grad, b3.grad)]
+        if fuse_opt:
+            hip_ops.linear_bwd_weight_adam_sets(sets, [model.critic.optimizer])
+        else:
+            hip_ops.linear_bwd_weight_sets(sets)
+            model._allreduce_grads(pol.critic_arena)
+            model.critic.optimizer.step()
+        actor_done = False
+        a_out = None
+        if n_updates % model.policy_delay == 0:  # :192-206
+            a_out, a_sum = (s["actor"], None) if single else (model._loss_now["actor"], s["actor"])
+            a1, a2, a3 = self.actor_layers
+            hip_ops.sac_actor_chain_fwd(self.actor, B, None, pb.x_pi, None, None, None, self.a_h1, self.a_h2, self.head_part, self.t_act,
+                                        rows_mode=nv.CHAIN_ROWS_OBS, head_n=A)
+            fin2 = nv.SacHeadFin(self.head_part.data_ptr(), a3.bias.data_ptr(), None, self.n_head, A, D, nv.CHAIN_HEAD_DETERMINISTIC, B, 0, 0.0, 0.0,
+                                 pb.x_pi.data_ptr(), None, None, None, None)
+            net1 = [hip_ops.chain_net(self.crit[0], pb.x_pi, self.c_h1[0], self.c_h2[0], self.q_part1[0], nv.CHAIN_ROLE_PI)]
+            hip_ops.q_chain_fwd(net1, W, D, self.cH1, self.cH2, B, self.t_q1, fin2)
+            aroot = hip_ops.chain_root("neg_mean", B, [self.q_part1[0]], b3s[:1], self.n_q1, q_out=self.qpi_out, loss_out=a_out, loss_sum=a_sum,
+                                       adam_advance=[model.actor.optimizer] if fuse_opt else ())
+            hip_ops.q_chain_bwd(back[:1], aroot, W, D, self.cH1, self.cH2, self.t_qb, gact_part=self.gact_part)
+            hip_ops.sac_actor_chain_bwd(self.actor, self.gact_part, 1, self.n_gact, None, pb.x_pi, None, None, self.a_h1, self.a_h2, self.g_params,
+                                        self.dz2a, self.dz1a, B, self.t_ab, kind=nv.CHAIN_HEAD_DETERMINISTIC)
+            if not pol.actor_target_arena.same_layout(pol.actor_arena) or not pol.critic_target_arena.same_layout(pol.critic_arena):
+                raise ValueError("Iterables have different lengths")  # zip_strict's error (utils.py:447)
+            if fuse_opt:
+                aopt, tau = model.actor.optimizer, model.tau
+                sh = aopt.shadow
+                shadow_of = lambda lin: sh[0] if sh is not None and sh[4] is lin.weight else None  # noqa: E731
+                t1, t2, t3 = self.tactor_layers
+                sets = [(self.dz1a, pb.x_pi[:, :D], a1.weight, a1.bias, 0, shadow_of(a1), (t1.weight.detach(), t1.bias.detach(), tau)),
+                        (self.dz2a, self.a_h1, a2.weight, a2.bias, 0, shadow_of(a2), (t2.weight.detach(), t2.bias.detach(), tau)),
+                        (self.g_params, self.a_h2, a3.weight, a3.bias, 0, shadow_of(a3), (t3.weight.detach(), t3.bias.detach(), tau))]
+                hip_ops.linear_bwd_weight_adam_sets(sets, [aopt], [("polyak", pol.critic_arena.flat, pol.critic_target_arena.flat, tau)])  # :199-205
+            else:
+                hip_ops.linear_bwd_weight_sets([(self.dz1a, pb.x_pi[:, :D], a1.weight.grad, a1.bias.grad), (self.dz2a, self.a_h1, a2.weight.grad, a2.bias.grad),
+                                                (self.g_params, self.a_h2, a3.weight.grad, a3.bias.grad)])
+                model._allreduce_grads(pol.actor_arena)
+                model.actor.optimizer.step_with(polyak=(pol.critic_arena, pol.critic_target_arena, model.tau),
+                                                own_target=(pol.actor_target_arena.flat, model.tau))
+            actor_done = True
+        if model.debug_capture:
+            model.last_train_tensors = dict(target_q=model._target_q.clone(), current_q=[self.q_out[0].clone().view(B, 1), self.q_out[1].clone().view(B, 1)],
+                                            critic_loss=c_out.clone(), actor_loss=a_out.clone() if actor_done else None)

@@ -900,8 +900,15 @@ def neg_mean_loss(q, gq, loss_out=None, loss_sum=None):
 
 # ---- row-chain kernels (csrc/cstr_chain.hip, include/cstr_rl_hip.h "row-chain kernels") -------------------------------------------
 def chain_supported(h1: int, h2: int, batch: int) -> bool:
-    return (16 <= h1 <= 384 and 16 <= h2 <= nv.CHAIN_MAX_WIDTH and h1 % 16 == 0 and h2 % 16 == 0
-            and 16 <= batch <= 1024 and batch % 16 == 0)  # h1: panel + staged W1 within 64 KB of LDS
+    """Widths multiples of 4; forward launches hold a 16 x (H1 + 4) panel and W1 staged as [H1][16] in 64 KB of LDS."""
+    return (16 <= h1 <= nv.CHAIN_MAX_WIDTH and 16 <= h2 <= nv.CHAIN_MAX_WIDTH and h1 % 4 == 0 and h2 % 4 == 0 and 4 * (1664 + 16 * (h1 + 4) + 16 * h1) <= 65536
+            and 16 <= batch <= 1024 and batch % 16 == 0)
+
+
+def chain_tiles_ok(kdim: int, tiles: int) -> bool:
+    """A wave holds at most 16 16-wide chunks of the reduction in registers."""
+    s = 4 // tiles
+    return -(-((kdim + 15) // 16) // s) <= 16
 
 
 def chain_colgroups(width: int, tiles: int) -> int:
@@ -913,25 +920,34 @@ def _dp(t):
 
 
 def sac_actor_desc(obs_dim: int, act_dim: int, w1, b1, w2, b2, hw, hb) -> "nv.SacActorNet":
+    """hw / hb: the merged [mu | log_std] head ([2A, H2]) or a deterministic actor's last Linear ([A, H2])."""
     h1, h2 = w1.shape[0], w2.shape[0]
-    for t, nm, shape in ((w1, "w1", (h1, obs_dim)), (b1, "b1", (h1,)), (w2, "w2", (h2, h1)), (b2, "b2", (h2,)), (hw, "hw", (2 * act_dim, h2)),
-                         (hb, "hb", (2 * act_dim,))):
+    hn = hw.shape[0]
+    if hn not in (act_dim, 2 * act_dim):
+        raise ValueError(f"head: {hn} outputs for {act_dim} actions")
+    for t, nm, shape in ((w1, "w1", (h1, obs_dim)), (b1, "b1", (h1,)), (w2, "w2", (h2, h1)), (b2, "b2", (h2,)), (hw, "hw", (hn, h2)),
+                         (hb, "hb", (hn,))):
         _chk(t, nm, shape, th.float32)
     return nv.SacActorNet(obs_dim, act_dim, h1, h2, w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), hw.data_ptr(), hb.data_ptr())
 
 
 def sac_actor_chain_fwd(actor: "nv.SacActorNet", batch: int, x_data, x_pi, x_next, out_done, out_rew, a_h1, a_h2, head_part, tiles: int,
                         ring: Optional[DeviceRing] = None, sample_idx=None, advance_ring: bool = False, head_rng_ctl=None, head_rng_offset: int = 0,
-                        eps_all=None):
-    """cstr_sac_actor_chain_fwd_f32: gather (or packed observation columns) + layer 1 + layer 2 + head partials of the 2B-row actor pass."""
+                        eps_all=None, rows_mode: int = 0, head_n: Optional[int] = None):
+    """cstr_sac_actor_chain_fwd_f32: gather (or packed observation columns) + layer 1 + layer 2 + head partials of an actor pass
+    (rows_mode: CHAIN_ROWS_PAIR = SAC's 2B rows, CHAIN_ROWS_NEXT / CHAIN_ROWS_OBS = B rows of a deterministic actor)."""
     w = actor.obs_dim + actor.act_dim
     ncg = chain_colgroups(actor.h2, tiles)
+    head_n = 2 * actor.act_dim if head_n is None else head_n
+    m = 2 * batch if rows_mode == nv.CHAIN_ROWS_PAIR else batch
     for t, nm in ((x_pi, "x_pi"), (x_next, "x_next")):
-        if not (t.is_cuda and t.dtype == th.float32 and tuple(t.shape) == (batch, w) and t.stride() == (w, 1)):
+        if t is not None and not (t.is_cuda and t.dtype == th.float32 and tuple(t.shape) == (batch, w) and t.stride() == (w, 1)):
             raise ValueError(f"{nm}: needs a float32 device matrix [{batch}, {w}] with row stride {w}")
-    _chk(a_h1, "a_h1", (batch, actor.h1), th.float32), _chk(a_h2, "a_h2", (batch, actor.h2), th.float32)
-    _chk(head_part, "head_part", (ncg, 2 * batch, 2 * actor.act_dim), th.float32)
-    _opt(eps_all, "eps_all", (2 * batch, actor.act_dim), th.float32), _opt(head_rng_ctl, "head_rng_ctl", (nv.RNG_CTL_WORDS,), th.int64)
+    _opt(a_h1, "a_h1", (batch, actor.h1), th.float32), _opt(a_h2, "a_h2", (batch, actor.h2), th.float32)
+    _chk(head_part, "head_part", (ncg, m, head_n), th.float32)
+    _opt(eps_all, "eps_all", (m, actor.act_dim), th.float32), _opt(head_rng_ctl, "head_rng_ctl", (nv.RNG_CTL_WORDS,), th.int64)
+    if not chain_tiles_ok(actor.h1, tiles):
+        raise ValueError(f"tiles = {tiles}: a wave's share of K = {actor.h1} does not fit")
     if sample_idx is not None:
         _chk(sample_idx, "sample_idx", (2, batch), th.int32)
         _chk(x_data, "x_data", (batch, w), th.float32), _chk(out_done, "out_done", (batch, 1), th.float32), _chk(out_rew, "out_rew", (batch, 1), th.float32)
@@ -939,7 +955,7 @@ def sac_actor_chain_fwd(actor: "nv.SacActorNet", batch: int, x_data, x_pi, x_nex
                                                 C.c_int(1 if advance_ring else 0), ptr(sample_idx),
                                                 C.c_int64(batch), ptr(x_data), ptr(x_pi), ptr(x_next), ptr(out_done), ptr(out_rew), ptr(a_h1),
                                                 ptr(a_h2), ptr(head_part), ptr(head_rng_ctl), C.c_uint64(int(head_rng_offset)), ptr(eps_all),
-                                                C.c_int(tiles), stream_ptr()),
+                                                C.c_int(rows_mode), C.c_int(head_n), C.c_int(tiles), stream_ptr()),
           "cstr_sac_actor_chain_fwd_f32")
 
 
@@ -959,7 +975,8 @@ def q_chain_fwd(nets, w_in: int, obs_dim: int, h1: int, h2: int, batch: int, til
 
 def linear_bwd_weight_adam_sets(sets, opts, flat=()):
     """cstr_linear_bwd_weight_adam_sets_f32: dW / db of several Linears AND their Adam steps in one launch. `sets`: [(dz [M, N], x [M, K]
-    (row-strided ok), weight parameter, bias parameter, optimiser index, shadow tensor or None)]; the parameters' .grad and moment views
+    (row-strided ok), weight parameter, bias parameter, optimiser index, shadow tensor or None[, (weight target, bias target, tau)])];
+    the parameters' .grad and moment views
     are looked up in `opts` = [FlatAdam, ...] (pre-advanced control words: see chain_root's adam_advance). `flat`: adam_multi segments
     (no shadow) for parameters without a tile and soft target updates."""
     sets, opts = list(sets), list(opts)
@@ -968,7 +985,9 @@ def linear_bwd_weight_adam_sets(sets, opts, flat=()):
     for i, o in enumerate(opts):
         g = o.param_groups[0]
         oarr[i] = nv.AdamOpt(o.ctl.data_ptr(), o.lr_dev.data_ptr(), g["betas"][0], g["betas"][1], g["eps"], o.grad_scale, 0)
-    for i, (dz, x, weight, bias, oi, shadow) in enumerate(sets):
+    for i, st in enumerate(sets):
+        dz, x, weight, bias, oi, shadow = st[:6]
+        own = st[6] if len(st) > 6 and st[6] is not None else (None, None, 0.0)
         m, n = dz.shape
         k = x.shape[-1]
         _f32c(dz, f"dz[{i}]")
@@ -987,7 +1006,9 @@ def linear_bwd_weight_adam_sets(sets, opts, flat=()):
             raise ValueError("shadow: wrong size")
         arr[i] = nv.WgradAdamSet(nv.WgradSet(dz.data_ptr(), x.data_ptr(), max(x.stride(0), k), wq[1].data_ptr(), bq[1].data_ptr(), m, n, k),
                                  wq[0].data_ptr(), wq[2].data_ptr(), wq[3].data_ptr(), bq[0].data_ptr(), bq[2].data_ptr(), bq[3].data_ptr(),
-                                 _dp(shadow), oi, 0)
+                                 _dp(shadow), oi, 0, _dp(own[0]), _dp(own[1]), float(own[2]), 0.0)
+        if own[0] is not None and (_f32c(own[0], "weight target").numel() != n * k or _f32c(own[1], "bias target").numel() != n):
+            raise ValueError(f"set {i}: target views do not match the parameters")
     farr, nf = _adam_segments(flat)
     check(nv.lib().cstr_linear_bwd_weight_adam_sets_f32(arr, C.c_int(len(sets)), oarr, C.c_int(len(opts)), farr, C.c_int(nf), stream_ptr()),
           "cstr_linear_bwd_weight_adam_sets_f32")
@@ -1020,11 +1041,13 @@ def q_chain_bwd(nets, root: "nv.ChainRoot", w_in: int, obs_dim: int, h1: int, h2
 
 
 def sac_actor_chain_bwd(actor: "nv.SacActorNet", gact_part, n_nets: int, n_parts: int, ent_coef, x_pi, params, eps, a_h1, a_h2, g_params, dz2, dz1,
-                        batch: int, tiles: int):
-    """cstr_sac_actor_chain_bwd_f32: action gradient from the critic's partials, Gaussian head backward, dz2 (recomputed), dz1 column group."""
+                        batch: int, tiles: int, kind: int = 0):
+    """cstr_sac_actor_chain_bwd_f32: action gradient from the critic's partials, head backward (kind: CHAIN_HEAD_GAUSSIAN / _DETERMINISTIC),
+    dz2 (recomputed), dz1 column group."""
+    hn = actor.act_dim if kind == nv.CHAIN_HEAD_DETERMINISTIC else 2 * actor.act_dim
     _chk(gact_part, "gact_part", (n_nets, n_parts, batch, actor.act_dim), th.float32)
-    _chk(g_params, "g_params", (batch, 2 * actor.act_dim), th.float32), _chk(dz2, "dz2", (batch, actor.h2), th.float32)
+    _chk(g_params, "g_params", (batch, hn), th.float32), _chk(dz2, "dz2", (batch, actor.h2), th.float32)
     _chk(dz1, "dz1", (batch, actor.h1), th.float32)
     check(nv.lib().cstr_sac_actor_chain_bwd_f32(C.byref(actor), ptr(gact_part), C.c_int(n_nets), C.c_int(n_parts), ptr(ent_coef), ptr(x_pi), ptr(params),
-                                                ptr(eps), ptr(a_h1), ptr(a_h2), ptr(g_params), ptr(dz2), ptr(dz1), C.c_int64(batch), C.c_int(tiles),
-                                                stream_ptr()), "cstr_sac_actor_chain_bwd_f32")
+                                                ptr(eps), ptr(a_h1), ptr(a_h2), ptr(g_params), ptr(dz2), ptr(dz1), C.c_int64(batch), C.c_int(kind),
+                                                C.c_int(tiles), stream_ptr()), "cstr_sac_actor_chain_bwd_f32")

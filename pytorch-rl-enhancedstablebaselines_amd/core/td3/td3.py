@@ -162,6 +162,13 @@ class TD3(OffPolicyAlgorithm):
         """td3.py:161-206 on the fused path (core/common/fused.py)."""
         s, pol = self._loss_sums, self.policy
         pb, gather = None, None
+        chain = self._chain_for(batch_size)
+        if chain is not None:  # the row-chain kernels (core/common/chain.py): 4 launches (9 with the policy step) instead of 13 (22)
+            pb = self._packed_batch(batch_size)
+            gather = self.replay_buffer.take_predrawn(pb) if fused.USE_GATHER_IN_FIRST_LAYER else None
+            if gather is None:
+                self.replay_buffer.sample_packed_into(pb)  # :161 + the critics' cat([obs, act])
+            return chain.step(self, pb, gather, n_updates)
         if self._use_packed_batch():
             pb = self._packed_batch(batch_size)
             if fused.USE_GATHER_IN_FIRST_LAYER and self._fast_actor_target.gather_supported(pb.samples.next_observations):
@@ -256,6 +263,16 @@ class TD3(OffPolicyAlgorithm):
             self.last_train_tensors = dict(target_q=self._target_q.clone(), current_q=[q.detach().clone() for q in qs],
                                            critic_loss=c_out.clone(),
                                            actor_loss=a_out.clone() if actor_done else None)
+
+    def _chain_for(self, batch_size: int):
+        """The row-chain form of the gradient step for this batch size (core/common/chain.py), or None: per-layer fused path."""
+        from core.common import chain
+
+        cache = self.__dict__.setdefault("_chain_cache", {})
+        key = (batch_size, chain.USE_CHAIN, fused.USE_FUSED_LINEAR)
+        if key not in cache:
+            cache[key] = chain.Td3Chain(self, batch_size) if chain.Td3Chain.supported(self, batch_size) else None
+        return cache[key]
 
     def _get_torch_save_params(self) -> tuple:
         """reference: td3.py:234-240"""

@@ -199,16 +199,18 @@ __device__ __forceinline__ void layer1_mfma(const float *xs, const float *w1s, f
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, h = lane >> 4;
     const float4 xa = *reinterpret_cast<const float4 *>(xs + r * 16 + 4 * h);
-    for (int tl = wave; tl < h1 / 16; tl += CH_WAVES) {
-        const float4 wb = *reinterpret_cast<const float4 *>(w1s + (16 * tl + r) * 16 + 4 * h);
+    for (int tl = wave; tl < (h1 + 15) / 16; tl += CH_WAVES) {
+        const float4 wb = *reinterpret_cast<const float4 *>(w1s + min(16 * tl + r, h1 - 1) * 16 + 4 * h);
         f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
         acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.x, wb.x, acc0, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.y, wb.y, acc1, 0, 0, 0);
         acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.z, wb.z, acc0, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.w, wb.w, acc1, 0, 0, 0);
         const f32x4 acc = acc0 + acc1;
+        if (16 * tl + r < h1) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) panel[(4 * h + e) * ld + 16 * tl + r] = fmaxf(acc[e], 0.0f);
+            for (int e = 0; e < 4; ++e) panel[(4 * h + e) * ld + 16 * tl + r] = fmaxf(acc[e], 0.0f);
+        }
     }
 }
 
@@ -229,6 +231,7 @@ struct ActorFwdArgs {
     const int32_t *idx; int batch, tiles;
     float *x_data, *x_pi, *x_next, *out_done, *out_rew, *a_h1, *a_h2, *head_part;
     const uint64_t *head_rng_ctl; uint64_t head_rng_offset; float *eps_all;
+    int rows_mode, head_n;  // CSTR_CHAIN_ROWS_*; head outputs: 2A (mu | log_std) or A (deterministic actor)
 };
 
 template <int D, int A, int NQ>
@@ -238,12 +241,13 @@ __global__ __launch_bounds__(CH_THREADS) void sac_actor_chain_fwd_kernel(const A
     constexpr int W = D + A, QPR = D / 4;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, r = lane & 15, h = lane >> 4;
     const int T = a.tiles, S = CH_WAVES / T, tile = wave % T, ks = wave / T;
-    const int H1 = a.net.h1, H2 = a.net.h2, B = a.batch, M = 2 * B;
+    const int H1 = a.net.h1, H2 = a.net.h2, B = a.batch, mode = a.rows_mode, HN = a.head_n;
+    const int M = mode == CSTR_CHAIN_ROWS_PAIR ? 2 * B : B;
     const int n0 = (blockIdx.x * T + tile) * 16, m0 = blockIdx.y * 16;
     float *xs = smem + SM_XS, *red = smem + SM_RED, *panel = smem + SM_PANEL;
     const int ld = H1 + 4;
     float *w1s = panel + 16 * ld;
-    const bool tile_ok = n0 < H2;
+    const bool col_ok = n0 + r < H2;
     // (a) everything that depends on nothing is requested NOW: the wide layer's B operand, the epilogue's bias and head weights, W1
     float4 bq[NQ];
     load_b_fwd<NQ>(bq, a.net.w2, H2, H1, n0, ks, S);
@@ -251,24 +255,27 @@ __global__ __launch_bounds__(CH_THREADS) void sac_actor_chain_fwd_kernel(const A
     const float bv = a.net.b2[col];
     float hwv[2 * A];
 #pragma unroll
-    for (int j = 0; j < 2 * A; ++j) hwv[j] = a.net.hw[(int64_t)j * H2 + col];
+    for (int j = 0; j < 2 * A; ++j) hwv[j] = j < HN ? a.net.hw[(int64_t)j * H2 + col] : 0.0f;
     stage_w1<D>(w1s, a.net.w1, a.net.b1, H1);
     // (b) the row group's 16 input rows: ReplayBuffer.sample's gather (buffers.py:316-323) or the already packed observation columns
     const bool mat = a.idx != nullptr && blockIdx.x == 0;  // this workgroup also materialises the packed batch (stores at the end)
-    float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f), vo = v;
     float actv[A], dn = 0.0f, to = 0.0f, rw = 0.0f;
 #pragma unroll
     for (int j = 0; j < A; ++j) actv[j] = 0.0f;
     int b = 0;
     bool next = false;
+    // rows of the pass: PAIR = [obs rows | next_obs rows] (SAC), NEXT = next_obs rows (a target actor), OBS = obs rows (the actor loss)
+    const bool data_row = mode != CSTR_CHAIN_ROWS_PAIR;  // (with a gather) every row also writes its transition's x_data / reward / done
     if (t < 16 * QPR) {
         const int row = t / QPR, qd = t % QPR, m = m0 + row;
-        next = m >= B;
-        b = next ? m - B : m;
+        next = mode == CSTR_CHAIN_ROWS_PAIR ? m >= B : mode == CSTR_CHAIN_ROWS_NEXT;
+        b = (mode == CSTR_CHAIN_ROWS_PAIR && next) ? m - B : m;
         if (a.idx) {
             const int64_t o = (int64_t)a.idx[b] * a.ring.n_envs + a.idx[B + b];
             v = *reinterpret_cast<const float4 *>((next ? a.ring.next_obs : a.ring.obs) + o * D + 4 * qd);
-            if (mat && !next && qd == 0) {
+            if (mat && data_row && next) vo = *reinterpret_cast<const float4 *>(a.ring.obs + o * D + 4 * qd);
+            if (mat && (!next || data_row) && qd == 0) {
 #pragma unroll
                 for (int j = 0; j < A; ++j) actv[j] = a.ring.act[o * A + j];
                 dn = a.ring.done[o]; to = a.ring.timeout[o]; rw = a.ring.rew[o];
@@ -306,29 +313,32 @@ __global__ __launch_bounds__(CH_THREADS) void sac_actor_chain_fwd_kernel(const A
     float hv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     if (wave < T) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) hv[e] = tile_ok ? fmaxf(acc[e] + bv, 0.0f) : 0.0f;
+        for (int e = 0; e < 4; ++e) hv[e] = col_ok ? fmaxf(acc[e] + bv, 0.0f) : 0.0f;
 #pragma unroll
         for (int j = 0; j < 2 * A; ++j) {
+            if (j < HN) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float s = rowsum16(hv[e] * hwv[j]);
-                if (r == 0) red[(tile * 16 + 4 * h + e) * 8 + j] = s;
+                for (int e = 0; e < 4; ++e) {
+                    const float s = rowsum16(hv[e] * hwv[j]);
+                    if (r == 0) red[(tile * 16 + 4 * h + e) * 8 + j] = s;
+                }
             }
         }
     }
     lds_barrier();
-    if (t < 16 * 2 * A) {
-        const int row = t / (2 * A), j = t % (2 * A);
+    if (t < 16 * HN) {
+        const int row = t / HN, j = t % HN;
         float s = red[row * 8 + j];
         for (int tl = 1; tl < T; ++tl) s += red[(tl * 16 + row) * 8 + j];
-        a.head_part[((int64_t)blockIdx.x * M + m0 + row) * (2 * A) + j] = s;
+        a.head_part[((int64_t)blockIdx.x * M + m0 + row) * HN + j] = s;
     }
     // ---- global stores, all behind the last barrier ----
-    if (wave < T && tile_ok && a.a_h2 && m0 < B) {  // the pi(obs) rows' activations, kept for the backward
+    const bool keep_rows = mode == CSTR_CHAIN_ROWS_OBS || (mode == CSTR_CHAIN_ROWS_PAIR && m0 < B);  // the rows a backward follows
+    if (wave < T && col_ok && a.a_h2 && keep_rows) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) a.a_h2[(int64_t)(m0 + 4 * h + e) * H2 + n0 + r] = hv[e];
     }
-    if (blockIdx.x == 0 && a.a_h1 && m0 < B) store_panel(panel, ld, a.a_h1, H1, m0);
+    if (blockIdx.x == 0 && a.a_h1 && keep_rows) store_panel(panel, ld, a.a_h1, H1, m0);
     if (noise) {
         const int row = lane / PAIRS, pr = lane % PAIRS;
         float *eo = a.eps_all + (int64_t)(m0 + row) * A + 2 * pr;
@@ -339,7 +349,14 @@ __global__ __launch_bounds__(CH_THREADS) void sac_actor_chain_fwd_kernel(const A
         const int qd = t % QPR;
         float *xo = (next ? a.x_next : a.x_pi) + (int64_t)b * W + 4 * qd;
         reinterpret_cast<float2 *>(xo)[0] = make_float2(v.x, v.y); reinterpret_cast<float2 *>(xo)[1] = make_float2(v.z, v.w);
-        if (!next) {
+        if (data_row && next) {  // a next_obs-only pass: this row's observation goes to x_data and x_pi as well
+            if (a.x_pi) {
+                float *xp = a.x_pi + (int64_t)b * W + 4 * qd;
+                reinterpret_cast<float2 *>(xp)[0] = make_float2(vo.x, vo.y); reinterpret_cast<float2 *>(xp)[1] = make_float2(vo.z, vo.w);
+            }
+            v = vo;
+        }
+        if (!next || data_row) {
             float *xd = a.x_data + (int64_t)b * W;
             reinterpret_cast<float2 *>(xd + 4 * qd)[0] = make_float2(v.x, v.y); reinterpret_cast<float2 *>(xd + 4 * qd)[1] = make_float2(v.z, v.w);
             if (qd == 0) {
@@ -380,42 +397,54 @@ __global__ __launch_bounds__(CH_THREADS) void q_chain_fwd_kernel(const QFwdArgs 
     float *xs = smem + SM_XS, *red = smem + SM_RED, *panel = smem + SM_PANEL;
     const int ld = H1 + 4;
     float *w1s = panel + 16 * ld;
-    const bool tile_ok = n0 < H2;
+    const bool col_ok = n0 + r < H2;
     // (a) requests that depend on nothing
     float4 bq[NQ];
     load_b_fwd<NQ>(bq, net.w2, H2, H1, n0, ks, S);
     const int col = min(n0 + r, H2 - 1);
     const float bv = net.b2[col];
-    const float w3v = net.w3[col];
+    const float w3v = col_ok ? net.w3[col] : 0.0f;
     stage_w1<W>(w1s, net.w1, net.b1, H1);
     const int role = a.has_fin ? net.role : CSTR_CHAIN_ROLE_PLAIN;
     // (b) input rows (16 floats per row in LDS: the inputs, 1.0 = the bias input, zeros); with a pending actor head the action columns
     //     of the pi(next_obs) rows are finalised HERE (every workgroup of the row group for itself: a lane per (row, action)), and the
     //     column-group-0 workgroups store what later launches need
-    const bool nxt = role >= CSTR_CHAIN_ROLE_NEXT;
+    // NEXT / NEXT_STORE: the network reads x_next whose action columns are finalised here; PI: the same for x_pi; STORE_PI: the input
+    // is complete and the column-group-0 workgroups finalise the pi(obs) rows as a side job
+    const bool nxt = role == CSTR_CHAIN_ROLE_NEXT || role == CSTR_CHAIN_ROLE_NEXT_STORE;
+    const bool own = nxt || role == CSTR_CHAIN_ROLE_PI;  // the finalised actions are this network's own input columns
     {
         const int row = t >> 4, k = t & 15;  // 256 threads = 16 x 16
         float xv = k == W ? 1.0f : 0.0f;
-        if (k < W && !(nxt && k >= D)) xv = net.x[(int64_t)(m0 + row) * W + k];
-        if (!(nxt && k >= D && k < W)) xs[row * 16 + k] = xv;
+        if (k < W && !(own && k >= D)) xv = net.x[(int64_t)(m0 + row) * W + k];
+        if (!(own && k >= D && k < W)) xs[row * 16 + k] = xv;
     }
-    const bool fin_rows = nxt || (role == CSTR_CHAIN_ROLE_STORE_PI && blockIdx.x == 0);
+    const bool fin_rows = own || (role == CSTR_CHAIN_ROLE_STORE_PI && blockIdx.x == 0);
     const bool fin_lane = fin_rows && t < 16 * A;  // a lane per (row, action) in wave 0
     float f_mu = 0.0f, f_raw = 0.0f, f_a = 0.0f, f_lp = 0.0f;
     const int f_row = t / A, f_j = t % A;
     if (fin_lane) {
-        const int64_t i = (nxt ? B : 0) + m0 + f_row;  // row of the 2B-row actor pass
-        const int64_t pstride = (int64_t)2 * B * 2 * A, ptotal = pstride * a.fin.n_parts;
-        const float ev = a.fin.eps[i * A + f_j], hb_mu = a.fin.hb[f_j], hb_raw = a.fin.hb[A + f_j];
-        f_mu = sum_parts(a.fin.head_part, a.fin.n_parts, pstride, i * (2 * A) + f_j, ptotal) + hb_mu;
-        f_raw = sum_parts(a.fin.head_part, a.fin.n_parts, pstride, i * (2 * A) + A + f_j, ptotal) + hb_raw;
-        float term;
-        sample_action(f_mu, f_raw, ev, f_a, term);
-        // log-prob of the row = sum of its actions' terms: the A lanes of a row are adjacent
-        f_lp = term;
-        if (A >= 2) f_lp += __shfl_xor(f_lp, 1, 64);
-        if (A == 4) f_lp += __shfl_xor(f_lp, 2, 64);
-        if (nxt) xs[f_row * 16 + D + f_j] = f_a;
+        const bool det = a.fin.kind == CSTR_CHAIN_HEAD_DETERMINISTIC;
+        const int HN = det ? A : 2 * A;
+        const int64_t i = (nxt ? a.fin.next_offset : 0) + m0 + f_row;  // row of the actor pass
+        const int64_t pstride = (int64_t)a.fin.part_rows * HN, ptotal = pstride * a.fin.n_parts;
+        const float ev = a.fin.eps ? a.fin.eps[i * A + f_j] : 0.0f, hb_mu = a.fin.hb[f_j], hb_raw = det ? 0.0f : a.fin.hb[A + f_j];
+        f_mu = sum_parts(a.fin.head_part, a.fin.n_parts, pstride, i * HN + f_j, ptotal) + hb_mu;
+        if (det) {
+            // deterministic actor (core/td3/policies.py:57-83): a = tanh(.); target actions get the clipped smoothing noise
+            // (core/td3/td3.py:167-171; target_smooth_kernel's expressions)
+            f_a = tanhf(f_mu);
+            if (nxt) f_a = fminf(fmaxf(f_a + fminf(fmaxf(ev * a.fin.sigma, -a.fin.clip), a.fin.clip), -1.0f), 1.0f);
+        } else {
+            f_raw = sum_parts(a.fin.head_part, a.fin.n_parts, pstride, i * HN + A + f_j, ptotal) + hb_raw;
+            float term;
+            sample_action(f_mu, f_raw, ev, f_a, term);
+            // log-prob of the row = sum of its actions' terms: the A lanes of a row are adjacent
+            f_lp = term;
+            if (A >= 2) f_lp += __shfl_xor(f_lp, 1, 64);
+            if (A == 4) f_lp += __shfl_xor(f_lp, 2, 64);
+        }
+        if (own) xs[f_row * 16 + D + f_j] = f_a;
     }
     lds_barrier();
     // (c) layer 1 recomputed on the matrix cores
@@ -427,7 +456,7 @@ __global__ __launch_bounds__(CH_THREADS) void q_chain_fwd_kernel(const QFwdArgs 
     if (wave < T) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            hv[e] = tile_ok ? fmaxf(acc[e] + bv, 0.0f) : 0.0f;
+            hv[e] = col_ok ? fmaxf(acc[e] + bv, 0.0f) : 0.0f;
 #ifdef CSTR_HEAD_F64  // experiment: the head's dot product over the workgroup's columns accumulated in f64
             double sd = (double)hv[e] * (double)w3v;
             sd += __shfl_xor(sd, 8, 64); sd += __shfl_xor(sd, 4, 64); sd += __shfl_xor(sd, 2, 64); sd += __shfl_xor(sd, 1, 64);
@@ -445,19 +474,20 @@ __global__ __launch_bounds__(CH_THREADS) void q_chain_fwd_kernel(const QFwdArgs 
         net.q_part[(int64_t)blockIdx.x * B + m0 + t] = s;
     }
     // ---- global stores, all behind the last barrier ----
-    if (wave < T && tile_ok && net.h2) {
+    if (wave < T && col_ok && net.h2) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) net.h2[(int64_t)(m0 + 4 * h + e) * H2 + n0 + r] = hv[e];
     }
     if (blockIdx.x == 0 && net.h1) store_panel(panel, ld, net.h1, H1, m0);
     if (fin_lane && blockIdx.x == 0 && role != CSTR_CHAIN_ROLE_NEXT) {
         const int bb = m0 + f_row;
+        const bool det = a.fin.kind == CSTR_CHAIN_HEAD_DETERMINISTIC;
         (nxt ? a.fin.x_next : a.fin.x_pi)[(int64_t)bb * W + D + f_j] = f_a;
-        if (!nxt) {
+        if (!nxt && !det) {
             a.fin.params[(int64_t)bb * 2 * A + f_j] = f_mu;
             a.fin.params[(int64_t)bb * 2 * A + A + f_j] = f_raw;
         }
-        if (f_j == 0) (nxt ? a.fin.logp_next : a.fin.logp_pi)[bb] = f_lp;
+        if (f_j == 0 && !det) (nxt ? a.fin.logp_next : a.fin.logp_pi)[bb] = f_lp;
     }
 }
 
@@ -574,7 +604,7 @@ __global__ __launch_bounds__(CH_THREADS) void q_chain_bwd_kernel(const QBwdArgs 
     const int T = a.tiles, S = CH_WAVES / T, tile = wave % T, ks = wave / T;
     const cstr_chain_net_t &net = a.nets[g];
     const int k0 = (blockIdx.x * T + tile) * 16, m0 = blockIdx.y * 16;
-    const bool tile_ok = k0 < H1;
+    const bool col_ok = k0 + r < H1;
     const int col = min(k0 + r, H1 - 1);
     float *red = smem + SM_RED, *gs = smem + SM_GS, *panel = smem + SM_PANEL;
     const int ld = H2 + 4;
@@ -655,7 +685,7 @@ __global__ __launch_bounds__(CH_THREADS) void q_chain_bwd_kernel(const QBwdArgs 
     float d[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     if (wave < T) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) d[e] = (tile_ok && ty[e] > 0.0f) ? acc[e] : 0.0f;
+        for (int e = 0; e < 4; ++e) d[e] = (col_ok && ty[e] > 0.0f) ? acc[e] : 0.0f;
         if (a.gact_part) {
 #pragma unroll
             for (int j = 0; j < A; ++j) {
@@ -677,7 +707,7 @@ __global__ __launch_bounds__(CH_THREADS) void q_chain_bwd_kernel(const QBwdArgs 
         }
     }
     // ---- global stores, all behind the last barrier ----
-    if (a.dz1 && wave < T && tile_ok) {
+    if (a.dz1 && wave < T && col_ok) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) a.dz1[((int64_t)g * B + m0 + 4 * h + e) * H1 + k0 + r] = d[e];
     }
@@ -706,7 +736,7 @@ struct ActorBwdArgs {
     const float *gact_part; int n_nets, n_parts; const float *ent_coef;
     const float *x_pi, *params, *eps, *a_h1, *a_h2;
     float *g_params, *dz2, *dz1;
-    int batch, tiles;
+    int batch, tiles, kind;  // CSTR_CHAIN_HEAD_*
 };
 
 template <int D, int A, int NQ>
@@ -718,8 +748,8 @@ __global__ __launch_bounds__(CH_THREADS) void sac_actor_chain_bwd_kernel(const A
     const int T = a.tiles, S = CH_WAVES / T, tile = wave % T, ks = wave / T;
     const int H1 = a.net.h1, H2 = a.net.h2, B = a.batch;
     const int k0 = (blockIdx.x * T + tile) * 16, m0 = blockIdx.y * 16;
-    const bool tile_ok = k0 < H1;
-    const int col = min(k0 + r, H1 - 1);
+    const bool col_ok = k0 + r < H1, det = a.kind == CSTR_CHAIN_HEAD_DETERMINISTIC;
+    const int col = min(k0 + r, H1 - 1), HN = det ? A : 2 * A;
     float *gs = smem + SM_GS, *panel = smem + SM_PANEL;
     const int ld = H2 + 4;
     float4 bq[NQ];
@@ -732,40 +762,48 @@ __global__ __launch_bounds__(CH_THREADS) void sac_actor_chain_bwd_kernel(const A
     float o_gu = 0.0f, o_gls = 0.0f;
     if (t < 16 * A) {
         const int row = t / A, j = t % A, b = m0 + row;
-        const float ecv = a.ent_coef[0], av = a.x_pi[(int64_t)b * W + D + j], raw = a.params[(int64_t)b * 2 * A + A + j];
-        const float epv = a.eps[(int64_t)b * A + j];
+        const float av = a.x_pi[(int64_t)b * W + D + j];
+        const float ecv = det ? 0.0f : a.ent_coef[0], raw = det ? 0.0f : a.params[(int64_t)b * 2 * A + A + j];
+        const float epv = det ? 0.0f : a.eps[(int64_t)b * A + j];
         // networks x column groups are ONE run of partials (stride B * A): summed in (network, group) order
         const int np = a.n_nets * a.n_parts;
         const float ga = sum_parts(a.gact_part, np, (int64_t)B * A, (int64_t)b * A + j, (int64_t)np * B * A);
-        const float gl = ecv * (1.0f / (float)B);  // d(loss)/d(logp) (sac_actor_loss_kernel)
-        const float s = expf(fminf(fmaxf(raw, LOG_STD_MIN), LOG_STD_MAX));
         const float one_m = 1.0f - av * av;
-        o_gu = ga * one_m + gl * (2.0f * av * one_m / (one_m + 1e-6f));
-        o_gls = (raw >= LOG_STD_MIN && raw <= LOG_STD_MAX) ? o_gu * epv * s - gl : 0.0f;
+        if (det) {  // a = tanh(z): d/dz = d/da * (1 - a^2)   (bias_act_bwd's tanh expression)
+            o_gu = ga * one_m;
+        } else {
+            const float gl = ecv * (1.0f / (float)B);  // d(loss)/d(logp) (sac_actor_loss_kernel)
+            const float s = expf(fminf(fmaxf(raw, LOG_STD_MIN), LOG_STD_MAX));
+            o_gu = ga * one_m + gl * (2.0f * av * one_m / (one_m + 1e-6f));
+            o_gls = (raw >= LOG_STD_MIN && raw <= LOG_STD_MAX) ? o_gu * epv * s - gl : 0.0f;
+        }
         gs[row * 8 + j] = o_gu;
-        gs[row * 8 + A + j] = o_gls;
+        gs[row * 8 + A + j] = o_gls;  // (deterministic head: zero -- the k chunk of the dz2 MFMA is 4 wide)
     }
     lds_barrier();
     // (c) dz2 = (g_params hw) * relu'(a_h2) on the matrix cores: K = 2A is one (A = 2) or two (A = 4) MFMA steps per 16 x 16 tile;
     //     A operand = g_params[r][h] (LDS), B operand = hw[h][column] straight from L2; the wave takes the tiles wave, wave + 4, ...
     {
-        const float ga0 = gs[r * 8 + h], ga1 = A == 4 ? gs[r * 8 + 4 + h] : 0.0f;
+        const bool two = HN > 4;  // 8 head outputs: two k steps
+        const float ga0 = gs[r * 8 + h], ga1 = two ? gs[r * 8 + 4 + h] : 0.0f;
         const int cpg = (H2 + gridDim.x - 1) / gridDim.x;
-        for (int tl = wave; tl < H2 / 16; tl += CH_WAVES) {
-            const int c = 16 * tl + r;
-            const float hb0 = a.net.hw[(int64_t)h * H2 + c], hb1 = A == 4 ? a.net.hw[(int64_t)(4 + h) * H2 + c] : 0.0f;
+        for (int tl = wave; tl < (H2 + 15) / 16; tl += CH_WAVES) {
+            const int c = 16 * tl + r, cc = min(c, H2 - 1);
+            const float hb0 = h < HN ? a.net.hw[(int64_t)h * H2 + cc] : 0.0f, hb1 = two ? a.net.hw[(int64_t)(4 + h) * H2 + cc] : 0.0f;
             float m[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) m[e] = a.a_h2[(int64_t)(m0 + 4 * h + e) * H2 + c];
+            for (int e = 0; e < 4; ++e) m[e] = a.a_h2[(int64_t)(m0 + 4 * h + e) * H2 + cc];
             f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ga0, hb0, acc, 0, 0, 0);
-            if (A == 4) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ga1, hb1, acc, 0, 0, 0);
+            if (two) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ga1, hb1, acc, 0, 0, 0);
             const bool mine = c / cpg == (int)blockIdx.x;  // this workgroup's share of the dz2 columns (stored now: nothing waits for it)
+            if (c < H2) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float dv = m[e] > 0.0f ? acc[e] : 0.0f;
-                panel[(4 * h + e) * ld + c] = dv;
-                if (mine) a.dz2[(int64_t)(m0 + 4 * h + e) * H2 + c] = dv;
+                for (int e = 0; e < 4; ++e) {
+                    const float dv = m[e] > 0.0f ? acc[e] : 0.0f;
+                    panel[(4 * h + e) * ld + c] = dv;
+                    if (mine) a.dz2[(int64_t)(m0 + 4 * h + e) * H2 + c] = dv;
+                }
             }
         }
     }
@@ -773,14 +811,14 @@ __global__ __launch_bounds__(CH_THREADS) void sac_actor_chain_bwd_kernel(const A
     f32x4 acc = tile_mma<NQ>(panel, ld, H2, bq, ks, S);
     acc = combine_split_k(acc, smem, T, S);
     // ---- global stores ----
-    if (wave < T && tile_ok) {
+    if (wave < T && col_ok) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) a.dz1[(int64_t)(m0 + 4 * h + e) * H1 + k0 + r] = ty[e] > 0.0f ? acc[e] : 0.0f;
     }
     if (t < 16 * A && blockIdx.x == 0) {
         const int row = t / A, j = t % A, b = m0 + row;
-        a.g_params[(int64_t)b * 2 * A + j] = o_gu;
-        a.g_params[(int64_t)b * 2 * A + A + j] = o_gls;
+        a.g_params[(int64_t)b * HN + j] = o_gu;
+        if (!det) a.g_params[(int64_t)b * HN + A + j] = o_gls;
     }
 }
 
@@ -793,7 +831,7 @@ static int nq_for(int kdim, int tiles)
 
 static bool chain_dims_ok(int h1, int h2, int64_t batch, int tiles)
 {
-    return h1 >= 16 && h2 >= 16 && h1 <= CSTR_CHAIN_MAX_WIDTH && h2 <= CSTR_CHAIN_MAX_WIDTH && h1 % 16 == 0 && h2 % 16 == 0 && batch >= 16 &&
+    return h1 >= 16 && h2 >= 16 && h1 <= CSTR_CHAIN_MAX_WIDTH && h2 <= CSTR_CHAIN_MAX_WIDTH && h1 % 4 == 0 && h2 % 4 == 0 && batch >= 16 &&
            batch <= 1024 && batch % 16 == 0 && (tiles == 1 || tiles == 2 || tiles == 4);
 }
 
@@ -832,14 +870,16 @@ static int check_actor(const cstr_sac_actor_t *n)
 extern "C" int cstr_sac_actor_chain_fwd_f32(const cstr_sac_actor_t *actor, const cstr_ring_t *ring, int64_t *ring_ctl, int advance_ring,
                                             const int32_t *sample_idx, int64_t batch, float *x_data, float *x_pi, float *x_next,
                                             float *out_done, float *out_rew, float *a_h1, float *a_h2, float *head_part,
-                                            const uint64_t *head_rng_ctl, uint64_t head_rng_offset, float *eps_all, int tiles,
-                                            cstr_stream_t stream)
+                                            const uint64_t *head_rng_ctl, uint64_t head_rng_offset, float *eps_all, int rows_mode,
+                                            int head_n, int tiles, cstr_stream_t stream)
 {
     const int rc = check_actor(actor);
     if (rc) return rc;
-    if (!x_pi || !x_next || !head_part || (eps_all && !head_rng_ctl)) return CSTR_E_BADARG;
+    if (!head_part || (eps_all && !head_rng_ctl)) return CSTR_E_BADARG;
+    if (rows_mode < CSTR_CHAIN_ROWS_PAIR || rows_mode > CSTR_CHAIN_ROWS_OBS || (head_n != actor->act_dim && head_n != 2 * actor->act_dim)) return CSTR_E_BADARG;
+    if ((rows_mode != CSTR_CHAIN_ROWS_OBS && !x_next) || (rows_mode != CSTR_CHAIN_ROWS_NEXT && !x_pi)) return CSTR_E_BADARG;
     if (!chain_dims_ok(actor->h1, actor->h2, batch, tiles)) return CSTR_E_UNSUPPORTED;
-    if (!aligned8(x_pi) || !aligned8(x_next)) return CSTR_E_BADARG;
+    if ((x_pi && !aligned8(x_pi)) || (x_next && !aligned8(x_next))) return CSTR_E_BADARG;
     ActorFwdArgs a = {};
     a.net = *actor;
     if (sample_idx) {
@@ -855,7 +895,8 @@ extern "C" int cstr_sac_actor_chain_fwd_f32(const cstr_sac_actor_t *actor, const
     a.idx = sample_idx; a.batch = (int)batch; a.tiles = tiles;
     a.x_data = x_data; a.x_pi = x_pi; a.x_next = x_next; a.out_done = out_done; a.out_rew = out_rew;
     a.a_h1 = a_h1; a.a_h2 = a_h2; a.head_part = head_part; a.head_rng_ctl = head_rng_ctl; a.head_rng_offset = head_rng_offset; a.eps_all = eps_all;
-    const dim3 grid((unsigned)((actor->h2 + 16 * tiles - 1) / (16 * tiles)), (unsigned)(2 * batch / 16));
+    a.rows_mode = rows_mode; a.head_n = head_n;
+    const dim3 grid((unsigned)((actor->h2 + 16 * tiles - 1) / (16 * tiles)), (unsigned)((rows_mode == CSTR_CHAIN_ROWS_PAIR ? 2 : 1) * batch / 16));
     const size_t lds = chain_lds_bytes(actor->h1, true);
     const int nq = nq_for(actor->h1, tiles), lay = chain_layout(actor->obs_dim, actor->act_dim);
     if (!nq || lds > CHAIN_LDS_LIMIT) return CSTR_E_UNSUPPORTED;
@@ -873,13 +914,21 @@ extern "C" int cstr_q_chain_fwd_f32(const cstr_chain_net_t *nets, int n_nets, in
     for (int g = 0; g < n_nets; ++g) {
         const cstr_chain_net_t &n = nets[g];
         if (!n.w1 || !n.b1 || !n.w2 || !n.b2 || !n.w3 || !n.b3 || !n.x || !n.q_part || !aligned16(n.w2)) return CSTR_E_BADARG;
-        if (n.role < 0 || n.role > 3 || (n.role != 0 && !fin)) return CSTR_E_BADARG;
+        if (n.role < 0 || n.role > CSTR_CHAIN_ROLE_PI || (n.role != 0 && !fin)) return CSTR_E_BADARG;
         a.nets[g] = n;
     }
     if (fin) {
         if (!fin->head_part || !fin->hb || fin->n_parts < 1 || fin->act_dim < 1 || fin->act_dim > MAX_A || fin->obs_dim != obs_dim || fin->obs_dim + fin->act_dim != w_in)
             return CSTR_E_BADARG;
-        if (!fin->eps || !fin->x_pi || !fin->x_next || !fin->params || !fin->logp_pi || !fin->logp_next) return CSTR_E_BADARG;
+        const bool det = fin->kind == CSTR_CHAIN_HEAD_DETERMINISTIC;
+        if (fin->kind != CSTR_CHAIN_HEAD_GAUSSIAN && !det) return CSTR_E_BADARG;
+        if (fin->part_rows < batch || fin->next_offset < 0 || fin->next_offset + batch > fin->part_rows) return CSTR_E_BADARG;
+        if (!det && (!fin->eps || !fin->x_pi || !fin->x_next || !fin->params || !fin->logp_pi || !fin->logp_next)) return CSTR_E_BADARG;
+        for (int g = 0; g < n_nets; ++g) {  // the buffers the roles in use write
+            const int role = nets[g].role;
+            if ((role == CSTR_CHAIN_ROLE_NEXT_STORE && !fin->x_next) || ((role == CSTR_CHAIN_ROLE_STORE_PI || role == CSTR_CHAIN_ROLE_PI) && !fin->x_pi))
+                return CSTR_E_BADARG;
+        }
         a.fin = *fin;
         a.has_fin = 1;
     }
@@ -926,19 +975,20 @@ extern "C" int cstr_q_chain_bwd_f32(const cstr_chain_net_t *nets, int n_nets, co
 
 extern "C" int cstr_sac_actor_chain_bwd_f32(const cstr_sac_actor_t *actor, const float *gact_part, int n_nets, int n_parts,
                                             const float *ent_coef, const float *x_pi, const float *params, const float *eps, const float *a_h1,
-                                            const float *a_h2, float *g_params, float *dz2, float *dz1, int64_t batch, int tiles,
+                                            const float *a_h2, float *g_params, float *dz2, float *dz1, int64_t batch, int kind, int tiles,
                                             cstr_stream_t stream)
 {
     const int rc = check_actor(actor);
     if (rc) return rc;
-    if (!gact_part || n_nets < 1 || n_nets > 2 || n_parts < 1 || !ent_coef || !x_pi || !params || !eps || !a_h1 || !a_h2 || !g_params || !dz2 || !dz1)
-        return CSTR_E_BADARG;
+    if (kind != CSTR_CHAIN_HEAD_GAUSSIAN && kind != CSTR_CHAIN_HEAD_DETERMINISTIC) return CSTR_E_BADARG;
+    if (!gact_part || n_nets < 1 || n_nets > 2 || n_parts < 1 || !x_pi || !a_h1 || !a_h2 || !g_params || !dz2 || !dz1) return CSTR_E_BADARG;
+    if (kind == CSTR_CHAIN_HEAD_GAUSSIAN && (!ent_coef || !params || !eps)) return CSTR_E_BADARG;
     if (!chain_dims_ok(actor->h1, actor->h2, batch, tiles)) return CSTR_E_UNSUPPORTED;
     ActorBwdArgs a = {};
     a.net = *actor;
     a.gact_part = gact_part; a.n_nets = n_nets; a.n_parts = n_parts; a.ent_coef = ent_coef;
     a.x_pi = x_pi; a.params = params; a.eps = eps; a.a_h1 = a_h1; a.a_h2 = a_h2;
-    a.g_params = g_params; a.dz2 = dz2; a.dz1 = dz1; a.batch = (int)batch; a.tiles = tiles;
+    a.g_params = g_params; a.dz2 = dz2; a.dz1 = dz1; a.batch = (int)batch; a.tiles = tiles; a.kind = kind;
     const dim3 grid((unsigned)((actor->h1 + 16 * tiles - 1) / (16 * tiles)), (unsigned)(batch / 16));
     const size_t lds = chain_lds_bytes(actor->h2, false);
     const int nq = nq_for(actor->h2, tiles), lay = chain_layout(actor->obs_dim, actor->act_dim);

@@ -530,20 +530,22 @@ __global__ __launch_bounds__(64 * WAVES) void linear_bwd_input_kernel(const floa
 struct AdamTile {
     float *w, *w_m, *w_v, *b, *b_m, *b_v, *shadow;
     const int64_t *adam_ctl; const double *lr; double beta1, beta2, eps; float gscale;
+    float *w_target, *b_target; float tau;  // soft update of these parameters' own target with the values just computed, or NULL
 };
 
 template <int WAVES, bool BUF = false, bool ADAM = false>
 __device__ __forceinline__ void linear_bwd_weight_tile(const float *__restrict__ dz, const float *__restrict__ x, const int ldx,
                                                        float *__restrict__ dw, float *__restrict__ db, const int M, const int N,
-                                                       const int K, const int64_t g, const AdamTile *ad = nullptr)
+                                                       const int K, const int64_t g, const AdamTile *ad = nullptr,
+                                                       const int tile_k = blockIdx.x, const int tile_n = blockIdx.y)
 {
     __shared__ f32x4 part[WAVES > 1 ? WAVES - 1 : 1][64];
     __shared__ float colpart[WAVES][64];
     __shared__ AdamScalars adam_sc;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, h = lane >> 4;
-    const int k0 = blockIdx.x * 16, n0 = blockIdx.y * 16;
+    const int k0 = tile_k * 16, n0 = tile_n * 16;
     const bool n_ok = n0 + r < N, k_ok = k0 + r < K;
-    const bool want_db = db != nullptr && blockIdx.x == 0;
+    const bool want_db = db != nullptr && tile_k == 0;
     float pw[4] = {0.0f, 0.0f, 0.0f, 0.0f}, pm[4] = {0.0f, 0.0f, 0.0f, 0.0f}, pv[4] = {0.0f, 0.0f, 0.0f, 0.0f}, bw = 0.0f, bm = 0.0f, bvv = 0.0f;
     if (ADAM) {
         if (wave == 0 && k_ok) {
@@ -627,6 +629,7 @@ __device__ __forceinline__ void linear_bwd_weight_tile(const float *__restrict__
                     const int64_t i = (int64_t)row * K + colk;
                     adam1(pw[e], acc[e], pm[e], pv[e], a);
                     ad->w[i] = pw[e]; ad->w_m[i] = pm[e]; ad->w_v[i] = pv[e];
+                    if (ad->w_target) ad->w_target[i] = polyak1(pw[e], ad->w_target[i], ad->tau, 1.0f - ad->tau);
                     if (ad->shadow)  // the tile-major copy the rollout kernel reads (cstr_policy_swizzle_f32's layout)
                         ad->shadow[(((int64_t)(row >> 4) * ((K + 15) >> 4) + (colk >> 4)) * 64 + (row & 15) + 16 * ((colk & 15) >> 2)) * 4 + (colk & 3)] = pw[e];
                 }
@@ -641,6 +644,7 @@ __device__ __forceinline__ void linear_bwd_weight_tile(const float *__restrict__
         if (ADAM) {
             adam1(bw, sum, bm, bvv, adam_sc);
             ad->b[n0 + lane] = bw; ad->b_m[n0 + lane] = bm; ad->b_v[n0 + lane] = bvv;
+            if (ad->b_target) ad->b_target[n0 + lane] = polyak1(bw, ad->b_target[n0 + lane], ad->tau, 1.0f - ad->tau);
         }
     }
 }
@@ -671,30 +675,37 @@ __global__ __launch_bounds__(64 * WAVES) void linear_bwd_weight_sets_kernel(cons
 // z < n_sets reduce one Linear's dW / db tile and update exactly those parameters; slices z >= n_sets are flat segments
 // (cstr_adam_seg_t: parameters without a weight-gradient tile -- SAC's entropy coefficient -- and soft target updates). Step counters
 // are pre-advanced by an earlier launch (cstr_chain_root_t.adam_advance): no control word is written here, no ticket.
+// The grid is ONE dimension of exactly the workgroups that have work: `first[i]` = first workgroup of slice i (sets, then flat
+// segments), first[n_sets + n_flat] = grid size; a set's workgroups walk its tiles k-major.
 struct WgradAdamSets {
     cstr_wgrad_adam_set_t s[CSTR_MAX_LINEAR_SETS];
     cstr_adam_opt_t o[CSTR_MAX_ADAM_SEGS];
     cstr_adam_seg_t f[CSTR_MAX_ADAM_SEGS];
-    int n_sets;
+    int first[CSTR_MAX_LINEAR_SETS + CSTR_MAX_ADAM_SEGS + 1];
+    int n_sets, n_flat;
 };
 
 template <int WAVES, bool BUF>
 __global__ __launch_bounds__(64 * WAVES) void linear_bwd_weight_adam_sets_kernel(const WgradAdamSets sets)
 {
-    if ((int)blockIdx.z >= sets.n_sets) {
-        const cstr_adam_seg_t &f = sets.f[blockIdx.z - sets.n_sets];
-        const int64_t bid = blockIdx.y * (int64_t)gridDim.x + blockIdx.x, nblk = (int64_t)gridDim.x * gridDim.y;
-        if (f.polyak_source) { polyak_body(f.polyak_source, f.param, (float)f.tau, (float)(1.0 - f.tau), f.n, bid, nblk); return; }
-        if (bid * (int64_t)blockDim.x * 4 >= ((f.n + 3) & ~(int64_t)3)) return;  // small segments: the workgroups with nothing to do leave at once
+    const int b = blockIdx.x, n_slices = sets.n_sets + sets.n_flat;
+    int i = 0;
+    while (i + 1 < n_slices && b >= sets.first[i + 1]) ++i;  // (uniform: a handful of scalar compares)
+    const int local = b - sets.first[i], count = sets.first[i + 1] - sets.first[i];
+    if (i >= sets.n_sets) {
+        const cstr_adam_seg_t &f = sets.f[i - sets.n_sets];
+        if (f.polyak_source) { polyak_body(f.polyak_source, f.param, (float)f.tau, (float)(1.0 - f.tau), f.n, local, count); return; }
         adam_body(f.param, f.grad, f.exp_avg, f.exp_avg_sq, f.adam_ctl, f.lr, f.beta1, f.beta2, f.eps, f.grad_scale, f.n, AdamShadow{nullptr, 0, 0, 4, 1},
-                  f.own_target, (float)f.tau, (float)(1.0 - f.tau), true, bid, nblk);
+                  f.own_target, (float)f.tau, (float)(1.0 - f.tau), true, local, count);
         return;
     }
-    const cstr_wgrad_adam_set_t &q = sets.s[blockIdx.z];
-    if ((int64_t)blockIdx.x * 16 >= q.g.k || (int64_t)blockIdx.y * 16 >= q.g.n) return;  // the grid covers the largest set
+    const cstr_wgrad_adam_set_t &q = sets.s[i];
+    const int kt = (int)((q.g.k + 15) >> 4);
     const cstr_adam_opt_t &o = sets.o[q.opt];
-    const AdamTile ad = {q.w, q.w_m, q.w_v, q.b, q.b_m, q.b_v, q.shadow, o.adam_ctl, o.lr, o.beta1, o.beta2, o.eps, o.grad_scale};
-    linear_bwd_weight_tile<WAVES, BUF, true>(q.g.dz, q.g.x, (int)q.g.ldx, q.g.dw, q.g.db, (int)q.g.m, (int)q.g.n, (int)q.g.k, 0, &ad);
+    const AdamTile ad = {q.w, q.w_m, q.w_v, q.b, q.b_m, q.b_v, q.shadow, o.adam_ctl, o.lr, o.beta1, o.beta2, o.eps, o.grad_scale,
+                         q.w_target, q.b_target, q.tau};
+    linear_bwd_weight_tile<WAVES, BUF, true>(q.g.dz, q.g.x, (int)q.g.ldx, q.g.dw, q.g.db, (int)q.g.m, (int)q.g.n, (int)q.g.k, 0, &ad, local % kt,
+                                             local / kt);
 }
 
 // ---- last hidden layer + scalar head of a Q network ------------------------------------------------------------
@@ -2707,7 +2718,8 @@ extern "C" int cstr_linear_bwd_weight_adam_sets_f32(const cstr_wgrad_adam_set_t 
     if (n_sets > CSTR_MAX_LINEAR_SETS || n_opts > CSTR_MAX_ADAM_SEGS || n_flat > CSTR_MAX_ADAM_SEGS) return CSTR_E_UNSUPPORTED;
     WgradAdamSets t;
     t.n_sets = n_sets;
-    int64_t kt = 1, nt = 1;
+    t.n_flat = n_flat;
+    int64_t total = 0;
     for (int i = 0; i < n_opts; ++i) {
         if (!opts[i].adam_ctl || !opts[i].lr) return CSTR_E_BADARG;
         t.o[i] = opts[i];
@@ -2716,9 +2728,10 @@ extern "C" int cstr_linear_bwd_weight_adam_sets_f32(const cstr_wgrad_adam_set_t 
         const cstr_wgrad_adam_set_t &q = sets[i];
         if (!q.g.dz || !q.g.x || !q.g.dw || q.g.m <= 32 || q.g.n <= 0 || q.g.k <= 0 || q.g.ldx < q.g.k) return CSTR_E_BADARG;
         if (!q.w || !q.w_m || !q.w_v || q.opt < 0 || q.opt >= n_opts || (q.g.db && (!q.b || !q.b_m || !q.b_v))) return CSTR_E_BADARG;
+        if ((q.w_target != nullptr) != (q.b_target != nullptr && q.g.db != nullptr) && q.g.db) return CSTR_E_BADARG;
         if (q.g.m * q.g.n >= (1 << 28) || q.g.m * q.g.ldx >= (1 << 28) || (q.g.n + 15) / 16 > 65535) return CSTR_E_UNSUPPORTED;
-        kt = kt > (q.g.k + 15) / 16 ? kt : (q.g.k + 15) / 16;
-        nt = nt > (q.g.n + 15) / 16 ? nt : (q.g.n + 15) / 16;
+        t.first[i] = (int)total;
+        total += ((q.g.k + 15) / 16) * ((q.g.n + 15) / 16);
         t.s[i] = q;
     }
     for (int i = 0; i < n_flat; ++i) {
@@ -2727,10 +2740,14 @@ extern "C" int cstr_linear_bwd_weight_adam_sets_f32(const cstr_wgrad_adam_set_t 
         if (!f.polyak_source && (!f.grad || !f.exp_avg || !f.exp_avg_sq || !f.adam_ctl || !f.lr)) return CSTR_E_BADARG;
         if (f.shadow) return CSTR_E_UNSUPPORTED;  // a shadowed matrix is updated by its weight-gradient tiles
         if (!aligned16(f.param) || (f.polyak_source && !aligned16(f.polyak_source))) return CSTR_E_BADARG;
+        t.first[n_sets + i] = (int)total;
+        int64_t wgs = ((f.n + 3) / 4 + 255) / 256;  // one 16-byte quad per lane
+        total += wgs < 1 ? 1 : (wgs > 256 ? 256 : wgs);
         t.f[i] = f;
     }
-    const dim3 grid((unsigned)kt, (unsigned)nt, (unsigned)(n_sets + n_flat));
-    linear_bwd_weight_adam_sets_kernel<4, true><<<grid, 256, 0, (hipStream_t)stream>>>(t);
+    t.first[n_sets + n_flat] = (int)total;
+    if (total > 0x7fffffff) return CSTR_E_UNSUPPORTED;
+    linear_bwd_weight_adam_sets_kernel<4, true><<<dim3((unsigned)total), 256, 0, (hipStream_t)stream>>>(t);
     return (int)hipGetLastError();
 }
 

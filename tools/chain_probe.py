@@ -1,75 +1,95 @@
 #!/usr/bin/env python3
 """Per-launch time of the SAC gradient step's row-chain kernels (csrc/cstr_chain.hip) at the bench shape, graph-replayed back-to-back
-launches + HIP events, for every `tiles` setting; the per-layer launches they replace beside them.
-    python tools/chain_probe.py [--batch 256] [--hidden 256]"""
+launches + HIP events, for every `tiles` setting; the per-layer launch they replace beside them. `chain_launches` is also what
+bench.py's `kernels` section times.
+    python tools/chain_probe.py [--batch 256]"""
 import argparse
 import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "pytorch-rl-enhancedstablebaselines_amd")):
-    sys.path.insert(0, p)
+    if p not in sys.path:
+        sys.path.insert(0, p)
 import torch as th  # noqa: E402
 
-from bench import event_time_us  # noqa: E402
-from core import _native as nv  # noqa: E402
-from core.common import chain, hip_ops  # noqa: E402
-from core.common.vec_env import CSTRVecEnv  # noqa: E402
-from core.sac import SAC  # noqa: E402
+
+def chain_launches(model, B: int, tiles=None) -> dict:
+    """{name: (callable issuing ONE launch, algorithmic FLOPs of its MFMA work)} for the six chain launches of a SAC gradient step on
+    `model` (state of the step's buffers as a real step leaves them: every launch is idempotent on it)."""
+    from core import _native as nv
+    from core.common import chain, hip_ops
+
+    old = chain.TILES
+    if tiles is not None:
+        chain.TILES = tuple(tiles)
+    try:
+        c = chain.SacChain(model, B)
+    finally:
+        chain.TILES = old
+    pb = model._packed_batch(B)
+    if model.replay_buffer._predrawn is None:
+        model.replay_buffer.sample_packed_into(pb)
+    rd = pb.samples
+    fa = model._fast_actor
+    if fa.rng_ctl is None:
+        fa.rng_ctl = hip_ops.new_rng_ctl(0, model.device)
+    W, D, A = c.W, c.D, c.A
+    fin = nv.SacHeadFin(c.head_part.data_ptr(), fa._hb.data_ptr(), c.eps_all.data_ptr(), c.n_head_parts, A, D, nv.CHAIN_HEAD_GAUSSIAN, 2 * B, B, 0.0, 0.0,
+                        pb.x_pi.data_ptr(), pb.x_next.data_ptr(), c.params.data_ptr(), c.logp_pi.data_ptr(), c.logp_next.data_ptr())
+    nets4 = [hip_ops.chain_net(c.crit[0], pb.x_data, c.c_h1[0], c.c_h2[0], c.q_part4[0], nv.CHAIN_ROLE_STORE_PI),
+             hip_ops.chain_net(c.crit[1], pb.x_data, c.c_h1[1], c.c_h2[1], c.q_part4[1], nv.CHAIN_ROLE_PLAIN),
+             hip_ops.chain_net(c.targ[0], pb.x_next, None, None, c.q_part4[2], nv.CHAIN_ROLE_NEXT_STORE),
+             hip_ops.chain_net(c.targ[1], pb.x_next, None, None, c.q_part4[3], nv.CHAIN_ROLE_NEXT)]
+    nets2 = [hip_ops.chain_net(c.crit[g], pb.x_pi, c.c_h1[g], c.c_h2[g], c.q_part2[g]) for g in range(2)]
+    back = [hip_ops.chain_net(c.crit[g], None, c.c_h1[g], c.c_h2[g]) for g in range(2)]
+    ent = th.ones(1, device=model.device)
+    b3s = [c.crit[0][2][1], c.crit[1][2][1], c.targ[0][2][1], c.targ[1][2][1]]
+    loss = th.zeros(1, device=model.device)
+    tq = th.zeros(B, 1, device=model.device)
+    root = hip_ops.chain_root("td", B, [c.q_part4[g] for g in range(4)], b3s, c.n_q4, gamma=0.99, scale=0.5, next_logp=c.logp_next, rew=rd.rewards,
+                              done=rd.dones, ent_coef=ent, target_out=tq, q_out=c.q_out, gq_out=c.gq, loss_out=loss)
+    aroot = hip_ops.chain_root("sac_actor", B, [c.q_part2[0], c.q_part2[1]], b3s[:2], c.n_q2, ent_coef=ent, logp=c.logp_pi, q_out=c.qpi_out, loss_out=loss)
+    actor_f = 2.0 * (D * c.aH1 + c.aH1 * c.aH2 + c.aH2 * 2 * A)
+    q_f = 2.0 * (W * c.cH1 + c.cH1 * c.cH2 + c.cH2)
+    keep = (c, pb, fin, nets4, nets2, back, root, aroot, ent, loss, tq)  # alive as long as the callables
+    return dict(
+        sac_actor_chain_fwd=(lambda k=keep: hip_ops.sac_actor_chain_fwd(c.actor, B, None, pb.x_pi, pb.x_next, None, None, c.a_h1, c.a_h2, c.head_part, c.t_act,
+                                                                        head_rng_ctl=fa.rng_ctl, eps_all=c.eps_all), actor_f * 2 * B),
+        q_chain_fwd_4nets=(lambda k=keep: hip_ops.q_chain_fwd(nets4, W, D, c.cH1, c.cH2, B, c.t_q4, fin), q_f * 4 * B),
+        q_chain_bwd_td=(lambda k=keep: hip_ops.q_chain_bwd(back, root, W, D, c.cH1, c.cH2, c.t_qb, dz2=c.dz2c, dz1=c.dz1c), 2.0 * c.cH1 * c.cH2 * 2 * B),
+        q_chain_fwd_2nets=(lambda k=keep: hip_ops.q_chain_fwd(nets2, W, D, c.cH1, c.cH2, B, c.t_q2), q_f * 2 * B),
+        q_chain_bwd_actor=(lambda k=keep: hip_ops.q_chain_bwd(back, aroot, W, D, c.cH1, c.cH2, c.t_qb, gact_part=c.gact_part), 2.0 * c.cH1 * c.cH2 * 2 * B),
+        sac_actor_chain_bwd=(lambda k=keep: hip_ops.sac_actor_chain_bwd(c.actor, c.gact_part, 2, c.n_gact, ent, pb.x_pi, c.params, c.eps_all, c.a_h1, c.a_h2,
+                                                                        c.g_params, c.dz2a, c.dz1a, B, c.t_ab), 2.0 * (c.aH1 * c.aH2 + 2 * A * c.aH2) * B))
 
 
 def main():
+    from bench import event_time_us
+    from core.common import hip_ops
+    from core.common.vec_env import CSTRVecEnv
+    from core.sac import SAC
+
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--n", type=int, default=200)
     args = ap.parse_args()
     B = args.batch
-    env = CSTRVecEnv(4096)
-    model = SAC("MlpPolicy", env, seed=0, batch_size=B)
+    model = SAC("MlpPolicy", CSTRVecEnv(4096), seed=0, batch_size=B)
     model.learn(4096 * 4)
     stream = th.cuda.current_stream()
-    pb = model._packed_batch(B)
-    model.replay_buffer.sample_packed_into(pb)
-    rd = pb.samples
     res = {}
+    names = None
     for tiles in (1, 2, 4):
-        chain.TILES = (tiles,) * 5
-        c = chain.SacChain(model, B)
-        fa = model._fast_actor
-        if fa.rng_ctl is None:
-            fa.rng_ctl = hip_ops.new_rng_ctl(0, model.device)
-        W, D, A = c.W, c.D, c.A
-        fin = nv.SacHeadFin(c.head_part.data_ptr(), fa._hb.data_ptr(), c.eps_all.data_ptr(), c.n_head_parts, A, D, 0, pb.x_pi.data_ptr(),
-                            pb.x_next.data_ptr(), c.params.data_ptr(), c.logp_pi.data_ptr(), c.logp_next.data_ptr())
-        nets4 = [hip_ops.chain_net(c.crit[0], pb.x_data, c.c_h1[0], c.c_h2[0], c.q_part4[0], nv.CHAIN_ROLE_STORE_PI),
-                 hip_ops.chain_net(c.crit[1], pb.x_data, c.c_h1[1], c.c_h2[1], c.q_part4[1], nv.CHAIN_ROLE_PLAIN),
-                 hip_ops.chain_net(c.targ[0], pb.x_next, None, None, c.q_part4[2], nv.CHAIN_ROLE_NEXT_STORE),
-                 hip_ops.chain_net(c.targ[1], pb.x_next, None, None, c.q_part4[3], nv.CHAIN_ROLE_NEXT)]
-        nets2 = [hip_ops.chain_net(c.crit[g], pb.x_pi, c.c_h1[g], c.c_h2[g], c.q_part2[g]) for g in range(2)]
-        back = [hip_ops.chain_net(c.crit[g], None, c.c_h1[g], c.c_h2[g]) for g in range(2)]
-        ent = th.ones(1, device=model.device)
-        b3s = [c.crit[0][2][1], c.crit[1][2][1], c.targ[0][2][1], c.targ[1][2][1]]
-        loss = th.zeros(1, device=model.device)
-        root = hip_ops.chain_root("td", B, [c.q_part4[g] for g in range(4)], b3s, c.n_q4, gamma=0.99, scale=0.5, next_logp=c.logp_next, rew=rd.rewards,
-                                  done=rd.dones, ent_coef=ent, target_out=model._target_q, q_out=c.q_out, gq_out=c.gq, loss_out=loss)
-        aroot = hip_ops.chain_root("sac_actor", B, [c.q_part2[0], c.q_part2[1]], b3s[:2], c.n_q2, ent_coef=ent, logp=c.logp_pi, q_out=c.qpi_out, loss_out=loss)
-        fns = dict(
-            actor_fwd=lambda: hip_ops.sac_actor_chain_fwd(c.actor, B, None, pb.x_pi, pb.x_next, None, None, c.a_h1, c.a_h2, c.head_part, tiles,
-                                                          head_rng_ctl=fa.rng_ctl, eps_all=c.eps_all),
-            q_fwd_4=lambda: hip_ops.q_chain_fwd(nets4, W, D, c.cH1, c.cH2, B, tiles, fin),
-            q_bwd_td=lambda: hip_ops.q_chain_bwd(back, root, W, D, c.cH1, c.cH2, tiles, dz2=c.dz2c, dz1=c.dz1c),
-            q_fwd_2=lambda: hip_ops.q_chain_fwd(nets2, W, D, c.cH1, c.cH2, B, tiles),
-            q_bwd_actor=lambda: hip_ops.q_chain_bwd(back, aroot, W, D, c.cH1, c.cH2, tiles, gact_part=c.gact_part),
-            actor_bwd=lambda: hip_ops.sac_actor_chain_bwd(c.actor, c.gact_part, 2, c.n_gact, ent, pb.x_pi, c.params, c.eps_all, c.a_h1, c.a_h2, c.g_params,
-                                                          c.dz2a, c.dz1a, B, tiles))
-        for name, fn in fns.items():
+        fns = chain_launches(model, B, (tiles,) * 5)
+        names = list(fns)
+        for fn, _ in fns.values():
             fn()
-        for name, fn in fns.items():
+        for name, (fn, _) in fns.items():
             res[(name, tiles)] = event_time_us(fn, args.n, stream, in_graph=True)
     print(f"chain kernels, batch {B}: us per graph-replayed launch at tiles = 1 / 2 / 4")
-    for name in ("actor_fwd", "q_fwd_4", "q_bwd_td", "q_fwd_2", "q_bwd_actor", "actor_bwd"):
-        print(f"  {name:12s} " + " / ".join(f"{res[(name, t)]:6.2f}" for t in (1, 2, 4)))
-    # the per-layer launches they replace, same shapes
+    for name in names:
+        print(f"  {name:20s} " + " / ".join(f"{res[(name, t)]:6.2f}" for t in (1, 2, 4)))
     h = 256
     x = th.randn(B, h, device=model.device)
     w, bias = th.randn(h, h, device=model.device) / 16, th.zeros(h, device=model.device)
