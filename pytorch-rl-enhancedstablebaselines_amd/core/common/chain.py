@@ -71,7 +71,9 @@ class SacChain:
         self.aH1, self.aH2 = l1.out_features, l2.out_features
         c = model.critic.q_networks[0]
         self.cH1, self.cH2 = c[0].out_features, c[2].out_features
-        self.t_act, self.t_q4, self.t_q2, self.t_qb, self.t_ab = TILES
+        t_act, t_q4, t_q2, t_qb, t_ab = TILES  # (a wave's share of the reduction must fit in registers: fewer tiles for wide layers)
+        self.t_act, self.t_q4, self.t_q2 = _pick_tiles(self.aH1, t_act), _pick_tiles(self.cH1, t_q4), _pick_tiles(self.cH1, t_q2)
+        self.t_qb, self.t_ab = _pick_tiles(self.cH2, t_qb), _pick_tiles(self.aH2, t_ab)
         self.actor = hip_ops.sac_actor_desc(self.D, self.A, l1.weight, l1.bias, l2.weight, l2.bias, fa._hw, fa._hb)
         self.actor_layers = (l1, l2)
         self.crit = [_q_layers(q) for q in model.critic.q_networks]
