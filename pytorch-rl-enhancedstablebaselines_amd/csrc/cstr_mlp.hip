@@ -1504,6 +1504,16 @@ __device__ unsigned long long policy_stamps[4096 * 16 * 8];
 #endif
 
 // FULL: every chunk of the stage is inside K (all stages but the last): no checks between the MFMAs
+// Workgroup barrier of the pipelined policy / rollout kernel: the waves hand activations over in LDS only, so the barrier waits for
+// LDS traffic (lgkmcnt) and NOT for the weight stream the waves have in flight -- `__syncthreads()` is a workgroup release fence,
+// i.e. s_waitcnt vmcnt(0): every wave sat out its outstanding global loads at each barrier (-DCSTR_POLICY_SYNC=1: the old form).
+#if defined(CSTR_POLICY_SYNC) && CSTR_POLICY_SYNC
+#define POLICY_BARRIER() __syncthreads()
+#else
+#define POLICY_BARRIER() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local"); __builtin_amdgcn_s_barrier(); \
+                              __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local"); } while (0)
+#endif
+
 template <bool SECOND, bool FULL>
 __device__ __forceinline__ void v2_mfma_stage(const int c_begin, const int kc, const float4 (&av)[V2_CH], const float4 (&b0)[V2_CH],
                                               const float4 (&b1)[V2_CH], f32x4 &c00, f32x4 &c01, f32x4 &c10, f32x4 &c11)
@@ -1588,7 +1598,16 @@ __device__ __forceinline__ void policy_rows_v2_body(const PolicyArgs &a, const R
     // how many of the NB chunks are requested BEFORE the first barrier: a wave is held while it issues loads (~60 ns per 1 KB wave
     // load), and everybody waits at the barrier for the last issuer -- the rest follows right after the barrier, before the MFMAs
     // (waves 0-3, SMALL: none before layer 1 -- A/B on MI355X: 0 / 2 / 4 chunks ahead of layer 1 = 10.60 / 10.61 / 10.73 us)
-    constexpr int PRE_YOUNG = SMALL ? 12 : V2_CH, PRE_OLD = SMALL ? 0 : V2_CH;
+    // (round 3: the barriers of this kernel are LDS-only -- see POLICY_BARRIER -- so requests no longer have to be held back for them)
+    // A/B (tools/rollout_ab.py, profiles/r03_rollout_ab.txt): __syncthreads + 12 / 0 ahead 12.93 us; LDS-only barriers 12.81; with all 16
+    // chunks of both wave groups requested ahead of the barrier 12.56 us (bit-identical outputs)
+#ifndef CSTR_PRE_YOUNG
+#define CSTR_PRE_YOUNG 16
+#endif
+#ifndef CSTR_PRE_OLD
+#define CSTR_PRE_OLD 16
+#endif
+    constexpr int PRE_YOUNG = SMALL ? CSTR_PRE_YOUNG : V2_CH, PRE_OLD = SMALL ? CSTR_PRE_OLD : V2_CH;
     // who draws the Gaussian noise (~1.7 us of dependent VALU work that needs nothing from memory): wave 7, AFTER its weight requests.
     // With the draw in front of them the requests sat behind everybody else's in the CU's in-order queue and wave 7 left layer 2
     // ~1 us after the other seven (in-kernel stamps, profiles/r02_rollout_phase_stamps.json); on a layer-1 wave, between requesting
@@ -1684,7 +1703,7 @@ __device__ __forceinline__ void policy_rows_v2_body(const PolicyArgs &a, const R
         for (int q = 0; q < V2_HEAD_Q; ++q) w3q[q] = load_k4_clamped<true>(w3r, 16 * (wave + WAVES * q) + 4 * h, H2, r < n_out);
     }
     V2_STAMP(1);
-    __syncthreads();
+    POLICY_BARRIER();
     V2_STAMP(2);
     if (SMALL) {  // the rest of the wave's B operand
         if (l1_wave) V2_REQUEST_B(PRE_OLD, NB);
@@ -1805,7 +1824,7 @@ __device__ __forceinline__ void policy_rows_v2_body(const PolicyArgs &a, const R
             for (int e = 0; e < 4; ++e) part[(wave * POLICY_ROWS + 4 * h + e) * 8 + r] = p0[e];
         }
     }
-    __syncthreads();
+    POLICY_BARRIER();
     V2_STAMP(5);
     if (FUSE && mt_wave) {  // an idle wave from here on: the draw runs beside the sampling tail and the collect step of waves 0-1
         // ReplayBuffer.sample's two index draws for the gather launch behind this one (buffers.py:112-113, :309), with the ring

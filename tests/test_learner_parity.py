@@ -1195,3 +1195,30 @@ def test_single_env_info_dict_matches_reference(golden):
     assert g["stable_steps"].max() >= 10 and (g["concentration_trend_reward"] == -0.2).any() and g["extreme_penalty"].min() < 0
     obs, r, te, tr, info = env.step(np.array([np.nan, 0.0], np.float32))  # the exception path: empty info (twoseriescstr.py:413-421)
     assert info == {} and tr and r == -10.0
+
+
+@pytest.mark.parametrize("algo", ["sac", "td3"])
+def test_logged_values_with_eight_iterations_per_graph_equal_one_per_graph(algo):
+    """with `enable_graph_capture(unroll=8)` the host bookkeeping of eight iterations runs after their replay, so a value
+    logged for iteration i is read when iteration i + 7 has already run. At a multiple of eight iterations the logged losses, the
+    entropy coefficient and TD3's kept actor loss (td3.py:207-211: the last actor update's, also after a critic-only step) must be
+    exactly what one iteration per graph logs -- same launches in the same order."""
+    from core.common.vec_env import CSTRVecEnv
+    from core.sac import SAC
+    from core.td3 import TD3
+
+    N, iters = 128, 40  # the first vec-step already passes learning_starts: one update per iteration; TD3: the last update is an actor update
+    out = []
+    for unroll in (1, 8):
+        cls = SAC if algo == "sac" else TD3
+        model = cls("MlpPolicy", CSTRVecEnv(N), seed=3, batch_size=64, buffer_size=N * 16, learning_starts=100, policy_kwargs=dict(net_arch=[64, 64]))
+        model.enable_graph_capture(True, unroll=unroll)
+        model.learn(N * iters)
+        th.cuda.synchronize()
+        assert model._n_updates == iters and model.graph_status()["active"]
+        if unroll == 8:
+            assert any(k[-1] == 8 for k in model._graph), "no eight-iteration graph was recorded"
+        lv = model.logger.name_to_value
+        keys = [k for k in ("train/critic_loss", "train/actor_loss", "train/ent_coef", "train/ent_coef_loss", "train/n_updates") if k in lv]
+        out.append({k: float(lv[k]) for k in keys})
+    assert out[0] == out[1] and len(out[0]) >= 3, out
