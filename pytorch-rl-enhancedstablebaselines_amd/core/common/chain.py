@@ -30,7 +30,7 @@ USE_CHAIN = os.environ.get("CSTR_CHAIN", "1") != "0"
 # single GPU: the dW / db launch applies the Adam step to the tiles it has reduced (cstr_linear_bwd_weight_adam_sets_f32): 8 launches
 USE_WGRAD_ADAM = os.environ.get("CSTR_WGRAD_ADAM", "1") != "0"
 # 16-column MFMA tiles per workgroup: actor forward, Q forward (4 networks), Q forward (2 networks), Q backward, actor backward
-TILES = tuple(int(v) for v in os.environ.get("CSTR_CHAIN_TILES", "2,4,2,2,1").split(","))
+TILES = tuple(int(v) for v in os.environ.get("CSTR_CHAIN_TILES", "2,2,2,2,1").split(","))
 
 
 def _q_layers(qnet: nn.Sequential):

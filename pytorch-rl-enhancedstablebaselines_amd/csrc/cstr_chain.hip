@@ -53,6 +53,14 @@ __device__ __forceinline__ float ld32(const __amdgpu_buffer_rsrc_t rs, const int
     return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, byte_off, 0, 0));
 }
 
+#ifdef CSTR_CHAIN_STAMPS  // diagnostic build only (make diag): s_memtime per wave at the phase boundaries, read by tools/chain_stamps.py
+__device__ unsigned long long chain_stamps[4 * 1024 * 4 * 8];  // [kernel][workgroup (linear, < 1024)][wave][stamp]
+#define CH_STAMP(K, I) do { const unsigned wg_ = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x; \
+        if ((threadIdx.x & 63) == 0 && wg_ < 1024) chain_stamps[(((K) * 1024 + wg_) * 4 + (threadIdx.x >> 6)) * 8 + (I)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define CH_STAMP(K, I) do { } while (0)
+#endif
+
 // LDS-only workgroup barrier: waits for this wave's LDS traffic (lgkmcnt), NOT for its outstanding global loads / stores -- the
 // chain kernels keep operand loads in flight across their phase boundaries and issue their global stores at the very end.
 __device__ __forceinline__ void lds_barrier()
@@ -112,20 +120,26 @@ template <int NQ>
 __device__ __forceinline__ f32x4 tile_mma(const float *panel, const int ld, const int kdim, const float4 (&bq)[NQ], const int ks, const int S)
 {
     const int lane = threadIdx.x & 63, r = lane & 15, h = lane >> 4;
-    f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
+    // FOUR independent accumulator chains (a dependent MFMA waits ~its own issue time again for the previous result): the wave's
+    // 4 NQ MFMAs are 4 chains of NQ instead of 2 of 2 NQ
+    f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
+    float4 av[NQ];
+#pragma unroll
+    for (int u = 0; u < NQ; ++u) {  // the A quads first: their LDS round trips overlap
+        const int k = 16 * (ks + S * u) + 4 * h;
+        av[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (k < kdim) av[u] = *reinterpret_cast<const float4 *>(panel + r * ld + k);  // kdim % 4 == 0: a quad is inside or outside
+    }
 #pragma unroll
     for (int u = 0; u < NQ; ++u) {
-        const int k = 16 * (ks + S * u) + 4 * h;
         if (16 * (ks + S * u) < kdim) {  // wave-uniform
-            float4 a = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            if (k < kdim) a = *reinterpret_cast<const float4 *>(panel + r * ld + k);  // kdim % 4 == 0: a quad is inside or outside
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bq[u].x, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bq[u].y, acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bq[u].z, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bq[u].w, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u].x, bq[u].x, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u].y, bq[u].y, acc1, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u].z, bq[u].z, acc2, 0, 0, 0);
+            acc3 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u].w, bq[u].w, acc3, 0, 0, 0);
         }
     }
-    return acc0 + acc1;
+    return (acc0 + acc1) + (acc2 + acc3);
 }
 
 // split-K combine: wave = tile + T * ks; the ks > 0 waves park their partial tile in LDS, the ks == 0 wave of the tile adds them in
@@ -148,20 +162,50 @@ __device__ __forceinline__ f32x4 combine_split_k(f32x4 acc, float *smem, const i
 // add would serialise n round trips to a freshly written buffer, the longest stretch of these kernels' prologues). n <= 16 takes the
 // branch-free form (lanes beyond n read zeros through the descriptor's range check: x + 0 is exact).
 constexpr int MAX_PARTS = 16;
+template <int NP>
+__device__ __forceinline__ float sum_parts_n(const __amdgpu_buffer_rsrc_t rs, const int n, const int64_t stride, const int64_t at)
+{
+    float v[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) v[p] = ld32(rs, p < n ? (int)(4 * (p * stride + at)) : BUF_OOB);
+    float s = v[0];
+#pragma unroll
+    for (int p = 1; p < NP; ++p) s += v[p];
+    return s;
+}
+
+// the same in two steps, so that a kernel can REQUEST its partials first thing, issue its other operand requests behind them and add
+// the partials up when they are needed: n <= 8 in registers, more through sum_parts at `sum()` time
+struct PartBatch {
+    float v[8];
+    const float *part; int n; int64_t stride, at, total;
+    __device__ __forceinline__ void request(const float *part_, const int n_, const int64_t stride_, const int64_t at_, const int64_t total_)
+    {
+        part = part_; n = n_; stride = stride_; at = at_; total = total_;
+        const __amdgpu_buffer_rsrc_t rs = rsrc_of(part, total);
+#pragma unroll
+        for (int p = 0; p < 8; ++p) v[p] = ld32(rs, (p < n && n <= 8) ? (int)(4 * (p * stride + at)) : BUF_OOB);
+    }
+    __device__ __forceinline__ float sum() const;
+};
+
 __device__ __forceinline__ float sum_parts(const float *part, const int n, const int64_t stride, const int64_t at, const int64_t total_floats)
 {
-    if (n <= MAX_PARTS) {
-        const __amdgpu_buffer_rsrc_t rs = rsrc_of(part, total_floats);
-        float v[MAX_PARTS];
-#pragma unroll
-        for (int p = 0; p < MAX_PARTS; ++p) v[p] = ld32(rs, p < n ? (int)(4 * (p * stride + at)) : BUF_OOB);
-        float s = v[0];
-#pragma unroll
-        for (int p = 1; p < MAX_PARTS; ++p) s += v[p];
-        return s;
-    }
+    const __amdgpu_buffer_rsrc_t rs = rsrc_of(part, total_floats);
+    if (n <= 4) return sum_parts_n<4>(rs, n, stride, at);  // (n is launch-uniform)
+    if (n <= 8) return sum_parts_n<8>(rs, n, stride, at);
+    if (n <= MAX_PARTS) return sum_parts_n<MAX_PARTS>(rs, n, stride, at);
     float s = part[at];
     for (int p = 1; p < n; ++p) s += part[p * stride + at];
+    return s;
+}
+
+__device__ __forceinline__ float PartBatch::sum() const
+{
+    if (n > 8) return sum_parts(part, n, stride, at, total);
+    float s = v[0];
+#pragma unroll
+    for (int p = 1; p < 8; ++p) s += v[p];
     return s;
 }
 
@@ -199,17 +243,32 @@ __device__ __forceinline__ void layer1_mfma(const float *xs, const float *w1s, f
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, h = lane >> 4;
     const float4 xa = *reinterpret_cast<const float4 *>(xs + r * 16 + 4 * h);
-    for (int tl = wave; tl < (h1 + 15) / 16; tl += CH_WAVES) {
-        const float4 wb = *reinterpret_cast<const float4 *>(w1s + min(16 * tl + r, h1 - 1) * 16 + 4 * h);
-        f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.x, wb.x, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.y, wb.y, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.z, wb.z, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.w, wb.w, acc1, 0, 0, 0);
-        const f32x4 acc = acc0 + acc1;
-        if (16 * tl + r < h1) {
+    const int n_tiles = (h1 + 15) / 16;
+    for (int t0 = wave; t0 < n_tiles; t0 += 4 * CH_WAVES) {  // four tiles in flight: their LDS reads, MFMA chains and stores interleave
+        float4 wb[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) panel[(4 * h + e) * ld + 16 * tl + r] = fmaxf(acc[e], 0.0f);
+        for (int i = 0; i < 4; ++i) wb[i] = *reinterpret_cast<const float4 *>(w1s + min(16 * (t0 + CH_WAVES * i) + r, h1 - 1) * 16 + 4 * h);
+        f32x4 acc0[4], acc1[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            acc0[i] = {0.0f, 0.0f, 0.0f, 0.0f};
+            acc1[i] = acc0[i];
+            acc0[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.x, wb[i].x, acc0[i], 0, 0, 0);
+            acc1[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.y, wb[i].y, acc1[i], 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            acc0[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.z, wb[i].z, acc0[i], 0, 0, 0);
+            acc1[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.w, wb[i].w, acc1[i], 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int tl = t0 + CH_WAVES * i;
+            const f32x4 acc = acc0[i] + acc1[i];
+            if (tl < n_tiles && 16 * tl + r < h1) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) panel[(4 * h + e) * ld + 16 * tl + r] = fmaxf(acc[e], 0.0f);
+            }
         }
     }
 }
@@ -248,6 +307,7 @@ __global__ __launch_bounds__(CH_THREADS) void sac_actor_chain_fwd_kernel(const A
     const int ld = H1 + 4;
     float *w1s = panel + 16 * ld;
     const bool col_ok = n0 + r < H2;
+    CH_STAMP(0, 0);
     // (a) everything that depends on nothing is requested NOW: the wide layer's B operand, the epilogue's bias and head weights, W1
     float4 bq[NQ];
     load_b_fwd<NQ>(bq, a.net.w2, H2, H1, n0, ks, S);
@@ -302,13 +362,18 @@ __global__ __launch_bounds__(CH_THREADS) void sac_actor_chain_fwd_kernel(const A
         philox4x32_10((uint32_t)ctr, (uint32_t)(ctr >> 32), (uint32_t)pr, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), rr);
         box_muller(rr[0], rr[1], e0, e1);
     }
+    CH_STAMP(0, 1);
     lds_barrier();
+    CH_STAMP(0, 2);
     // (c) layer 1, recomputed by every workgroup of the row group -> panel
     layer1_mfma(xs, w1s, panel, ld, H1);
     lds_barrier();
+    CH_STAMP(0, 3);
     // (d) layer 2: this wave's 16 x 16 tile (its share of K), (e) split-K combine
     f32x4 acc = tile_mma<NQ>(panel, ld, H1, bq, ks, S);
+    CH_STAMP(0, 4);
     acc = combine_split_k(acc, smem, T, S);
+    CH_STAMP(0, 5);
     // (f) epilogue of the tile's first wave: bias + ReLU, head partials over these 16 columns
     float hv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     if (wave < T) {
@@ -326,6 +391,7 @@ __global__ __launch_bounds__(CH_THREADS) void sac_actor_chain_fwd_kernel(const A
         }
     }
     lds_barrier();
+    CH_STAMP(0, 6);
     if (t < 16 * HN) {
         const int row = t / HN, j = t % HN;
         float s = red[row * 8 + j];
@@ -375,6 +441,7 @@ __global__ __launch_bounds__(CH_THREADS) void sac_actor_chain_fwd_kernel(const A
             a.ring_ctl[3] += 1;
         }
     }
+    CH_STAMP(0, 7);
 }
 
 // ---- Q networks, forward chain ------------------------------------------------------------------------------------------------
@@ -398,6 +465,29 @@ __global__ __launch_bounds__(CH_THREADS) void q_chain_fwd_kernel(const QFwdArgs 
     const int ld = H1 + 4;
     float *w1s = panel + 16 * ld;
     const bool col_ok = n0 + r < H2;
+    CH_STAMP(1, 0);
+    const int role = a.has_fin ? net.role : CSTR_CHAIN_ROLE_PLAIN;
+    // the pending actor head's partial sums, noise and biases of this lane's (row, action): the longest dependent chain of the launch
+    // starts with these loads, so they are requested before everything else
+    const bool nxt = role == CSTR_CHAIN_ROLE_NEXT || role == CSTR_CHAIN_ROLE_NEXT_STORE;
+    const bool own = nxt || role == CSTR_CHAIN_ROLE_PI;  // the finalised actions are this network's own input columns
+    const bool fin_rows = own || (role == CSTR_CHAIN_ROLE_STORE_PI && blockIdx.x == 0);
+    const bool fin_lane = fin_rows && t < 16 * A;  // a lane per (row, action) in wave 0
+    const int f_row = t / A, f_j = t % A;
+    PartBatch p_mu, p_raw;
+    float f_ev = 0.0f, f_hb_mu = 0.0f, f_hb_raw = 0.0f;
+    bool f_det = false;
+    if (fin_lane) {
+        f_det = a.fin.kind == CSTR_CHAIN_HEAD_DETERMINISTIC;
+        const int HN = f_det ? A : 2 * A;
+        const int64_t i = (nxt ? a.fin.next_offset : 0) + m0 + f_row;  // row of the actor pass
+        const int64_t pstride = (int64_t)a.fin.part_rows * HN, ptotal = pstride * a.fin.n_parts;
+        p_mu.request(a.fin.head_part, a.fin.n_parts, pstride, i * HN + f_j, ptotal);
+        if (!f_det) p_raw.request(a.fin.head_part, a.fin.n_parts, pstride, i * HN + A + f_j, ptotal);
+        f_ev = a.fin.eps ? a.fin.eps[i * A + f_j] : 0.0f;
+        f_hb_mu = a.fin.hb[f_j];
+        f_hb_raw = f_det ? 0.0f : a.fin.hb[A + f_j];
+    }
     // (a) requests that depend on nothing
     float4 bq[NQ];
     load_b_fwd<NQ>(bq, net.w2, H2, H1, n0, ks, S);
@@ -405,38 +495,29 @@ __global__ __launch_bounds__(CH_THREADS) void q_chain_fwd_kernel(const QFwdArgs 
     const float bv = net.b2[col];
     const float w3v = col_ok ? net.w3[col] : 0.0f;
     stage_w1<W>(w1s, net.w1, net.b1, H1);
-    const int role = a.has_fin ? net.role : CSTR_CHAIN_ROLE_PLAIN;
     // (b) input rows (16 floats per row in LDS: the inputs, 1.0 = the bias input, zeros); with a pending actor head the action columns
     //     of the pi(next_obs) rows are finalised HERE (every workgroup of the row group for itself: a lane per (row, action)), and the
     //     column-group-0 workgroups store what later launches need
     // NEXT / NEXT_STORE: the network reads x_next whose action columns are finalised here; PI: the same for x_pi; STORE_PI: the input
     // is complete and the column-group-0 workgroups finalise the pi(obs) rows as a side job
-    const bool nxt = role == CSTR_CHAIN_ROLE_NEXT || role == CSTR_CHAIN_ROLE_NEXT_STORE;
-    const bool own = nxt || role == CSTR_CHAIN_ROLE_PI;  // the finalised actions are this network's own input columns
     {
         const int row = t >> 4, k = t & 15;  // 256 threads = 16 x 16
         float xv = k == W ? 1.0f : 0.0f;
         if (k < W && !(own && k >= D)) xv = net.x[(int64_t)(m0 + row) * W + k];
         if (!(own && k >= D && k < W)) xs[row * 16 + k] = xv;
     }
-    const bool fin_rows = own || (role == CSTR_CHAIN_ROLE_STORE_PI && blockIdx.x == 0);
-    const bool fin_lane = fin_rows && t < 16 * A;  // a lane per (row, action) in wave 0
     float f_mu = 0.0f, f_raw = 0.0f, f_a = 0.0f, f_lp = 0.0f;
-    const int f_row = t / A, f_j = t % A;
     if (fin_lane) {
-        const bool det = a.fin.kind == CSTR_CHAIN_HEAD_DETERMINISTIC;
-        const int HN = det ? A : 2 * A;
-        const int64_t i = (nxt ? a.fin.next_offset : 0) + m0 + f_row;  // row of the actor pass
-        const int64_t pstride = (int64_t)a.fin.part_rows * HN, ptotal = pstride * a.fin.n_parts;
-        const float ev = a.fin.eps ? a.fin.eps[i * A + f_j] : 0.0f, hb_mu = a.fin.hb[f_j], hb_raw = det ? 0.0f : a.fin.hb[A + f_j];
-        f_mu = sum_parts(a.fin.head_part, a.fin.n_parts, pstride, i * HN + f_j, ptotal) + hb_mu;
+        const bool det = f_det;
+        const float ev = f_ev;
+        f_mu = p_mu.sum() + f_hb_mu;
         if (det) {
             // deterministic actor (core/td3/policies.py:57-83): a = tanh(.); target actions get the clipped smoothing noise
             // (core/td3/td3.py:167-171; target_smooth_kernel's expressions)
             f_a = tanhf(f_mu);
             if (nxt) f_a = fminf(fmaxf(f_a + fminf(fmaxf(ev * a.fin.sigma, -a.fin.clip), a.fin.clip), -1.0f), 1.0f);
         } else {
-            f_raw = sum_parts(a.fin.head_part, a.fin.n_parts, pstride, i * HN + A + f_j, ptotal) + hb_raw;
+            f_raw = p_raw.sum() + f_hb_raw;
             float term;
             sample_action(f_mu, f_raw, ev, f_a, term);
             // log-prob of the row = sum of its actions' terms: the A lanes of a row are adjacent
@@ -446,12 +527,17 @@ __global__ __launch_bounds__(CH_THREADS) void q_chain_fwd_kernel(const QFwdArgs 
         }
         if (own) xs[f_row * 16 + D + f_j] = f_a;
     }
+    CH_STAMP(1, 1);
     lds_barrier();
+    CH_STAMP(1, 2);
     // (c) layer 1 recomputed on the matrix cores
     layer1_mfma(xs, w1s, panel, ld, H1);
     lds_barrier();
+    CH_STAMP(1, 3);
     f32x4 acc = tile_mma<NQ>(panel, ld, H1, bq, ks, S);
+    CH_STAMP(1, 4);
     acc = combine_split_k(acc, smem, T, S);
+    CH_STAMP(1, 5);
     float hv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     if (wave < T) {
 #pragma unroll
@@ -468,6 +554,7 @@ __global__ __launch_bounds__(CH_THREADS) void q_chain_fwd_kernel(const QFwdArgs 
         }
     }
     lds_barrier();
+    CH_STAMP(1, 6);
     if (t < 16) {
         float s = red[t * 8];
         for (int tl = 1; tl < T; ++tl) s += red[(tl * 16 + t) * 8];
@@ -489,6 +576,7 @@ __global__ __launch_bounds__(CH_THREADS) void q_chain_fwd_kernel(const QFwdArgs 
         }
         if (f_j == 0 && !det) (nxt ? a.fin.logp_next : a.fin.logp_pi)[bb] = f_lp;
     }
+    CH_STAMP(1, 7);
 }
 
 // ---- Q networks, loss root + backward chain -------------------------------------------------------------------------------------
@@ -608,6 +696,26 @@ __global__ __launch_bounds__(CH_THREADS) void q_chain_bwd_kernel(const QBwdArgs 
     const int col = min(k0 + r, H1 - 1);
     float *red = smem + SM_RED, *gs = smem + SM_GS, *panel = smem + SM_PANEL;
     const int ld = H2 + 4;
+    CH_STAMP(2, 0);
+    // the row group's Q partials (freshly written by the launch in front of this one) start the prologue's dependent chain: requested
+    // before everything else
+    PartBatch pq[4];
+    float r_nl = 0.0f, r_rw = 0.0f, r_dn = 0.0f, r_b3[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (t < 16) {
+        const int row = m0 + t, P = rt.n_parts, need = rt.mode == 1 ? 4 : a.n_nets;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (q < need) {
+                pq[q].request(rt.q_part[q], P, B, row, (int64_t)P * B);
+                r_b3[q] = rt.b3[q][0];
+            }
+        }
+        if (rt.mode == 1) {
+            r_nl = rt.next_logp ? rt.next_logp[row] : 0.0f;
+            r_rw = rt.rew[row];
+            r_dn = rt.done[row];
+        }
+    }
     // (a) operands that depend on nothing: the tile's B operand (W2 read along n), the epilogue's relu'(h1) mask values and first-layer
     //     action columns, and this thread's columns of the h2 panel + w3 for the dz2 recompute
     float4 bq[NQ];
@@ -634,30 +742,30 @@ __global__ __launch_bounds__(CH_THREADS) void q_chain_bwd_kernel(const QBwdArgs 
     // (b) d(loss)/dq of this network for the row group's 16 rows (cstr_head_root_t's expressions)
     float o_q = 0.0f, o_gq = 0.0f, o_tq = 0.0f;
     if (t < 16) {
-        const int row = m0 + t, P = rt.n_parts;
         const bool with_alpha = rt.mode == 1 && rt.alpha.log_alpha != nullptr;
         const float ec = with_alpha ? expf(rt.alpha.log_alpha[0]) : (rt.ent_coef ? rt.ent_coef[0] : 0.0f);
         const float kq = rt.scale * 2.0f / (float)B, inv = 1.0f / (float)B;
         if (rt.mode == 1) {
-            const float nl = rt.next_logp ? rt.next_logp[row] : 0.0f, rw = rt.rew[row], dn = rt.done[row];
-            const float qa = q_from_parts(rt.q_part[2], rt.b3[2], P, B, row), qb = q_from_parts(rt.q_part[3], rt.b3[3], P, B, row);
-            o_q = q_from_parts(rt.q_part[g], rt.b3[g], P, B, row);
+            const float qa = pq[2].sum() + r_b3[2], qb = pq[3].sum() + r_b3[3];
+            o_q = (g == 0 ? pq[0].sum() + r_b3[0] : pq[1].sum() + r_b3[1]);
             float q = fminf(qa, qb);
-            if (rt.next_logp) q = q - ec * nl;
-            o_tq = rw + (1.0f - dn) * rt.gamma * q;
+            if (rt.next_logp) q = q - ec * r_nl;
+            o_tq = r_rw + (1.0f - r_dn) * rt.gamma * q;
             o_gq = kq * (o_q - o_tq);
         } else if (rt.mode == 3) {
-            o_q = q_from_parts(rt.q_part[0], rt.b3[0], P, B, row);
+            o_q = pq[0].sum() + r_b3[0];
             o_gq = -inv;
         } else {
-            const float q1 = q_from_parts(rt.q_part[0], rt.b3[0], P, B, row), q2 = q_from_parts(rt.q_part[1], rt.b3[1], P, B, row);
+            const float q1 = pq[0].sum() + r_b3[0], q2 = pq[1].sum() + r_b3[1];
             const bool first = q1 <= q2;
             o_q = g == 0 ? q1 : q2;
             o_gq = (first == (g == 0)) ? -inv : 0.0f;
         }
         gs[t] = o_gq;
     }
+    CH_STAMP(2, 1);
     lds_barrier();
+    CH_STAMP(2, 2);
     // (c) dz2 = dq * w3 * relu'(h2), recomputed by every workgroup of the row group into the panel (values kept for the store at the end)
     {
         float gq[16];
@@ -679,9 +787,12 @@ __global__ __launch_bounds__(CH_THREADS) void q_chain_bwd_kernel(const QBwdArgs 
         }
     }
     lds_barrier();
+    CH_STAMP(2, 3);
     // (d) dz1 tile = (dz2 W2)[rows][k0 .. k0 + 15], (e) split-K combine, (f) * relu'(h1); partial action gradient
     f32x4 acc = tile_mma<NQ>(panel, ld, H2, bq, ks, S);
+    CH_STAMP(2, 4);
     acc = combine_split_k(acc, smem, T, S);
+    CH_STAMP(2, 5);
     float d[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     if (wave < T) {
 #pragma unroll
@@ -706,6 +817,7 @@ __global__ __launch_bounds__(CH_THREADS) void q_chain_bwd_kernel(const QBwdArgs 
             a.gact_part[(((int64_t)g * gridDim.x + blockIdx.x) * B + m0 + row) * A + j] = s;
         }
     }
+    CH_STAMP(2, 6);
     // ---- global stores, all behind the last barrier ----
     if (a.dz1 && wave < T && col_ok) {
 #pragma unroll
@@ -728,6 +840,7 @@ __global__ __launch_bounds__(CH_THREADS) void q_chain_bwd_kernel(const QBwdArgs 
         if (rt.gq_out) rt.gq_out[(int64_t)g * B + row] = o_gq;
         if (rt.mode == 1 && g == 0 && rt.target_out) rt.target_out[row] = o_tq;
     }
+    CH_STAMP(2, 7);
 }
 
 // ---- SAC actor, backward chain -------------------------------------------------------------------------------------------------
@@ -752,11 +865,24 @@ __global__ __launch_bounds__(CH_THREADS) void sac_actor_chain_bwd_kernel(const A
     const int col = min(k0 + r, H1 - 1), HN = det ? A : 2 * A;
     float *gs = smem + SM_GS, *panel = smem + SM_PANEL;
     const int ld = H2 + 4;
+    CH_STAMP(3, 0);
     float4 bq[NQ];
     load_b_bwd<NQ>(bq, a.net.w2, H2, H1, k0, ks, S);
     float ty[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) ty[e] = a.a_h1[(int64_t)(m0 + 4 * h + e) * H1 + col];
+    // the dz2 recompute's operands of this wave's first four tiles (tiles wave, wave + 4, ...): head weights and relu'(a_h2) mask values
+    constexpr int ZT = 4;
+    const int n_ztiles = (H2 + 15) / 16;
+    float zb0[ZT], zb1[ZT], zm[ZT][4];
+#pragma unroll
+    for (int i = 0; i < ZT; ++i) {
+        const int cc = min(16 * (wave + CH_WAVES * i) + r, H2 - 1);
+        zb0[i] = h < HN ? a.net.hw[(int64_t)h * H2 + cc] : 0.0f;
+        zb1[i] = HN > 4 ? a.net.hw[(int64_t)(4 + h) * H2 + cc] : 0.0f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) zm[i][e] = a.a_h2[(int64_t)(m0 + 4 * h + e) * H2 + cc];
+    }
     // (b) d(loss)/d(action) from the critic's partial sums, then the squashed-Gaussian head's backward (gaussian_head_bwd_kernel's
     //     expressions): g_params[row] = (d/d mean | d/d log_std) -> gs[16][8] (zero-padded: the k chunk of the dz2 MFMA)
     float o_gu = 0.0f, o_gls = 0.0f;
@@ -780,24 +906,22 @@ __global__ __launch_bounds__(CH_THREADS) void sac_actor_chain_bwd_kernel(const A
         gs[row * 8 + j] = o_gu;
         gs[row * 8 + A + j] = o_gls;  // (deterministic head: zero -- the k chunk of the dz2 MFMA is 4 wide)
     }
+    CH_STAMP(3, 1);
     lds_barrier();
+    CH_STAMP(3, 2);
     // (c) dz2 = (g_params hw) * relu'(a_h2) on the matrix cores: K = 2A is one (A = 2) or two (A = 4) MFMA steps per 16 x 16 tile;
     //     A operand = g_params[r][h] (LDS), B operand = hw[h][column] straight from L2; the wave takes the tiles wave, wave + 4, ...
     {
         const bool two = HN > 4;  // 8 head outputs: two k steps
         const float ga0 = gs[r * 8 + h], ga1 = two ? gs[r * 8 + 4 + h] : 0.0f;
         const int cpg = (H2 + gridDim.x - 1) / gridDim.x;
-        for (int tl = wave; tl < (H2 + 15) / 16; tl += CH_WAVES) {
-            const int c = 16 * tl + r, cc = min(c, H2 - 1);
-            const float hb0 = h < HN ? a.net.hw[(int64_t)h * H2 + cc] : 0.0f, hb1 = two ? a.net.hw[(int64_t)(4 + h) * H2 + cc] : 0.0f;
-            float m[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) m[e] = a.a_h2[(int64_t)(m0 + 4 * h + e) * H2 + cc];
+        auto dz2_tile = [&](const int tl, const float hb0, const float hb1, const float (&m)[4]) {
+            const int c = 16 * tl + r;
             f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ga0, hb0, acc, 0, 0, 0);
             if (two) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ga1, hb1, acc, 0, 0, 0);
             const bool mine = c / cpg == (int)blockIdx.x;  // this workgroup's share of the dz2 columns (stored now: nothing waits for it)
-            if (c < H2) {
+            if (tl < n_ztiles && c < H2) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float dv = m[e] > 0.0f ? acc[e] : 0.0f;
@@ -805,11 +929,24 @@ __global__ __launch_bounds__(CH_THREADS) void sac_actor_chain_bwd_kernel(const A
                     if (mine) a.dz2[(int64_t)(m0 + 4 * h + e) * H2 + c] = dv;
                 }
             }
+        };
+#pragma unroll
+        for (int i = 0; i < ZT; ++i) dz2_tile(wave + CH_WAVES * i, zb0[i], zb1[i], zm[i]);
+        for (int tl = wave + CH_WAVES * ZT; tl < n_ztiles; tl += CH_WAVES) {  // layers wider than 256: the remaining tiles
+            const int cc = min(16 * tl + r, H2 - 1);
+            const float hb0 = h < HN ? a.net.hw[(int64_t)h * H2 + cc] : 0.0f, hb1 = two ? a.net.hw[(int64_t)(4 + h) * H2 + cc] : 0.0f;
+            float m[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) m[e] = a.a_h2[(int64_t)(m0 + 4 * h + e) * H2 + cc];
+            dz2_tile(tl, hb0, hb1, m);
         }
     }
     lds_barrier();
+    CH_STAMP(3, 3);
     f32x4 acc = tile_mma<NQ>(panel, ld, H2, bq, ks, S);
+    CH_STAMP(3, 4);
     acc = combine_split_k(acc, smem, T, S);
+    CH_STAMP(3, 5);
     // ---- global stores ----
     if (wave < T && col_ok) {
 #pragma unroll
@@ -820,6 +957,7 @@ __global__ __launch_bounds__(CH_THREADS) void sac_actor_chain_bwd_kernel(const A
         a.g_params[(int64_t)b * HN + j] = o_gu;
         if (!det) a.g_params[(int64_t)b * HN + A + j] = o_gls;
     }
+    CH_STAMP(3, 7);
 }
 
 // chunks of 16 along the reduction a wave owns, rounded up to an instantiated size (0: not covered)
@@ -858,6 +996,12 @@ constexpr size_t CHAIN_LDS_LIMIT = 64 * 1024;
 }  // namespace
 
 // ---- C ABI --------------------------------------------------------------------------------------------------------------------
+#ifdef CSTR_CHAIN_STAMPS
+extern "C" int cstr_diag_chain_stamps(unsigned long long *host_out, int64_t words)
+{
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(chain_stamps), (size_t)words * 8);
+}
+#endif
 
 static int check_actor(const cstr_sac_actor_t *n)
 {
