@@ -33,6 +33,10 @@ USE_WGRAD_ADAM = os.environ.get("CSTR_WGRAD_ADAM", "1") != "0"
 TILES = tuple(int(v) for v in os.environ.get("CSTR_CHAIN_TILES", "2,2,2,2,1").split(","))
 
 
+# TD3's class-default nets are [400, 300]; A/B on MI355X (bench --algo td3): 2,2,2,2,1 0.0888 ms, 2,4,2,2,1 0.0916, 4,4,2,2,1 0.0936
+TD3_TILES = tuple(int(v) for v in os.environ.get("CSTR_CHAIN_TILES_TD3", "2,2,2,2,1").split(","))
+
+
 def _q_layers(qnet: nn.Sequential):
     lin = [m for m in qnet if isinstance(m, nn.Linear)]
     return tuple((m.weight, m.bias) for m in lin)
@@ -72,7 +76,7 @@ class SacChain:
         c = model.critic.q_networks[0]
         self.cH1, self.cH2 = c[0].out_features, c[2].out_features
         t_act, t_q4, t_q2, t_qb, t_ab = TILES  # (a wave's share of the reduction must fit in registers: fewer tiles for wide layers)
-        self.t_act, self.t_q4, self.t_q2 = _pick_tiles(self.aH1, t_act), _pick_tiles(self.cH1, t_q4), _pick_tiles(self.cH1, t_q2)
+        self.t_act, self.t_q4, self.t_q2 = _pick_tiles(self.aH1, t_act, True), _pick_tiles(self.cH1, t_q4, True), _pick_tiles(self.cH1, t_q2, True)
         self.t_qb, self.t_ab = _pick_tiles(self.cH2, t_qb), _pick_tiles(self.aH2, t_ab)
         self.actor = hip_ops.sac_actor_desc(self.D, self.A, l1.weight, l1.bias, l2.weight, l2.bias, fa._hw, fa._hb)
         self.actor_layers = (l1, l2)
@@ -225,10 +229,10 @@ class SacChain:
                                             ent_coef=ent_coef.detach().clone(), log_prob=self.logp_pi.clone())
 
 
-def _pick_tiles(kdim: int, want: int) -> int:
+def _pick_tiles(kdim: int, want: int, forward: bool = False) -> int:
     """The largest tile count <= `want` whose per-wave share of a K = kdim reduction fits in registers."""
     for t in (4, 2, 1):
-        if t <= want and hip_ops.chain_tiles_ok(kdim, t):
+        if t <= want and hip_ops.chain_tiles_ok(kdim, t, forward):
             return t
     return 1
 
@@ -277,8 +281,8 @@ class Td3Chain:
         self.aH1, self.aH2 = a1.out_features, a2.out_features
         c = model.critic.q_networks[0]
         self.cH1, self.cH2 = c[0].out_features, c[2].out_features
-        t_act, t_q4, t_q2, t_qb, t_ab = TILES
-        self.t_act, self.t_q4, self.t_q1 = _pick_tiles(self.aH1, t_act), _pick_tiles(self.cH1, t_q4), _pick_tiles(self.cH1, t_q2)
+        t_act, t_q4, t_q2, t_qb, t_ab = TD3_TILES
+        self.t_act, self.t_q4, self.t_q1 = _pick_tiles(self.aH1, t_act, True), _pick_tiles(self.cH1, t_q4, True), _pick_tiles(self.cH1, t_q2, True)
         self.t_qb, self.t_ab = _pick_tiles(self.cH2, t_qb), _pick_tiles(self.aH2, t_ab)
         self.actor = hip_ops.sac_actor_desc(self.D, self.A, a1.weight, a1.bias, a2.weight, a2.bias, a3.weight, a3.bias)
         self.tactor = hip_ops.sac_actor_desc(self.D, self.A, t1.weight, t1.bias, t2.weight, t2.bias, t3.weight, t3.bias)

@@ -900,15 +900,15 @@ def neg_mean_loss(q, gq, loss_out=None, loss_sum=None):
 
 # ---- row-chain kernels (csrc/cstr_chain.hip, include/cstr_rl_hip.h "row-chain kernels") -------------------------------------------
 def chain_supported(h1: int, h2: int, batch: int) -> bool:
-    """Widths multiples of 4; forward launches hold a 16 x (H1 + 4) panel and W1 staged as [H1][16] in 64 KB of LDS."""
+    """Widths multiples of 4; forward launches hold a 16 x (H1 + 4) panel and W1 staged as [H1][8 or 16] in 64 KB of LDS."""
     return (16 <= h1 <= nv.CHAIN_MAX_WIDTH and 16 <= h2 <= nv.CHAIN_MAX_WIDTH and h1 % 4 == 0 and h2 % 4 == 0 and 4 * (1664 + 16 * (h1 + 4) + 16 * h1) <= 65536
             and 16 <= batch <= 1024 and batch % 16 == 0)
 
 
-def chain_tiles_ok(kdim: int, tiles: int) -> bool:
-    """A wave holds at most 16 16-wide chunks of the reduction in registers."""
+def chain_tiles_ok(kdim: int, tiles: int, forward: bool = False) -> bool:
+    """A wave holds at most 16 (forward chains: 32) 16-wide chunks of the reduction in registers."""
     s = 4 // tiles
-    return -(-((kdim + 15) // 16) // s) <= 16
+    return -(-((kdim + 15) // 16) // s) <= (32 if forward else 16)
 
 
 def chain_colgroups(width: int, tiles: int) -> int:
@@ -946,7 +946,7 @@ def sac_actor_chain_fwd(actor: "nv.SacActorNet", batch: int, x_data, x_pi, x_nex
     _opt(a_h1, "a_h1", (batch, actor.h1), th.float32), _opt(a_h2, "a_h2", (batch, actor.h2), th.float32)
     _chk(head_part, "head_part", (ncg, m, head_n), th.float32)
     _opt(eps_all, "eps_all", (m, actor.act_dim), th.float32), _opt(head_rng_ctl, "head_rng_ctl", (nv.RNG_CTL_WORDS,), th.int64)
-    if not chain_tiles_ok(actor.h1, tiles):
+    if not chain_tiles_ok(actor.h1, tiles, forward=True):
         raise ValueError(f"tiles = {tiles}: a wave's share of K = {actor.h1} does not fit")
     if sample_idx is not None:
         _chk(sample_idx, "sample_idx", (2, batch), th.int32)

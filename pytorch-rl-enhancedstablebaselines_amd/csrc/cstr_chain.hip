@@ -35,7 +35,7 @@ constexpr int SM_RED = SM_PART + 3 * 64 * 4;        // red[4 tiles][16 rows][8]:
 constexpr int SM_XS = SM_RED + 4 * 16 * 8;          // xs[16][16]: the row group's input rows
 constexpr int SM_GS = SM_XS + 16 * 16;              // gs[16][8]: per-row gradients of the prologue
 constexpr int SM_PANEL = SM_GS + 16 * 8;            // panel[16][K + 4]: A operand of the wide layer
-static size_t chain_lds_bytes(int k, bool with_w1) { return (size_t)(SM_PANEL + 16 * (k + 4) + (with_w1 ? 16 * k : 0)) * sizeof(float); }
+static size_t chain_lds_bytes(int k, int w1_pad) { return (size_t)(SM_PANEL + 16 * (k + 4) + w1_pad * k) * sizeof(float); }
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc_of(const float *base, const int64_t floats)
 {
@@ -226,28 +226,37 @@ __device__ __forceinline__ void sample_action(const float mu, const float raw, c
 // h1 = relu(x W1^T + b1) for the row group's 16 rows, K = KIN <= 12 inputs: ONE 16-wide k chunk. The inputs sit in xs[16][16]
 // (LDS; column KIN holds 1.0, the rest zeros) and W1 is staged as w1s[H1][16] with b1 in column KIN, so the bias rides in the k
 // chain and a 16 x 16 tile is 4 MFMAs + 4 ReLU + 4 LDS stores; the wave takes the tiles wave, wave + 4, ...
+// (inputs + the bias column that fit in 8 floats -- obs 4 / act 2 -- are staged 8 wide: half the LDS, so more workgroups per CU;
+// the upper half of the 16-wide k chunk is zero in registers)
+template <int KIN>
+constexpr int l1_pad() { return KIN + 1 <= 8 ? 8 : 16; }
+
 template <int KIN>
 __device__ __forceinline__ void stage_w1(float *w1s, const float *w1, const float *b1, const int h1)
 {
+    constexpr int KP = l1_pad<KIN>();
     for (int c = threadIdx.x; c < h1; c += CH_THREADS) {
-        float w[16];
+        float w[KP];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) w[k] = k < KIN ? w1[(int64_t)c * KIN + k] : 0.0f;
+        for (int k = 0; k < KP; ++k) w[k] = k < KIN ? w1[(int64_t)c * KIN + k] : 0.0f;
         w[KIN] = b1[c];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) *reinterpret_cast<float4 *>(w1s + c * 16 + 4 * q) = make_float4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
+        for (int q = 0; q < KP / 4; ++q) *reinterpret_cast<float4 *>(w1s + c * KP + 4 * q) = make_float4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
     }
 }
 
+template <int KP>
 __device__ __forceinline__ void layer1_mfma(const float *xs, const float *w1s, float *panel, const int ld, const int h1)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, h = lane >> 4;
-    const float4 xa = *reinterpret_cast<const float4 *>(xs + r * 16 + 4 * h);
+    const bool hk = 4 * h < KP;  // this lane's quad of the k chunk exists in the staged images
+    const float4 zero4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    const float4 xa = hk ? *reinterpret_cast<const float4 *>(xs + r * 16 + 4 * h) : zero4;
     const int n_tiles = (h1 + 15) / 16;
     for (int t0 = wave; t0 < n_tiles; t0 += 4 * CH_WAVES) {  // four tiles in flight: their LDS reads, MFMA chains and stores interleave
         float4 wb[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) wb[i] = *reinterpret_cast<const float4 *>(w1s + min(16 * (t0 + CH_WAVES * i) + r, h1 - 1) * 16 + 4 * h);
+        for (int i = 0; i < 4; ++i) wb[i] = hk ? *reinterpret_cast<const float4 *>(w1s + min(16 * (t0 + CH_WAVES * i) + r, h1 - 1) * KP + 4 * h) : zero4;
         f32x4 acc0[4], acc1[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -366,7 +375,7 @@ __global__ __launch_bounds__(CH_THREADS) void sac_actor_chain_fwd_kernel(const A
     lds_barrier();
     CH_STAMP(0, 2);
     // (c) layer 1, recomputed by every workgroup of the row group -> panel
-    layer1_mfma(xs, w1s, panel, ld, H1);
+    layer1_mfma<l1_pad<D>()>(xs, w1s, panel, ld, H1);
     lds_barrier();
     CH_STAMP(0, 3);
     // (d) layer 2: this wave's 16 x 16 tile (its share of K), (e) split-K combine
@@ -531,7 +540,7 @@ __global__ __launch_bounds__(CH_THREADS) void q_chain_fwd_kernel(const QFwdArgs 
     lds_barrier();
     CH_STAMP(1, 2);
     // (c) layer 1 recomputed on the matrix cores
-    layer1_mfma(xs, w1s, panel, ld, H1);
+    layer1_mfma<l1_pad<W>()>(xs, w1s, panel, ld, H1);
     lds_barrier();
     CH_STAMP(1, 3);
     f32x4 acc = tile_mma<NQ>(panel, ld, H1, bq, ks, S);
@@ -961,10 +970,10 @@ __global__ __launch_bounds__(CH_THREADS) void sac_actor_chain_bwd_kernel(const A
 }
 
 // chunks of 16 along the reduction a wave owns, rounded up to an instantiated size (0: not covered)
-static int nq_for(int kdim, int tiles)
+static int nq_for(int kdim, int tiles, int nq_max = 16)
 {
     const int s = CH_WAVES / tiles, nch = (kdim + 15) / 16, per = (nch + s - 1) / s;
-    return per <= 4 ? 4 : per <= 8 ? 8 : per <= 16 ? 16 : 0;
+    return per <= 4 ? 4 : per <= 8 ? 8 : per <= 16 ? 16 : (per <= 32 && nq_max >= 32) ? 32 : 0;
 }
 
 static bool chain_dims_ok(int h1, int h2, int64_t batch, int tiles)
@@ -982,8 +991,15 @@ static int chain_layout(int obs_dim, int act_dim)
     do {                                                                                           \
         if ((NQV) == 4) KERNEL<D_, A_, 4><<<GRID, CH_THREADS, LDS, STREAM>>>(ARGS);                \
         else if ((NQV) == 8) KERNEL<D_, A_, 8><<<GRID, CH_THREADS, LDS, STREAM>>>(ARGS);           \
-        else KERNEL<D_, A_, 16><<<GRID, CH_THREADS, LDS, STREAM>>>(ARGS);                          \
+        else if ((NQV) == 16) KERNEL<D_, A_, 16><<<GRID, CH_THREADS, LDS, STREAM>>>(ARGS);         \
+        else KERNEL<D_, A_, NQ_TOP_##KERNEL><<<GRID, CH_THREADS, LDS, STREAM>>>(ARGS);             \
     } while (0)
+// the widest per-wave share instantiated per kernel: the forward chains (B operand = 16-byte quads) also exist with 32 chunks (wide
+// first hidden layers with 4 tiles per workgroup: TD3's / MADDPG's 400); the backward chains stop at 16
+#define NQ_TOP_sac_actor_chain_fwd_kernel 32
+#define NQ_TOP_q_chain_fwd_kernel 32
+#define NQ_TOP_q_chain_bwd_kernel 16
+#define NQ_TOP_sac_actor_chain_bwd_kernel 16
 #define CHAIN_DISPATCH(KERNEL, LAY, NQV, GRID, LDS, STREAM, ARGS)                                  \
     do {                                                                                           \
         if ((LAY) == 0) CHAIN_NQ(KERNEL, 4, 2, NQV, GRID, LDS, STREAM, ARGS);                      \
@@ -1041,8 +1057,8 @@ extern "C" int cstr_sac_actor_chain_fwd_f32(const cstr_sac_actor_t *actor, const
     a.a_h1 = a_h1; a.a_h2 = a_h2; a.head_part = head_part; a.head_rng_ctl = head_rng_ctl; a.head_rng_offset = head_rng_offset; a.eps_all = eps_all;
     a.rows_mode = rows_mode; a.head_n = head_n;
     const dim3 grid((unsigned)((actor->h2 + 16 * tiles - 1) / (16 * tiles)), (unsigned)((rows_mode == CSTR_CHAIN_ROWS_PAIR ? 2 : 1) * batch / 16));
-    const size_t lds = chain_lds_bytes(actor->h1, true);
-    const int nq = nq_for(actor->h1, tiles), lay = chain_layout(actor->obs_dim, actor->act_dim);
+    const size_t lds = chain_lds_bytes(actor->h1, actor->obs_dim + 1 <= 8 ? 8 : 16);
+    const int nq = nq_for(actor->h1, tiles, 32), lay = chain_layout(actor->obs_dim, actor->act_dim);
     if (!nq || lds > CHAIN_LDS_LIMIT) return CSTR_E_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
     CHAIN_DISPATCH(sac_actor_chain_fwd_kernel, lay, nq, grid, lds, s, a);
@@ -1078,8 +1094,8 @@ extern "C" int cstr_q_chain_fwd_f32(const cstr_chain_net_t *nets, int n_nets, in
     }
     a.n_nets = n_nets; a.h1 = h1; a.h2 = h2; a.batch = (int)batch; a.tiles = tiles;
     const dim3 grid((unsigned)((h2 + 16 * tiles - 1) / (16 * tiles)), (unsigned)(batch / 16), (unsigned)n_nets);
-    const size_t lds = chain_lds_bytes(h1, true);
-    const int nq = nq_for(h1, tiles), lay = chain_layout(obs_dim, w_in - obs_dim);
+    const size_t lds = chain_lds_bytes(h1, w_in + 1 <= 8 ? 8 : 16);
+    const int nq = nq_for(h1, tiles, 32), lay = chain_layout(obs_dim, w_in - obs_dim);
     if (!nq || lay < 0 || lds > CHAIN_LDS_LIMIT) return CSTR_E_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
     CHAIN_DISPATCH(q_chain_fwd_kernel, lay, nq, grid, lds, s, a);
@@ -1109,7 +1125,7 @@ extern "C" int cstr_q_chain_bwd_f32(const cstr_chain_net_t *nets, int n_nets, co
     a.n_nets = n_nets; a.h1 = h1; a.h2 = h2; a.tiles = tiles;
     a.dz2 = dz2; a.dz1 = dz1; a.gact_part = gact_part;
     const dim3 grid((unsigned)((h1 + 16 * tiles - 1) / (16 * tiles)), (unsigned)(root->batch / 16 + 1), (unsigned)n_nets);
-    const size_t lds = chain_lds_bytes(h2, false);
+    const size_t lds = chain_lds_bytes(h2, 0);
     const int nq = nq_for(h2, tiles), lay = chain_layout(obs_dim, w_in - obs_dim);
     if (!nq || lay < 0 || lds > CHAIN_LDS_LIMIT) return CSTR_E_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
@@ -1134,7 +1150,7 @@ extern "C" int cstr_sac_actor_chain_bwd_f32(const cstr_sac_actor_t *actor, const
     a.x_pi = x_pi; a.params = params; a.eps = eps; a.a_h1 = a_h1; a.a_h2 = a_h2;
     a.g_params = g_params; a.dz2 = dz2; a.dz1 = dz1; a.batch = (int)batch; a.tiles = tiles; a.kind = kind;
     const dim3 grid((unsigned)((actor->h1 + 16 * tiles - 1) / (16 * tiles)), (unsigned)(batch / 16));
-    const size_t lds = chain_lds_bytes(actor->h2, false);
+    const size_t lds = chain_lds_bytes(actor->h2, 0);
     const int nq = nq_for(actor->h2, tiles), lay = chain_layout(actor->obs_dim, actor->act_dim);
     if (!nq || lds > CHAIN_LDS_LIMIT) return CSTR_E_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;

@@ -154,3 +154,32 @@ def test_rollout_entry_points_reject_bad_arguments_on_the_host():
     assert gl(null, fake, 1) == -1 and gl(fake, null, 1) == -1 and gl(fake, fake, 7) == -1 and gl(fake, fake, 1, ring_ctl=null) == -1
     assert gl(fake, C.c_void_p(0x1004), 1) == -1                   # weight rows are read as 16-byte vectors
     assert gl(fake, fake, 1, batch=1 << 20) == -2 and gl(fake, fake, 1, ring_=odd) == -2
+
+
+def test_chain_entry_points_reject_bad_arguments_on_the_host():
+    """The row-chain ABI (include/cstr_rl_hip.h, "row-chain kernels") validates shapes, layouts and pointers before any launch."""
+    lib = nv.lib()
+    null, fake = C.c_void_p(None), C.c_void_p(0x1000)
+    actor = nv.SacActorNet(4, 2, 256, 256, 0x1000, 0x1000, 0x1000, 0x1000, 0x1000, 0x1000)
+    args = lambda a, batch, tiles, mode=0, hn=4: (C.byref(a), null, null, 0, null, C.c_int64(batch), null, fake, fake, null, null, fake, fake, fake,  # noqa: E731
+                                                     null, C.c_uint64(0), null, mode, hn, tiles, null)
+    assert lib.cstr_sac_actor_chain_fwd_f32(*args(nv.SacActorNet(5, 2, 256, 256, 0x1000, 0x1000, 0x1000, 0x1000, 0x1000, 0x1000), 256, 2)) == -2  # layout
+    assert lib.cstr_sac_actor_chain_fwd_f32(*args(actor, 250, 2)) == -2        # batch not a multiple of 16
+    assert lib.cstr_sac_actor_chain_fwd_f32(*args(actor, 256, 3)) == -2        # tiles
+    assert lib.cstr_sac_actor_chain_fwd_f32(*args(actor, 256, 2, mode=7)) == -1
+    assert lib.cstr_sac_actor_chain_fwd_f32(*args(actor, 256, 2, hn=3)) == -1  # head outputs: A or 2A
+    wide = nv.SacActorNet(4, 2, 640, 256, 0x1000, 0x1000, 0x1000, 0x1000, 0x1000, 0x1000)
+    assert lib.cstr_sac_actor_chain_fwd_f32(*args(wide, 256, 2)) == -2         # wider than CSTR_CHAIN_MAX_WIDTH
+    net = nv.ChainNet(*([0x1000] * 10), 0, 0)
+    nets = (nv.ChainNet * 1)(net)
+    assert lib.cstr_q_chain_fwd_f32(nets, 5, 6, 4, 256, 256, C.c_int64(256), null, 2, null) == -1   # more than 4 networks
+    assert lib.cstr_q_chain_fwd_f32(nets, 1, 6, 3, 256, 256, C.c_int64(256), null, 2, null) == -2   # (3, 3) is not a layout
+    bad_role = (nv.ChainNet * 1)(nv.ChainNet(*([0x1000] * 10), 2, 0))
+    assert lib.cstr_q_chain_fwd_f32(bad_role, 1, 6, 4, 256, 256, C.c_int64(256), null, 2, null) == -1  # a finalising role without `fin`
+    root = nv.ChainRoot()
+    root.mode, root.batch, root.n_parts = 9, 256, 4
+    assert lib.cstr_q_chain_bwd_f32(nets, 1, C.byref(root), 6, 4, 256, 256, null, null, null, 2, null) == -1  # mode
+    root.mode = 1
+    assert lib.cstr_q_chain_bwd_f32(nets, 1, C.byref(root), 6, 4, 256, 256, null, null, null, 2, null) == -1  # TD root needs two networks
+    assert lib.cstr_sac_actor_chain_bwd_f32(C.byref(actor), null, 2, 8, fake, fake, fake, fake, fake, fake, fake, fake, fake, C.c_int64(256), 0, 1, null) == -1
+    assert lib.cstr_linear_bwd_weight_adam_sets_f32(null, 1, null, 1, null, 0, null) == -1

@@ -914,34 +914,49 @@ def test_ou_action_noise_on_the_legacy_stream_matches_numpy(graph):
 @pytest.mark.parametrize("cfg", [
     dict(ent_coef=0.2), dict(ent_coef="auto_0.5", target_update_interval=2, gradient_steps=3), dict(tau=0.02, gamma=0.9, batch_size=37),
     dict(policy_kwargs=dict(net_arch=dict(pi=[48], qf=[40, 24, 16]))), dict(policy_kwargs=dict(net_arch=[300, 200]), learning_rate=1e-3),
-    dict(target_entropy=-0.5, policy_kwargs=dict(net_arch=[64, 64], activation_fn=th.nn.Tanh))])
-def test_sac_fused_path_equals_stock_aten_path_across_configurations(cfg):
+    dict(target_entropy=-0.5, policy_kwargs=dict(net_arch=[64, 64], activation_fn=th.nn.Tanh)),
+    # the chain kernels' other layouts and ragged widths: obs 8 / act 2, obs 8 / act 4 (eight head outputs: two k steps in the actor
+    # backward's dz2), widths that are not multiples of 16, asymmetric actor / critic widths, every tiles setting
+    dict(env_kw=dict(obs_dim=8), policy_kwargs=dict(net_arch=[72, 40])),
+    dict(env_kw=dict(obs_dim=8, twin=True), policy_kwargs=dict(net_arch=dict(pi=[48, 36], qf=[80, 52])), batch_size=48),
+    dict(env_kw=dict(obs_dim=8, twin=True), ent_coef=0.1, chain_tiles=(1, 1, 1, 1, 1)),
+    dict(chain_tiles=(4, 4, 4, 4, 4), batch_size=128), dict(chain_tiles=(1, 2, 4, 1, 2), policy_kwargs=dict(net_arch=[128, 96]))])
+def test_sac_fused_path_equals_stock_aten_path_across_configurations(cfg, monkeypatch):
     """The fused learner (MFMA Linear kernels, HIP heads, flat-arena updates) against the stock-ATen evaluation of the same
     statements -- which the golden tests pin to the reference at the class defaults -- over the constructor space: fixed /
     initialised entropy coefficient, several gradient steps per call, delayed target updates, ragged batch, asymmetric and
     deeper networks, Tanh activations. Same ring, same index stream, same (teacher-forced) noise: weights must agree."""
-    from core.common import legacy_rng
+    from core.common import chain, legacy_rng
     from core.common.vec_env import CSTRVecEnv
     from core.sac import SAC
 
     cfg = dict(cfg)
     steps = cfg.pop("gradient_steps", 1)
+    env_kw = cfg.pop("env_kw", {})
+    if "chain_tiles" in cfg:
+        monkeypatch.setattr(chain, "TILES", cfg.pop("chain_tiles"))
     B = cfg.setdefault("batch_size", 64)
     kw = dict(policy_kwargs=dict(net_arch=[64, 64]))
     kw.update(cfg)
     models = []
     for fused_path in (True, False):
-        model = SAC("MlpPolicy", CSTRVecEnv(16), seed=7, buffer_size=16 * 32, learning_starts=10**9, **kw)
+        model = SAC("MlpPolicy", CSTRVecEnv(16, **env_kw), seed=7, buffer_size=16 * 32, learning_starts=10**9, **kw)
         model.learn(16 * 20)  # warm-up only: uniform actions from the seeded space -> identical rings
         assert model.fused_learner
         model.fused_learner = fused_path
         models.append(model)
     a, b = models
+    act_dim = a.action_space.shape[0]
+    relu = kw["policy_kwargs"].get("activation_fn", th.nn.ReLU) is th.nn.ReLU
+    two_layer = all(len(v) == 2 for v in ([kw["policy_kwargs"]["net_arch"]] if isinstance(kw["policy_kwargs"]["net_arch"], list)
+                                          else kw["policy_kwargs"]["net_arch"].values()))
+    if relu and two_layer and B % 16 == 0:  # these configurations run on the row-chain kernels
+        assert a._chain_for(B) is not None
     for name in ("observations", "next_observations", "actions", "rewards", "dones"):
         assert th.equal(getattr(a.replay_buffer, name), getattr(b.replay_buffer, name))
     g = th.Generator().manual_seed(0)
     for call in range(3):
-        eps = [th.randn(B, 2, generator=g) for _ in range(2 * steps)]
+        eps = [th.randn(B, act_dim, generator=g) for _ in range(2 * steps)]
         for m in (a, b):
             m.actor.action_dist.eps_queue = [e.clone() for e in eps]
             legacy_rng.seed(100 + call, m.device)
@@ -950,6 +965,11 @@ def test_sac_fused_path_equals_stock_aten_path_across_configurations(cfg):
     for (n1, p1), (_, p2) in zip(a.policy.named_parameters(), b.policy.named_parameters()):
         scale = max(float(p2.detach().abs().max()), 1e-3)
         assert float((p1 - p2).detach().abs().max()) < 2e-5 * scale + 2e-6, n1
+    # the optimiser state as well (the chain path updates it inside the dW / db launch)
+    for oa, ob in ((a.actor.optimizer, b.actor.optimizer), (a.critic.optimizer, b.critic.optimizer)):
+        assert oa.step_count == ob.step_count == 3 * steps
+        assert float((oa.exp_avg - ob.exp_avg).abs().max()) < 1e-5 * max(float(ob.exp_avg.abs().max()), 1e-6) + 1e-9
+        assert float((oa.exp_avg_sq - ob.exp_avg_sq).abs().max()) < 1e-4 * max(float(ob.exp_avg_sq.abs().max()), 1e-12)
     if a.ent_coef_optimizer is not None:
         assert abs(float(a.log_ent_coef.detach()) - float(b.log_ent_coef.detach())) < 1e-6
     assert a._n_updates == b._n_updates == 3 * steps
@@ -1222,3 +1242,44 @@ def test_logged_values_with_eight_iterations_per_graph_equal_one_per_graph(algo)
         keys = [k for k in ("train/critic_loss", "train/actor_loss", "train/ent_coef", "train/ent_coef_loss", "train/n_updates") if k in lv]
         out.append({k: float(lv[k]) for k in keys})
     assert out[0] == out[1] and len(out[0]) >= 3, out
+
+
+def test_a_capture_that_fails_inside_the_gradient_step_leaves_no_debts(monkeypatch):
+    """the one-launch rollout leaves host-side debts behind (indices "drawn" by a launch that was only recorded, a Philox
+    advance for a consumer that was never reached). If the recorded body raises between the rollout launch and the first sample, the
+    eager fallback must not gather with stale indices or advance the ring / the Philox offset twice: after the fallback the ring
+    position, the add counter and the sampler stream are what an eager run from the same seed has."""
+    import warnings
+
+    from core.common import legacy_rng
+    from core.common.vec_env import CSTRVecEnv
+    from core.sac import SAC
+
+    N, iters = 128, 12
+    outs = []
+    for broken in (True, False):
+        model = SAC("MlpPolicy", CSTRVecEnv(N), seed=5, batch_size=64, buffer_size=N * 8, learning_starts=100, policy_kwargs=dict(net_arch=[64, 64]))
+        model.enable_graph_capture(broken)
+        if broken:
+            orig = model._train_device_only
+
+            def failing(gradient_steps, batch_size):
+                if th.cuda.is_current_stream_capturing():
+                    raise RuntimeError("injected failure between the rollout launch and the first sample")
+                return orig(gradient_steps, batch_size)
+
+            monkeypatch.setattr(model, "_train_device_only", failing)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            model.learn(N * iters)
+        th.cuda.synchronize()
+        if broken:
+            assert model._graph_error is not None and "injected" in model._graph_error and not model._graph_enabled
+            assert model.replay_buffer._predrawn is None and model._rng_advance is None
+        outs.append(dict(ctl=model.replay_buffer.ring.ctl.cpu().numpy().copy(), mt=legacy_rng.global_stream(model.device).cpu().numpy().copy(),
+                         n=model._n_updates, steps=model.num_timesteps, rng=model._fast_actor.rng_ctl.cpu().numpy()[:2].copy()))
+    a, b = outs
+    assert a["n"] == b["n"] == iters and a["steps"] == b["steps"]
+    np.testing.assert_array_equal(a["ctl"], b["ctl"])
+    np.testing.assert_array_equal(a["mt"], b["mt"])
+    np.testing.assert_array_equal(a["rng"], b["rng"])
