@@ -26,7 +26,8 @@ NAMES = ["entry", "prologue", "barrier1", "panel", "mfma", "combine", "partials"
 
 if __name__ == "__main__":
     B = 256
-    model = SAC("MlpPolicy", CSTRVecEnv(4096), seed=0, batch_size=B)
+    arch = [int(v) for v in os.environ.get("ARCH", "256,256").split(",")]
+    model = SAC("MlpPolicy", CSTRVecEnv(4096), seed=0, batch_size=B, policy_kwargs=dict(net_arch=arch))
     model.learn(4096 * 4)
     fns = chain_launches(model, B)
     lib = nv.lib()
@@ -58,5 +59,6 @@ if __name__ == "__main__":
         row["entry_spread_ns"] = int((t0.max() - launch0) / ghz)
         row["workgroups"] = int(live.sum())
         out[name] = row
-        print(name, json.dumps(row))
-    json.dump(out, open(os.path.join(ROOT, "gpurun_out", "r03_chain_phase_stamps.json"), "w"), indent=1)
+        print(name, {k: (int(v["median_ns"] / 10) if isinstance(v, dict) else v) for k, v in row.items() if k != "entry_spread_ns"})
+    tag = "" if arch == [256, 256] else "_" + "x".join(str(v) for v in arch)
+    json.dump(out, open(os.path.join(ROOT, "gpurun_out", f"r03_chain_phase_stamps{tag}.json"), "w"), indent=1)
