@@ -546,7 +546,7 @@ int cstr_linear_bwd_weight_adam_sets_f32(const cstr_wgrad_adam_set_t *sets, int 
  * SAC.train (core/sac/sac.py:215-287) = 10 launches instead of 20; everything is deterministic (no float atomics).
  * Networks: create_mlp(in, out, [H1, H2], ReLU) (core/common/torch_layers.py:110-183); H1, H2 multiples of 4, <= 512; batch a
  * multiple of 16, <= 1024; (obs_dim, act_dim) as the ring's layouts. `tiles` = 16-column tiles per workgroup (1, 2 or 4). */
-#define CSTR_CHAIN_MAX_NETS 4
+#define CSTR_CHAIN_MAX_NETS 16
 #define CSTR_CHAIN_MAX_WIDTH 512
 
 /* One Q network Linear(W, H1)-ReLU-Linear(H1, H2)-ReLU-Linear(H2, 1) (core/common/policies.py:960-987) of a chain launch. */
@@ -613,7 +613,8 @@ typedef struct cstr_sac_head_fin {
     float *params, *logp_pi, *logp_next; /* Gaussian head: [B][2A], [B], [B] */
 } cstr_sac_head_fin_t;
 
-/* Forward of n_nets <= 4 Q networks on `batch` rows each in ONE launch: layer 1 recomputed per workgroup (K = W <= 12), layer 2 one
+/* Forward of n_nets <= 16 Q networks on `batch` rows each in ONE launch (16: every agent's critic and target critic of a 4-agent MADDPG
+ * step without a policy update, core/maddpg/maddpg.py:146-164): layer 1 recomputed per workgroup (K = W <= 12), layer 2 one
  * MFMA column group per workgroup, head as partial sums q_part [n_colgroups][batch]. SAC / TD3 critic step: nets 0, 1 = the critic on
  * x_data, nets 2, 3 = the target on x_next (core/sac/sac.py:250, :258; core/td3/td3.py:173, :179); actor loss: the critic on x_pi
  * (:273). `fin` (or NULL): the SAC actor's pending head (roles above). */
@@ -629,8 +630,8 @@ int cstr_q_chain_fwd_f32(const cstr_chain_net_t *nets, int n_nets, int w_in, int
 typedef struct cstr_chain_root {
     int32_t mode, batch;
     float gamma, scale;
-    const float *q_part[CSTR_CHAIN_MAX_NETS]; /* nets 0, 1: q1 / q2 (the differentiated networks); 2, 3: q1_t / q2_t (mode 1) */
-    const float *b3[CSTR_CHAIN_MAX_NETS];
+    const float *q_part[4]; /* nets 0, 1: q1 / q2 (the differentiated networks); 2, 3: q1_t / q2_t (mode 1) */
+    const float *b3[4];
     int32_t n_parts, reserved;
     const float *next_logp, *rew, *done;  /* mode 1 */
     const float *ent_coef;                /* [1]: mode 1 without alpha part, mode 2 */

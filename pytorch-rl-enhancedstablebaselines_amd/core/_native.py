@@ -85,7 +85,7 @@ class PolicyMlp(C.Structure):
                 ("b2", C.c_void_p), ("w3", C.c_void_p), ("b3", C.c_void_p), ("w2_swizzled", C.c_void_p)]
 
 
-CHAIN_MAX_NETS, CHAIN_MAX_WIDTH = 4, 512
+CHAIN_MAX_NETS, CHAIN_MAX_WIDTH = 16, 512
 CHAIN_ROLE_PLAIN, CHAIN_ROLE_STORE_PI, CHAIN_ROLE_NEXT, CHAIN_ROLE_NEXT_STORE, CHAIN_ROLE_PI = 0, 1, 2, 3, 4
 CHAIN_ROWS_PAIR, CHAIN_ROWS_NEXT, CHAIN_ROWS_OBS = 0, 1, 2
 CHAIN_HEAD_GAUSSIAN, CHAIN_HEAD_DETERMINISTIC = 0, 1

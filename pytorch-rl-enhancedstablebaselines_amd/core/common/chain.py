@@ -392,3 +392,127 @@ class Td3Chain:
         if model.debug_capture:
             model.last_train_tensors = dict(target_q=model._target_q.clone(), current_q=[self.q_out[0].clone().view(B, 1), self.q_out[1].clone().view(B, 1)],
                                             critic_loss=c_out.clone(), actor_loss=a_out.clone() if actor_done else None)
+
+
+class MaddpgCriticChain:
+    """The critic steps of MADDPG.train (core/maddpg/maddpg.py:146-164) on the chain kernels. Every agent's twin critic reads the SAME joint
+    input (cat(all observations, all actions)) and its target the same next input, so
+      * one agent's critic step = Q chain forward (critic + target, 4 networks) -> Q backward chain (TD target + loss inside) -> dW / db +
+        Adam: 3 launches instead of 7;
+      * a step WITHOUT a policy update = ONE forward launch for all agents' 4 x n_agents networks, a backward launch per agent and one
+        dW / db + Adam launch per two agents.
+    Centralised critics only (IDDPG's local critics read per-agent inputs and stay on the per-layer path)."""
+
+    @staticmethod
+    def supported(model, batch_size: int) -> bool:
+        C = model.critic
+        if not (USE_CHAIN and fused.USE_FUSED_LINEAR and model.fused_learner and not C.local and C.n_critics == 2 and 4 * model.n_agents <= nv.CHAIN_MAX_NETS):
+            return False
+        from core.common.arena import FlatAdam
+
+        if not all(isinstance(o, FlatAdam) for o in C.optimizer_list):
+            return False
+        for nets in list(C.q_networks_list) + list(model.critic_target.q_networks_list):
+            for q in nets:
+                mods = list(q)
+                if len(mods) != 5 or not all(isinstance(mods[i], nn.Linear) for i in (0, 2, 4)) or not all(isinstance(mods[i], nn.ReLU) for i in (1, 3)):
+                    return False
+                if mods[4].out_features != 1:
+                    return False
+        c1, c2 = C.q_networks_list[0][0][0], C.q_networks_list[0][0][2]
+        d, a = model.observation_space.shape[0], model.action_space.shape[0]
+        if (d, a) not in hip_ops.LAYOUTS or c1.in_features != d + a:
+            return False
+        return hip_ops.chain_supported(c1.out_features, c2.out_features, batch_size) and all(p.grad is not None for p in C.parameters())
+
+    def __init__(self, model, batch_size: int):
+        dev, B, n = model.device, batch_size, model.n_agents
+        self.B, self.n = B, n
+        self.D, self.A = model.observation_space.shape[0], model.action_space.shape[0]
+        self.W = self.D + self.A
+        c = model.critic.q_networks_list[0][0]
+        self.H1, self.H2 = c[0].out_features, c[2].out_features
+        t_act, t_q4, t_q2, t_qb, t_ab = TD3_TILES
+        self.t_q, self.t_qb = _pick_tiles(self.H1, t_q4, True), _pick_tiles(self.H2, t_qb)
+        self.crit = [[_q_layers(q) for q in nets] for nets in model.critic.q_networks_list]
+        self.targ = [[_q_layers(q) for q in nets] for nets in model.critic_target.q_networks_list]
+        e = lambda *sh: th.empty(*sh, dtype=th.float32, device=dev)  # noqa: E731
+        self.n_q = hip_ops.chain_colgroups(self.H2, self.t_q)
+        self.c_h1, self.c_h2 = e(n, 2, B, self.H1), e(n, 2, B, self.H2)
+        self.q_part = e(n, 4, self.n_q, B)
+        self.q_out, self.gq = e(n, 2, B), e(n, 2, B)
+        self.dz2, self.dz1 = e(n, 2, B, self.H2), e(n, 2, B, self.H1)
+
+    def _nets4(self, i: int, x_cur, x_next):
+        return [hip_ops.chain_net(self.crit[i][0], x_cur, self.c_h1[i, 0], self.c_h2[i, 0], self.q_part[i, 0]),
+                hip_ops.chain_net(self.crit[i][1], x_cur, self.c_h1[i, 1], self.c_h2[i, 1], self.q_part[i, 1]),
+                hip_ops.chain_net(self.targ[i][0], x_next, None, None, self.q_part[i, 2]),
+                hip_ops.chain_net(self.targ[i][1], x_next, None, None, self.q_part[i, 3])]
+
+    def _backward(self, model, i: int, rd, fuse_opt: bool) -> None:
+        B = self.B
+        b3s = [self.crit[i][0][2][1], self.crit[i][1][2][1], self.targ[i][0][2][1], self.targ[i][1][2][1]]
+        root = hip_ops.chain_root("td", B, [self.q_part[i, g] for g in range(4)], b3s, self.n_q, gamma=model.gamma, scale=1.0, rew=rd.rewards,
+                                  done=rd.dones, target_out=model._target_q[i], q_out=self.q_out[i], gq_out=self.gq[i], loss_out=model._loss_now,
+                                  loss_sum=model._loss_sums[f"critic{i}"], adam_advance=[model.critic.optimizer_list[i]] if fuse_opt else ())
+        back = [hip_ops.chain_net(self.crit[i][g], None, self.c_h1[i, g], self.c_h2[i, g]) for g in range(2)]
+        hip_ops.q_chain_bwd(back, root, self.W, self.D, self.H1, self.H2, self.t_qb, dz2=self.dz2[i], dz1=self.dz1[i])
+
+    def _sets(self, i: int, x_cur, fuse_opt: bool, opt_index: int = 0) -> list:
+        B, sets = self.B, []
+        for g in range(2):
+            (w1, b1), (w2, b2), (w3, b3) = self.crit[i][g]
+            if fuse_opt:
+                sets += [(self.dz1[i, g], x_cur, w1, b1, opt_index, None), (self.dz2[i, g], self.c_h1[i, g], w2, b2, opt_index, None),
+                         (self.gq[i, g].view(B, 1), self.c_h2[i, g], w3, b3, opt_index, None)]
+            else:
+                sets += [(self.dz1[i, g], x_cur, w1.grad, b1.grad), (self.dz2[i, g], self.c_h1[i, g], w2.grad, b2.grad),
+                         (self.gq[i, g].view(B, 1), self.c_h2[i, g], w3.grad, b3.grad)]
+        return sets
+
+    @staticmethod
+    def _fuse_opt(model, B: int) -> bool:
+        return USE_WGRAD_ADAM and model.world_size == 1 and B > 32 and not getattr(model, "_force_segment_boundaries", False)
+
+    def captured(self, model, i: int) -> dict:
+        B = self.B
+        return dict(target_q=model._target_q[i].clone(), current_q=[self.q_out[i, 0].clone().view(B, 1), self.q_out[i, 1].clone().view(B, 1)],
+                    critic_loss=model._loss_now.clone(), actor_loss=None)
+
+    def critic_step(self, model, i: int, x_cur, x_next, rd) -> None:
+        """Agent i's critic step (:146-164): 3 launches."""
+        fuse_opt = self._fuse_opt(model, self.B)
+        hip_ops.q_chain_fwd(self._nets4(i, x_cur, x_next), self.W, self.D, self.H1, self.H2, self.B, self.t_q)
+        self._backward(model, i, rd, fuse_opt)
+        opt = model.critic.optimizer_list[i]
+        if fuse_opt:
+            hip_ops.linear_bwd_weight_adam_sets(self._sets(i, x_cur, True), [opt])
+        else:
+            hip_ops.linear_bwd_weight_sets(self._sets(i, x_cur, False))
+            model._allreduce_grads(model.policy.critic_slices[i])
+            opt.step()
+
+    def critic_steps_all(self, model, x_cur, x_next, rd, capture=None) -> None:
+        """Every agent's critic step of an update WITHOUT a policy step: the agents' steps do not depend on each other (no soft update in
+        between), so their 4 x n_agents networks share ONE forward launch; a backward launch per agent; a dW / db + Adam launch per two
+        agents. The same kernels on the same operands as `critic_step`: bit-identical."""
+        fuse_opt = self._fuse_opt(model, self.B)
+        nets = [net for i in range(self.n) for net in self._nets4(i, x_cur, x_next)]
+        hip_ops.q_chain_fwd(nets, self.W, self.D, self.H1, self.H2, self.B, self.t_q)
+        for i in range(self.n):
+            self._backward(model, i, rd, fuse_opt)
+            if capture is not None:
+                capture.append(self.captured(model, i))
+        opts = model.critic.optimizer_list
+        if fuse_opt:
+            for i0 in range(0, self.n, 2):
+                group = list(range(i0, min(i0 + 2, self.n)))
+                sets = [st for k, i in enumerate(group) for st in self._sets(i, x_cur, True, opt_index=k)]
+                hip_ops.linear_bwd_weight_adam_sets(sets, [opts[i] for i in group])
+        else:
+            for i0 in range(0, self.n, 2):
+                group = list(range(i0, min(i0 + 2, self.n)))
+                hip_ops.linear_bwd_weight_sets([st for i in group for st in self._sets(i, x_cur, False)])
+            for i in range(self.n):
+                model._allreduce_grads(model.policy.critic_slices[i])
+            opts[0].step_with(*opts[1:])

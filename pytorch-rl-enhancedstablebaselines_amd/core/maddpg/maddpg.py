@@ -343,6 +343,15 @@ class MADDPG(OffPolicyAlgorithm):
                 shared_next = None if C.local else self.critic_target._input(0, rd.next_observations, next_actions)
         if pb is None:
             shared_cur = None if C.local else C._input(0, rd.observations, rd.actions)
+        cchain = self._critic_chain_for(B) if (pb is not None and shared_next is not None) else None
+        if cchain is not None and BATCH_AGENT_CRITIC_STEPS and n_updates % self.policy_delay != 0:
+            # a step WITHOUT a policy update on the row-chain kernels (core/common/chain.py:MaddpgCriticChain): one forward launch for
+            # every agent's critic and target critic, a backward launch per agent, one dW / db + Adam launch per two agents
+            captured_many = [] if self.debug_capture else None
+            cchain.critic_steps_all(self, shared_cur, shared_next, rd, captured_many)
+            if self.debug_capture:
+                self.last_train_tensors = dict(agents=captured_many, batched_critic_steps=True)
+            return
         if (BATCH_AGENT_CRITIC_STEPS and n_updates % self.policy_delay != 0 and shared_next is not None and B <= fused.LOSS_ROOT_MAX_ROWS
                 and self.n_agents <= hip_ops.nv.MAX_ADAM_SEGS
                 and all(fused.twin_pair_supported(c, t) and fused.loss_root_supported(c) for c, t in zip(self._fast_critics, self._fast_critic_targets))
@@ -372,31 +381,35 @@ class MADDPG(OffPolicyAlgorithm):
         for i in range(self.n_agents):
             x_next = shared_next if shared_next is not None else self.critic_target._input(i, rd.next_observations, next_actions)
             x_cur = shared_cur if shared_cur is not None else C._input(i, rd.observations, rd.actions)
-            if fused.twin_pair_supported(self._fast_critics[i], self._fast_critic_targets[i]):
-                # :154 and :148-151 as ONE four-network chain (three launches instead of six)
-                qs, qs_t = fused.twin_pair_forward(self._fast_critics[i], self._fast_critic_targets[i], x_cur, x_next)
+            if cchain is not None:  # agent i's critic step on the row-chain kernels: 3 launches instead of 7
+                cchain.critic_step(self, i, x_cur, x_next, rd)
+                qs = None
             else:
-                with th.no_grad():  # :148-151
-                    qs_t = self._fast_critic_targets[i].forward_input(x_next, train_params=False)
-                qs = self._fast_critics[i].forward_input(x_cur)  # :154
-            scale = 1.0 if len(qs) == 2 else 0.5
-            root = len(qs) == 2 and qs.stacked is not None and B <= fused.LOSS_ROOT_MAX_ROWS and fused.loss_root_supported(self._fast_critics[i])
-            td_root = None
-            if root:  # TD target (:148-151) + critic loss (:157-159) inside the critic backward's first launch
-                td_root = dict(mode="td", q1_t=qs_t[0], q2_t=qs_t[-1], next_logp=None, rew=rd.rewards, done=rd.dones, ent_coef=None,
-                               gamma=self.gamma, scale=scale, q1=qs[0].detach(), q2=qs[-1].detach(), target_out=self._target_q[i],
-                               loss_out=self._loss_now, loss_sum=self._loss_sums[f"critic{i}"], alpha=None)
-            else:  # TD target + critic loss in one launch
-                hip_ops.td_twin_q_loss(qs_t[0], qs_t[-1], None, rd.rewards, rd.dones, None, self.gamma, qs[0], qs[-1], scale,
-                                       self._target_q[i], gq[0], gq[1], self._loss_now, self._loss_sums[f"critic{i}"])
-            if len(qs) == 2:
-                with fused.loss_root(td_root):
-                    fused.backward_q(qs, gq)  # :162-164
-            else:
-                with fused.deferred_weight_grads():
-                    th.autograd.backward([qs[0]], [gq[0] + gq[1]])
-            self._allreduce_grads(pol.critic_slices[i])
-            C.optimizer_list[i].step()
+                if fused.twin_pair_supported(self._fast_critics[i], self._fast_critic_targets[i]):
+                    # :154 and :148-151 as ONE four-network chain (three launches instead of six)
+                    qs, qs_t = fused.twin_pair_forward(self._fast_critics[i], self._fast_critic_targets[i], x_cur, x_next)
+                else:
+                    with th.no_grad():  # :148-151
+                        qs_t = self._fast_critic_targets[i].forward_input(x_next, train_params=False)
+                    qs = self._fast_critics[i].forward_input(x_cur)  # :154
+                scale = 1.0 if len(qs) == 2 else 0.5
+                root = len(qs) == 2 and qs.stacked is not None and B <= fused.LOSS_ROOT_MAX_ROWS and fused.loss_root_supported(self._fast_critics[i])
+                td_root = None
+                if root:  # TD target (:148-151) + critic loss (:157-159) inside the critic backward's first launch
+                    td_root = dict(mode="td", q1_t=qs_t[0], q2_t=qs_t[-1], next_logp=None, rew=rd.rewards, done=rd.dones, ent_coef=None,
+                                   gamma=self.gamma, scale=scale, q1=qs[0].detach(), q2=qs[-1].detach(), target_out=self._target_q[i],
+                                   loss_out=self._loss_now, loss_sum=self._loss_sums[f"critic{i}"], alpha=None)
+                else:  # TD target + critic loss in one launch
+                    hip_ops.td_twin_q_loss(qs_t[0], qs_t[-1], None, rd.rewards, rd.dones, None, self.gamma, qs[0], qs[-1], scale,
+                                           self._target_q[i], gq[0], gq[1], self._loss_now, self._loss_sums[f"critic{i}"])
+                if len(qs) == 2:
+                    with fused.loss_root(td_root):
+                        fused.backward_q(qs, gq)  # :162-164
+                else:
+                    with fused.deferred_weight_grads():
+                        th.autograd.backward([qs[0]], [gq[0] + gq[1]])
+                self._allreduce_grads(pol.critic_slices[i])
+                C.optimizer_list[i].step()
             critic_loss_now = self._loss_now.clone() if self.debug_capture else None
             actor_loss_now = None
             if n_updates % self.policy_delay == 0:  # :167-185
@@ -443,13 +456,24 @@ class MADDPG(OffPolicyAlgorithm):
                 if self.debug_capture:
                     actor_loss_now = self._loss_now.clone()
             if self.debug_capture:
-                captured.append(dict(target_q=self._target_q[i].clone(), current_q=[q.detach().clone() for q in qs],
-                                     critic_loss=critic_loss_now, actor_loss=actor_loss_now))
+                current = ([cchain.q_out[i, 0].clone().view(B, 1), cchain.q_out[i, 1].clone().view(B, 1)] if qs is None
+                           else [q.detach().clone() for q in qs])
+                captured.append(dict(target_q=self._target_q[i].clone(), current_q=current, critic_loss=critic_loss_now, actor_loss=actor_loss_now))
         if not self.faithful_quirks and n_updates % self.policy_delay == 0:
             pol.critic_target_arena.polyak_from(pol.critic_arena, self.tau)
             pol.actor_target_arena.polyak_from(pol.actor_arena, self.tau)
         if self.debug_capture:
             self.last_train_tensors = dict(agents=captured)
+
+    def _critic_chain_for(self, batch_size: int):
+        """The critic steps on the row-chain kernels for this batch size (core/common/chain.py:MaddpgCriticChain), or None."""
+        from core.common import chain
+
+        cache = self.__dict__.setdefault("_chain_cache", {})
+        key = (batch_size, chain.USE_CHAIN, fused.USE_FUSED_LINEAR)
+        if key not in cache:
+            cache[key] = chain.MaddpgCriticChain(self, batch_size) if chain.MaddpgCriticChain.supported(self, batch_size) else None
+        return cache[key]
 
     def learn(self, total_timesteps: int, callback=None, log_interval: int = 4, tb_log_name: str = "MADDPG",
               reset_num_timesteps: bool = True, progress_bar: bool = False):

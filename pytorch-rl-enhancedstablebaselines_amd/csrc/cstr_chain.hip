@@ -228,35 +228,69 @@ __device__ __forceinline__ void sample_action(const float mu, const float raw, c
 // chain and a 16 x 16 tile is 4 MFMAs + 4 ReLU + 4 LDS stores; the wave takes the tiles wave, wave + 4, ...
 // (inputs + the bias column that fit in 8 floats -- obs 4 / act 2 -- are staged 8 wide: half the LDS, so more workgroups per CU;
 // the upper half of the 16-wide k chunk is zero in registers)
+// Inputs whose rows are whole 16-byte quads (obs 4, obs 8, obs 8 + act 4 = 12) need no staging at all: the B operand quads come
+// straight from W1 in L2 and the bias is added in the tile's epilogue (l1_pad() == 0: no LDS image -- 25 KB less per workgroup at
+// H1 = 400, i.e. twice as many workgroups per CU).
 template <int KIN>
-constexpr int l1_pad() { return KIN + 1 <= 8 ? 8 : 16; }
+constexpr int l1_pad() { return KIN % 4 == 0 ? 0 : (KIN + 1 <= 8 ? 8 : 16); }
 
 template <int KIN>
 __device__ __forceinline__ void stage_w1(float *w1s, const float *w1, const float *b1, const int h1)
 {
     constexpr int KP = l1_pad<KIN>();
+    if (KP == 0) return;  // direct form: nothing to stage
     for (int c = threadIdx.x; c < h1; c += CH_THREADS) {
-        float w[KP];
+        float w[KP > 0 ? KP : 4];
 #pragma unroll
         for (int k = 0; k < KP; ++k) w[k] = k < KIN ? w1[(int64_t)c * KIN + k] : 0.0f;
-        w[KIN] = b1[c];
+        w[KP > 0 ? KIN : 0] = b1[c];
 #pragma unroll
         for (int q = 0; q < KP / 4; ++q) *reinterpret_cast<float4 *>(w1s + c * KP + 4 * q) = make_float4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
     }
 }
 
-template <int KP>
-__device__ __forceinline__ void layer1_mfma(const float *xs, const float *w1s, float *panel, const int ld, const int h1)
+// direct form (KP == 0): the wave's first four tiles' B quads and biases, requested at kernel entry
+template <int KIN>
+struct L1Direct {
+    float4 wb[4];
+    float bias[4];
+    __device__ __forceinline__ void request(const float *w1, const float *b1, const int h1)
+    {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, h = lane >> 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n = min(16 * (wave + CH_WAVES * i) + r, h1 - 1);
+            wb[i] = 4 * h < KIN ? *reinterpret_cast<const float4 *>(w1 + (int64_t)n * KIN + 4 * h) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            bias[i] = b1[n];
+        }
+    }
+};
+
+template <int KP, int KIN>
+__device__ __forceinline__ void layer1_mfma(const float *xs, const float *w1s, float *panel, const int ld, const int h1,
+                                            const L1Direct<KIN> *dir = nullptr, const float *w1 = nullptr, const float *b1 = nullptr)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, h = lane >> 4;
-    const bool hk = 4 * h < KP;  // this lane's quad of the k chunk exists in the staged images
+    const bool hk = KP == 0 ? 4 * h < KIN : 4 * h < KP;  // this lane's quad of the k chunk exists
     const float4 zero4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     const float4 xa = hk ? *reinterpret_cast<const float4 *>(xs + r * 16 + 4 * h) : zero4;
     const int n_tiles = (h1 + 15) / 16;
     for (int t0 = wave; t0 < n_tiles; t0 += 4 * CH_WAVES) {  // four tiles in flight: their LDS reads, MFMA chains and stores interleave
         float4 wb[4];
+        float bb[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-        for (int i = 0; i < 4; ++i) wb[i] = hk ? *reinterpret_cast<const float4 *>(w1s + min(16 * (t0 + CH_WAVES * i) + r, h1 - 1) * KP + 4 * h) : zero4;
+        for (int i = 0; i < 4; ++i) {
+            if (KP == 0) {  // direct: requested at entry (first group) or here (wider layers)
+                if (t0 == wave) { wb[i] = dir->wb[i]; bb[i] = dir->bias[i]; }
+                else {
+                    const int n = min(16 * (t0 + CH_WAVES * i) + r, h1 - 1);
+                    wb[i] = hk ? *reinterpret_cast<const float4 *>(w1 + (int64_t)n * KIN + 4 * h) : zero4;
+                    bb[i] = b1[n];
+                }
+            } else {
+                wb[i] = hk ? *reinterpret_cast<const float4 *>(w1s + min(16 * (t0 + CH_WAVES * i) + r, h1 - 1) * KP + 4 * h) : zero4;
+            }
+        }
         f32x4 acc0[4], acc1[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -276,7 +310,7 @@ __device__ __forceinline__ void layer1_mfma(const float *xs, const float *w1s, f
             const f32x4 acc = acc0[i] + acc1[i];
             if (tl < n_tiles && 16 * tl + r < h1) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) panel[(4 * h + e) * ld + 16 * tl + r] = fmaxf(acc[e], 0.0f);
+                for (int e = 0; e < 4; ++e) panel[(4 * h + e) * ld + 16 * tl + r] = fmaxf(acc[e] + bb[i], 0.0f);
             }
         }
     }
@@ -326,6 +360,8 @@ __global__ __launch_bounds__(CH_THREADS) void sac_actor_chain_fwd_kernel(const A
 #pragma unroll
     for (int j = 0; j < 2 * A; ++j) hwv[j] = j < HN ? a.net.hw[(int64_t)j * H2 + col] : 0.0f;
     stage_w1<D>(w1s, a.net.w1, a.net.b1, H1);
+    L1Direct<D> l1d;
+    if (l1_pad<D>() == 0) l1d.request(a.net.w1, a.net.b1, H1);
     // (b) the row group's 16 input rows: ReplayBuffer.sample's gather (buffers.py:316-323) or the already packed observation columns
     const bool mat = a.idx != nullptr && blockIdx.x == 0;  // this workgroup also materialises the packed batch (stores at the end)
     float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f), vo = v;
@@ -375,7 +411,7 @@ __global__ __launch_bounds__(CH_THREADS) void sac_actor_chain_fwd_kernel(const A
     lds_barrier();
     CH_STAMP(0, 2);
     // (c) layer 1, recomputed by every workgroup of the row group -> panel
-    layer1_mfma<l1_pad<D>()>(xs, w1s, panel, ld, H1);
+    layer1_mfma<l1_pad<D>(), D>(xs, w1s, panel, ld, H1, &l1d, a.net.w1, a.net.b1);
     lds_barrier();
     CH_STAMP(0, 3);
     // (d) layer 2: this wave's 16 x 16 tile (its share of K), (e) split-K combine
@@ -504,6 +540,8 @@ __global__ __launch_bounds__(CH_THREADS) void q_chain_fwd_kernel(const QFwdArgs 
     const float bv = net.b2[col];
     const float w3v = col_ok ? net.w3[col] : 0.0f;
     stage_w1<W>(w1s, net.w1, net.b1, H1);
+    L1Direct<W> l1d;
+    if (l1_pad<W>() == 0) l1d.request(net.w1, net.b1, H1);
     // (b) input rows (16 floats per row in LDS: the inputs, 1.0 = the bias input, zeros); with a pending actor head the action columns
     //     of the pi(next_obs) rows are finalised HERE (every workgroup of the row group for itself: a lane per (row, action)), and the
     //     column-group-0 workgroups store what later launches need
@@ -540,7 +578,7 @@ __global__ __launch_bounds__(CH_THREADS) void q_chain_fwd_kernel(const QFwdArgs 
     lds_barrier();
     CH_STAMP(1, 2);
     // (c) layer 1 recomputed on the matrix cores
-    layer1_mfma<l1_pad<W>()>(xs, w1s, panel, ld, H1);
+    layer1_mfma<l1_pad<W>(), W>(xs, w1s, panel, ld, H1, &l1d, net.w1, net.b1);
     lds_barrier();
     CH_STAMP(1, 3);
     f32x4 acc = tile_mma<NQ>(panel, ld, H1, bq, ks, S);
@@ -1057,7 +1095,7 @@ extern "C" int cstr_sac_actor_chain_fwd_f32(const cstr_sac_actor_t *actor, const
     a.a_h1 = a_h1; a.a_h2 = a_h2; a.head_part = head_part; a.head_rng_ctl = head_rng_ctl; a.head_rng_offset = head_rng_offset; a.eps_all = eps_all;
     a.rows_mode = rows_mode; a.head_n = head_n;
     const dim3 grid((unsigned)((actor->h2 + 16 * tiles - 1) / (16 * tiles)), (unsigned)((rows_mode == CSTR_CHAIN_ROWS_PAIR ? 2 : 1) * batch / 16));
-    const size_t lds = chain_lds_bytes(actor->h1, actor->obs_dim + 1 <= 8 ? 8 : 16);
+    const size_t lds = chain_lds_bytes(actor->h1, 0);  // obs rows are whole quads: layer 1's operand is read directly
     const int nq = nq_for(actor->h1, tiles, 32), lay = chain_layout(actor->obs_dim, actor->act_dim);
     if (!nq || lds > CHAIN_LDS_LIMIT) return CSTR_E_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
@@ -1094,7 +1132,7 @@ extern "C" int cstr_q_chain_fwd_f32(const cstr_chain_net_t *nets, int n_nets, in
     }
     a.n_nets = n_nets; a.h1 = h1; a.h2 = h2; a.batch = (int)batch; a.tiles = tiles;
     const dim3 grid((unsigned)((h2 + 16 * tiles - 1) / (16 * tiles)), (unsigned)(batch / 16), (unsigned)n_nets);
-    const size_t lds = chain_lds_bytes(h1, w_in + 1 <= 8 ? 8 : 16);
+    const size_t lds = chain_lds_bytes(h1, w_in % 4 == 0 ? 0 : (w_in + 1 <= 8 ? 8 : 16));
     const int nq = nq_for(h1, tiles, 32), lay = chain_layout(obs_dim, w_in - obs_dim);
     if (!nq || lay < 0 || lds > CHAIN_LDS_LIMIT) return CSTR_E_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;

@@ -172,7 +172,7 @@ def test_chain_entry_points_reject_bad_arguments_on_the_host():
     assert lib.cstr_sac_actor_chain_fwd_f32(*args(wide, 256, 2)) == -2         # wider than CSTR_CHAIN_MAX_WIDTH
     net = nv.ChainNet(*([0x1000] * 10), 0, 0)
     nets = (nv.ChainNet * 1)(net)
-    assert lib.cstr_q_chain_fwd_f32(nets, 5, 6, 4, 256, 256, C.c_int64(256), null, 2, null) == -1   # more than 4 networks
+    assert lib.cstr_q_chain_fwd_f32(nets, 17, 6, 4, 256, 256, C.c_int64(256), null, 2, null) == -1  # more than 16 networks
     assert lib.cstr_q_chain_fwd_f32(nets, 1, 6, 3, 256, 256, C.c_int64(256), null, 2, null) == -2   # (3, 3) is not a layout
     bad_role = (nv.ChainNet * 1)(nv.ChainNet(*([0x1000] * 10), 2, 0))
     assert lib.cstr_q_chain_fwd_f32(bad_role, 1, 6, 4, 256, 256, C.c_int64(256), null, 2, null) == -1  # a finalising role without `fin`
