@@ -651,6 +651,11 @@ typedef struct cstr_chain_root {
 int cstr_q_chain_bwd_f32(const cstr_chain_net_t *nets, int n_nets, const cstr_chain_root_t *root, int w_in, int obs_dim, int h1, int h2,
                          float *dz2, float *dz1, float *gact_part, int tiles, cstr_stream_t stream);
 
+/* out[row * out_stride + col] = sum over p < n_parts of part[p][row][col] (p ascending): the finalisation of a chain launch's partial
+ * sums for a consumer that is not a chain kernel -- MADDPG's per-layer actor backward (core/maddpg/maddpg.py:174-179) reads
+ * d(loss)/d(action) from the action columns of a critic-input gradient. */
+int cstr_chain_sum_parts_f32(const float *part, int n_parts, int64_t rows, int cols, float *out, int64_t out_stride, cstr_stream_t stream);
+
 /* Backward of the SAC actor from the critic's action-gradient partials in ONE launch (cstr_gaussian_head_bwd_input_f32 +
  * cstr_linear_bwd_input_f32): d(loss)/d(action) = sum of gact_part over networks and column groups; d(loss)/d(logp) = ent_coef / B
  * (core/sac/sac.py:275); the squashed-Gaussian head's analytic backward -> g_params [B][2A]; dz2 = (g_params hw) * relu'(a_h2)

@@ -25,7 +25,7 @@ SYMBOLS = (
     "cstr_squashed_gaussian_fwd_f32", "cstr_squashed_gaussian_bwd_f32", "cstr_sac_alpha_f32", "cstr_twin_q_loss_f32",
     "cstr_sac_actor_loss_f32", "cstr_neg_mean_loss_f32",
     "cstr_sac_actor_chain_fwd_f32", "cstr_q_chain_fwd_f32", "cstr_q_chain_bwd_f32", "cstr_sac_actor_chain_bwd_f32",
-    "cstr_linear_bwd_weight_adam_sets_f32",
+    "cstr_linear_bwd_weight_adam_sets_f32", "cstr_chain_sum_parts_f32",
 )
 
 

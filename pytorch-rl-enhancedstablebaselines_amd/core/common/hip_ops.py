@@ -1051,3 +1051,15 @@ def sac_actor_chain_bwd(actor: "nv.SacActorNet", gact_part, n_nets: int, n_parts
     check(nv.lib().cstr_sac_actor_chain_bwd_f32(C.byref(actor), ptr(gact_part), C.c_int(n_nets), C.c_int(n_parts), ptr(ent_coef), ptr(x_pi), ptr(params),
                                                 ptr(eps), ptr(a_h1), ptr(a_h2), ptr(g_params), ptr(dz2), ptr(dz1), C.c_int64(batch), C.c_int(kind),
                                                 C.c_int(tiles), stream_ptr()), "cstr_sac_actor_chain_bwd_f32")
+
+
+def chain_sum_parts(part, out):
+    """cstr_chain_sum_parts_f32: out [rows, cols] (row-strided ok) = sum over the leading dimension(s) of part [..., rows, cols]."""
+    rows, cols = out.shape
+    n_parts = part.numel() // (rows * cols)
+    if part.numel() != n_parts * rows * cols or _f32c(part, "part") is None:
+        raise ValueError("part: needs [n_parts, rows, cols]")
+    if not (out.is_cuda and out.dtype == th.float32 and out.stride(1) == 1):
+        raise ValueError("out: needs a float32 device matrix with unit inner stride")
+    check(nv.lib().cstr_chain_sum_parts_f32(ptr(part), C.c_int(n_parts), C.c_int64(rows), C.c_int(cols), ptr(out), C.c_int64(out.stride(0)), stream_ptr()),
+          "cstr_chain_sum_parts_f32")

@@ -430,8 +430,18 @@ class MADDPG(OffPolicyAlgorithm):
                         x_pi = th.cat([rd.observations] + acts, dim=1)
                     else:
                         x_pi = C._input(i, rd.observations, th.cat(acts, dim=-1))
-                qs_pi = self._fast_critics[i].forward_input(x_pi, train_params=False, only_first=True)
-                if qs_pi.stacked is not None and B <= fused.LOSS_ROOT_MAX_ROWS and fused.loss_root_supported(self._fast_critics[i]):
+                if cchain is not None and tuple(x_pi.shape) == (B, cchain.W) and x_pi.is_contiguous() and x_pi.requires_grad:
+                    # -mean(Q1) (:177) and its gradient down to the critic input on the chain kernels (3 launches instead of 6); the actors'
+                    # backward (per-layer kernels) reads the action columns
+                    g_x = cchain.actor_loss_grad(self, i, x_pi.detach())
+                    with fused.deferred_weight_grads():
+                        th.autograd.backward([x_pi], [g_x])
+                    qs_pi = None
+                else:
+                    qs_pi = self._fast_critics[i].forward_input(x_pi, train_params=False, only_first=True)
+                if qs_pi is None:
+                    pass
+                elif qs_pi.stacked is not None and B <= fused.LOSS_ROOT_MAX_ROWS and fused.loss_root_supported(self._fast_critics[i]):
                     # -mean(Q1) (:177) rides in the first launch of the backward through the (frozen) first Q network
                     with fused.loss_root(dict(mode="neg_mean", q1=qs_pi[0].detach(), loss_out=self._loss_now,
                                               loss_sum=self._loss_sums[f"actor{i}"])):

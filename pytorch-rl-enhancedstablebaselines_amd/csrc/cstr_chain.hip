@@ -1007,6 +1007,16 @@ __global__ __launch_bounds__(CH_THREADS) void sac_actor_chain_bwd_kernel(const A
     CH_STAMP(3, 7);
 }
 
+// out[row][col] = sum over parts of part[p][row][col]: the consumer-side finalisation of a chain launch's partial sums for a consumer that
+// is NOT a chain kernel (MADDPG's per-layer actor backward reads d(loss)/d(action) from the action columns of a critic-input gradient)
+__global__ __launch_bounds__(256) void chain_sum_parts_kernel(const float *__restrict__ part, const int n_parts, const int64_t rows, const int cols,
+                                                              float *__restrict__ out, const int64_t out_stride)
+{
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x, n = rows * cols;
+    if (i >= n) return;
+    out[(i / cols) * out_stride + i % cols] = sum_parts(part, n_parts, n, i, (int64_t)n_parts * n);
+}
+
 // chunks of 16 along the reduction a wave owns, rounded up to an instantiated size (0: not covered)
 static int nq_for(int kdim, int tiles, int nq_max = 16)
 {
@@ -1168,6 +1178,15 @@ extern "C" int cstr_q_chain_bwd_f32(const cstr_chain_net_t *nets, int n_nets, co
     if (!nq || lay < 0 || lds > CHAIN_LDS_LIMIT) return CSTR_E_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
     CHAIN_DISPATCH(q_chain_bwd_kernel, lay, nq, grid, lds, s, a);
+    return (int)hipGetLastError();
+}
+
+extern "C" int cstr_chain_sum_parts_f32(const float *part, int n_parts, int64_t rows, int cols, float *out, int64_t out_stride, cstr_stream_t stream)
+{
+    if (!part || !out || n_parts < 1 || rows < 1 || cols < 1 || out_stride < cols) return CSTR_E_BADARG;
+    if ((int64_t)n_parts * rows * cols >= (1 << 28)) return CSTR_E_UNSUPPORTED;
+    const int64_t n = rows * cols;
+    chain_sum_parts_kernel<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(part, n_parts, rows, cols, out, out_stride);
     return (int)hipGetLastError();
 }
 
