@@ -88,6 +88,7 @@ class OffPolicyAlgorithm(BaseAlgorithm):
 
     def _setup_model(self) -> None:
         """reference: off_policy_algorithm.py:172-212"""
+        self._chain_cache = {}  # row-chain step objects hold raw pointers of the policy's tensors: rebuilt with the policy
         self._setup_lr_schedule()
         blas.configure()
         if self.world_size > 1 and self._denv is not None:
