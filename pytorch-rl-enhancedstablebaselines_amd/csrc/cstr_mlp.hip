@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <type_traits>
 
 #include "../../include/cstr_rl_hip.h"
 #include "cstr_device.h"
@@ -1496,11 +1497,23 @@ __global__ __launch_bounds__(64 * POLICY_WAVES) void policy_rows_fwd_kernel(cons
 // summation order differs (split-K MFMA instead of per-lane partial dots + shuffle tree).
 constexpr int V2_CH = 4, V2_MAX_WIDTH = 512;
 
+// 1 KB piece `piece` of the tile-major weight copy: lane's 16 bytes through a buffer load whose per-lane offset (16 * lane) is ONE
+// register for every request and whose piece offset is scalar -- no 64-bit vector address arithmetic between the MFMAs
+using u32x4_t = __attribute__((ext_vector_type(4))) unsigned int;
+__device__ __forceinline__ float4 v2_piece(const __amdgpu_buffer_rsrc_t rs, const int lane16, const int piece)
+{
+    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rs, lane16, piece << 10, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+
 #ifdef CSTR_POLICY_STAMPS  // diagnostic build only (make diag): s_memtime per wave at the phase boundaries, read by tools/policy_stamps.py
 __device__ unsigned long long policy_stamps[4096 * 16 * 8];
 #define V2_STAMP(i) do { if (lane == 0 && blockIdx.x < 4096) policy_stamps[(blockIdx.x * 16 + wave) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+// second bank (wave slots 8-15 of the workgroup's 16): stamps inside layer 2 of the h <= 256 instantiation
+#define V2_STAMP2(i) do { if (lane == 0 && blockIdx.x < 4096) policy_stamps[(blockIdx.x * 16 + 8 + wave) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define V2_STAMP(i) do { } while (0)
+#define V2_STAMP2(i) do { } while (0)
 #endif
 
 // FULL: every chunk of the stage is inside K (all stages but the last): no checks between the MFMAs
@@ -1541,23 +1554,63 @@ struct RolloutArgs {
 };
 
 template <int ACT, int HEAD, bool VEC0, bool K0_SMALL, bool SMALL, bool FUSE>
-__device__ __forceinline__ void policy_rows_v2_body(const PolicyArgs &a, const RolloutArgs *ro)
+__device__ __forceinline__ void policy_rows_v2_body(const PolicyArgs &a, const RolloutArgs *ro, uint32_t *kernarg_touch = nullptr)
 {
     constexpr int WAVES = POLICY_WAVES, L1_WAVES = 4;
     constexpr int MAXC = SMALL ? 16 : V2_MAX_WIDTH / 16;  // 16-wide k chunks / column tiles the instantiation is sized for (register budget)
     constexpr int V2_HEAD_Q = MAXC / WAVES;     // head k chunks per wave
     constexpr int L1_T = MAXC / L1_WAVES;       // layer-1 column tiles per layer-1 wave
-    constexpr int NB = SMALL ? 16 : V2_CH;      // B chunks per tile requested before the first barrier: ALL of K (SMALL) or stage 0
+#ifndef CSTR_L2_DEPTH
+#define CSTR_L2_DEPTH 4
+#endif
+    constexpr int NB = SMALL ? CSTR_L2_DEPTH : V2_CH;  // B chunks per tile requested before the first barrier: the ring of the per-chunk pipeline (SMALL) or stage 0
     extern __shared__ float policy_lds[];
     const int H1 = a.h1, H2 = a.h2, kc1 = (H1 + 15) >> 4, kc2 = (H2 + 15) >> 4, S1 = 16 * kc1 + 4, S2 = 16 * kc2 + 4;
     float *h1s = policy_lds, *h2s = h1s + POLICY_ROWS * S1, *part = h2s + POLICY_ROWS * S2;  // part [8 waves][16 rows][8]
     float *eps_s = part + WAVES * POLICY_ROWS * 8, *term = eps_s + POLICY_ROWS * 8;          // eps [16][8], terms [2][16][8]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, h = lane >> 4;
     const int64_t m0 = (int64_t)blockIdx.x * POLICY_ROWS;
-    const bool draw = HEAD == 0 && a.rng_ctl != nullptr;
-    const int n_out = HEAD == 0 ? 2 * a.act_dim : a.act_dim;
     const float4 *w2s = reinterpret_cast<const float4 *>(a.w2s);
     const bool l1_wave = wave < L1_WAVES;
+    V2_STAMP(0);
+    // L2 warm-up: a launch starts with its XCD's L2 cold, and every line of the weight copy is first touched by ONE of the XCD's
+    // 32 workgroups, whose wave then waits a fabric round trip in the middle of layer 2 (the slowest wave of a workgroup arrived
+    // ~1.3 us after the typical one). So each wave first touches one distinct 1 KB piece (8 lines, lanes 0-7; per XCD, under the
+    // observed round-robin placement, blocks b, b + 8, ... cover the whole copy; any other placement is only slower): the copy is
+    // in every L2 one fabric round trip after launch. The value is kept live to the end so that the load is not eliminated.
+    // Round 3 (in-kernel stamps): the touch is WAITED for before a wave's first operand requests of layer 2 -- without the wait they race
+    // the warm-up into a cold L2 (first barrier 1,700 cycles later) -- but layer 1's own operand requests leave right behind it, in the
+    // same cold round trip.
+    constexpr int WARM_N = SMALL ? 1 : 4;  // pieces <= 256 (h <= 256) / <= 1024 (h <= 512) over 256 loaders
+    float warm[WARM_N];
+    auto warm_issue = [&]() {
+        const int pieces = kc2 * kc1, loader = (int)((blockIdx.x >> 3) & 31u) * WAVES + wave;
+        const float *wf = reinterpret_cast<const float *>(w2s);
+#pragma unroll
+        for (int i = 0; i < WARM_N; ++i) warm[i] = wf[(int64_t)min(loader + 32 * WAVES * i, pieces - 1) * 256 + (lane & 7) * 32];
+    };
+    auto warm_wait = [&]() {
+#pragma unroll
+        for (int i = 0; i < WARM_N; ++i) asm volatile("" ::"v"(warm[i]));  // the value has to be in its register here
+    };
+    // ---- the launch's first requests: everything up to the sched_barrier reads only what the kernel's leading scalar parameters carry
+    // (preloaded SGPRs); the first wait for the argument structs sits behind them ----
+    float4 xa = make_float4(0.0f, 0.0f, 0.0f, 0.0f), w1v[L1_T];
+    float b1v[L1_T];
+    warm_issue();  // in front of layer 1's operands: their out-of-range zeroing below already waits for them
+    if (K0_SMALL && l1_wave) {
+        xa = load_k4_clamped<VEC0>(a.x + min(m0 + r, a.m - 1) * a.ldx, 4 * h, a.k0, m0 + r < a.m);
+#pragma unroll
+        for (int i = 0; i < L1_T; ++i) {
+            const int n = 16 * (wave + L1_WAVES * i) + r;
+            w1v[i] = load_k4_clamped<VEC0>(a.w1 + (int64_t)min(n, H1 - 1) * a.k0, 4 * h, a.k0, n < H1);
+            b1v[i] = a.b1[min(n, H1 - 1)];
+        }
+    }
+    if (kernarg_touch) kernarg_touch_wait(*kernarg_touch);
+    __builtin_amdgcn_sched_barrier(0);
+    const bool draw = HEAD == 0 && a.rng_ctl != nullptr;
+    const int n_out = HEAD == 0 ? 2 * a.act_dim : a.act_dim;
     constexpr int MT_Q = (MT_N + 63) / 64;
     __shared__ uint32_t mt_lds[FUSE ? MT_N : 1];
     const bool mt_wave = FUSE && K0_SMALL && ro->mt_state != nullptr && blockIdx.x == gridDim.x - 1 && wave == 2;  // wave-uniform
@@ -1567,7 +1620,6 @@ __device__ __forceinline__ void policy_rows_v2_body(const PolicyArgs &a, const R
     CollectIn env_in;   // layout 2 (two trains): a lane per env
     CollectInQ env_q;   // layouts 0, 1: four lanes per env (collect_env_quad)
     int64_t ring_pos = 0;
-    V2_STAMP(0);
 
     // Roles before the first barrier. The CU's vector-memory path is ONE in-order queue that moves ~75 GB/s: layer 2's weights
     // (256 KB per workgroup at 256 x 256) need ~3.4 us of it, as long as the layer's MFMAs, so the stream has to start at t = 0 and
@@ -1581,33 +1633,24 @@ __device__ __forceinline__ void policy_rows_v2_body(const PolicyArgs &a, const R
     // branchy dword loads; out-of-range chunks are never fed to an MFMA, out-of-range head lanes are zeroed after the load.
     float4 bq0[NB], bq1[NB], w3q[V2_HEAD_Q];
     float b2q0, b2q1;
-    const int t0 = min(wave, kc2 - 1), t1 = min(wave + WAVES, kc2 - 1);
-    // L2 warm-up: a launch starts with its XCD's L2 cold, and every line of the weight copy is first touched by ONE of the XCD's
-    // 32 workgroups, whose wave then waits a fabric round trip in the middle of layer 2 (the slowest wave of a workgroup arrived
-    // ~1.3 us after the typical one). So each wave first touches one distinct 1 KB piece (8 lines, lanes 0-7; per XCD, under the
-    // observed round-robin placement, blocks b, b + 8, ... cover the whole copy; any other placement is only slower): the copy is
-    // in every L2 one fabric round trip after launch. The value is kept live to the end so that the load is not eliminated.
-    float warm = 0.0f;
-    {
-        const int pieces = kc2 * kc1, loader = (int)((blockIdx.x >> 3) & 31u) * WAVES + wave;
-        const float *wf = reinterpret_cast<const float *>(w2s);
-        for (int pc = loader; pc < pieces; pc += 32 * WAVES) warm += wf[(int64_t)pc * 256 + (lane & 7) * 32];
-    }
-#define V2_REQUEST_B(FROM, TO) do { _Pragma("unroll") for (int u = (FROM); u < (TO); ++u) { const int c = min(u, kc1 - 1); \
-        bq0[u] = w2s[((int64_t)t0 * kc1 + c) * 64 + lane]; bq1[u] = w2s[((int64_t)t1 * kc1 + c) * 64 + lane]; } } while (0)
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);  // the wave index as a SCALAR (piece offsets of the buffer loads)
+    const int t0 = min(wave_s, kc2 - 1), t1 = min(wave_s + WAVES, kc2 - 1);
+#ifdef CSTR_DIAG_ROT  // diagnostic only (wrong results): do the waves' simultaneous requests collide in the L2's channels?
+#define V2_CHUNK(u) (((u) + CSTR_DIAG_ROT * wave + (int)(blockIdx.x >> 3)) & 15)
+#else
+#define V2_CHUNK(u) min((u), kc1 - 1)
+#endif
+    const __amdgpu_buffer_rsrc_t w2rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.w2s), 0, kc2 * kc1 * 1024, 0x00020000);
+    const int lane16 = 16 * lane;
+#define V2_REQUEST_B(FROM, TO) do { _Pragma("unroll") for (int u = (FROM); u < (TO); ++u) { const int c = V2_CHUNK(u); \
+        bq0[u] = v2_piece(w2rs, lane16, t0 * kc1 + c); bq1[u] = v2_piece(w2rs, lane16, t1 * kc1 + c); } } while (0)
     // how many of the NB chunks are requested BEFORE the first barrier: a wave is held while it issues loads (~60 ns per 1 KB wave
     // load), and everybody waits at the barrier for the last issuer -- the rest follows right after the barrier, before the MFMAs
     // (waves 0-3, SMALL: none before layer 1 -- A/B on MI355X: 0 / 2 / 4 chunks ahead of layer 1 = 10.60 / 10.61 / 10.73 us)
     // (round 3: the barriers of this kernel are LDS-only -- see POLICY_BARRIER -- so requests no longer have to be held back for them)
     // A/B (tools/rollout_ab.py, profiles/r03_rollout_ab.txt): __syncthreads + 12 / 0 ahead 12.93 us; LDS-only barriers 12.81; with all 16
     // chunks of both wave groups requested ahead of the barrier 12.56 us (bit-identical outputs)
-#ifndef CSTR_PRE_YOUNG
-#define CSTR_PRE_YOUNG 16
-#endif
-#ifndef CSTR_PRE_OLD
-#define CSTR_PRE_OLD 16
-#endif
-    constexpr int PRE_YOUNG = SMALL ? CSTR_PRE_YOUNG : V2_CH, PRE_OLD = SMALL ? CSTR_PRE_OLD : V2_CH;
+    constexpr int PRE_YOUNG = NB, PRE_OLD = NB;
     // who draws the Gaussian noise (~1.7 us of dependent VALU work that needs nothing from memory): wave 7, AFTER its weight requests.
     // With the draw in front of them the requests sat behind everybody else's in the CU's in-order queue and wave 7 left layer 2
     // ~1 us after the other seven (in-kernel stamps, profiles/r02_rollout_phase_stamps.json); on a layer-1 wave, between requesting
@@ -1619,7 +1662,11 @@ __device__ __forceinline__ void policy_rows_v2_body(const PolicyArgs &a, const R
         const uint64_t seed = a.rng_ctl[0], base = a.rng_ctl[1];
         const int64_t row = m0 + lane;
         if (lane < POLICY_ROWS && row < a.m) {
+#ifdef CSTR_DIAG_NO_NOISE  // diagnostic only: what the launch costs without the draw on wave 7
+            for (int j0 = 0; j0 < 0; j0 += 2) {
+#else
             for (int j0 = 0; j0 < a.act_dim; j0 += 2) {
+#endif
                 const uint64_t ctr = base + (uint64_t)row;
                 uint32_t rnd[4];
                 float e0, e1;
@@ -1638,18 +1685,11 @@ __device__ __forceinline__ void policy_rows_v2_body(const PolicyArgs &a, const R
         if (tid < POLICY_ROWS * p2) h2s[(tid / p2) * S2 + H2 + tid % p2] = 0.0f;
     }
     if (!l1_wave) {
+        if (SMALL && noise_wave) draw_noise();  // in front of its few ring requests: nobody is waiting for them before the first barrier
+        warm_wait();
         V2_REQUEST_B(0, PRE_YOUNG);
-        if (noise_wave) draw_noise();
+        if (!SMALL && noise_wave) draw_noise();
     } else if (K0_SMALL) {
-        float4 w1v[L1_T];
-        float b1v[L1_T];
-        const float4 xa = load_k4_clamped<VEC0>(a.x + min(m0 + r, a.m - 1) * a.ldx, 4 * h, a.k0, m0 + r < a.m);
-#pragma unroll
-        for (int i = 0; i < L1_T; ++i) {
-            const int n = 16 * (wave + L1_WAVES * i) + r;
-            w1v[i] = load_k4_clamped<VEC0>(a.w1 + (int64_t)min(n, H1 - 1) * a.k0, 4 * h, a.k0, n < H1);
-            b1v[i] = a.b1[min(n, H1 - 1)];
-        }
         if (FUSE && wave < (POLICY_ROWS * 8) / 64) {  // the collect step's operands of this lane's env: requested now, used by the sampling tail
             const int64_t e = min(m0 + (tid >> 3), a.m - 1);
             ring_pos = ro->ring_ctl[0];  // (behind layer 1's operand requests: see draw_noise)
@@ -1661,7 +1701,7 @@ __device__ __forceinline__ void policy_rows_v2_body(const PolicyArgs &a, const R
 #pragma unroll
             for (int i = 0; i < MT_Q; ++i) mtq[i] = ro->mt_state[min(lane + 64 * i, MT_N - 1)];
         }
-        V2_REQUEST_B(0, PRE_OLD);
+        if (!SMALL) { warm_wait(); V2_REQUEST_B(0, PRE_OLD); }
 #pragma unroll
         for (int i = 0; i < L1_T; ++i) {
             const int t = wave + L1_WAVES * i;
@@ -1689,7 +1729,9 @@ __device__ __forceinline__ void policy_rows_v2_body(const PolicyArgs &a, const R
             for (int i = 0; i < MT_Q; ++i)
                 if (lane + 64 * i < MT_N) mt_lds[lane + 64 * i] = mtq[i];
         }
+        if (SMALL) { warm_wait(); V2_REQUEST_B(0, PRE_OLD); }
     } else {
+        warm_wait();
         policy_layer<ACT, true, VEC0, false, 16>(a.x + m0 * a.ldx, a.ldx, m0 + r < a.m, a.k0, a.w1, a.b1, H1, h1s, S1, wave, L1_WAVES);
         V2_REQUEST_B(0, PRE_OLD);
     }
@@ -1705,12 +1747,6 @@ __device__ __forceinline__ void policy_rows_v2_body(const PolicyArgs &a, const R
     V2_STAMP(1);
     POLICY_BARRIER();
     V2_STAMP(2);
-    if (SMALL) {  // the rest of the wave's B operand
-        if (l1_wave) V2_REQUEST_B(PRE_OLD, NB);
-        else {
-            V2_REQUEST_B(PRE_YOUNG, NB);
-        }
-    }
 #undef V2_REQUEST_B
 
     // layer 2: tile pairs (t, t + 8); column = lane & 15, row = 4 * (lane >> 4) + register in the epilogue
@@ -1726,30 +1762,55 @@ __device__ __forceinline__ void policy_rows_v2_body(const PolicyArgs &a, const R
                     if (ACT == ACT_TANH) v = tanhf(v); \
                     h2s[(4 * h + e) * S2 + col] = v; } } } } while (0)
     if (SMALL) {
-        // the whole B operand of the wave's ONE tile pair is in registers or on its way; only the A operand (LDS) is staged, one
-        // stage ahead; the MFMAs of a stage wait (in-order vmcnt) for exactly the B chunks they consume
+        // ONE tile pair per wave, K walked chunk by chunk with a ring of NB B chunks per tile in registers: chunk c's 8 MFMAs, then the
+        // request for chunk c + NB into the slot they have just read. Why per chunk and per wave (tools/probes/stream_mfma_probe.hip,
+        // profiles/r03_stream_mfma_probe.txt; one workgroup per CU, 256 KB stream + 1024 MFMAs per CU):
+        //   * requesting the whole operand ahead and then consuming it in k order costs 16,200 cycles (the waves' load issue and MFMA issue
+        //     serialise: stream 5,000 + MFMAs 8,400 would be the sum, 8,400 the ideal); the round-2 form of this loop was that;
+        //   * loader waves beside matrix waves on the same SIMD slow each other down (loads x 3.7, MFMAs x 1.5);
+        //   * a wave that interleaves ONE load with the MFMAs of one chunk, 4 chunks ahead, does both in 9,900 cycles.
         const int t = wave;
         if (t < kc2) {
             const bool second = t + WAVES < kc2;  // wave-uniform
             f32x4 c00 = {0.0f, 0.0f, 0.0f, 0.0f}, c01 = c00, c10 = c00, c11 = c00;
-            float4 av[2][V2_CH];
+            float4 av[2];
+#ifdef CSTR_STAMP_VM0  // diagnostic: when has this wave's ring landed?
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+            V2_STAMP2(0);
+            av[0] = *reinterpret_cast<const float4 *>(ar);
+            auto walk = [&](auto second_c) {
+                constexpr bool SECOND = decltype(second_c)::value;
 #pragma unroll
-            for (int u = 0; u < V2_CH; ++u) av[0][u] = *reinterpret_cast<const float4 *>(ar + 16 * min(u, kc1 - 1));
-#pragma unroll
-            for (int s = 0; s < 16 / V2_CH; ++s) {
-                if (s * V2_CH >= kc1) break;  // wave-uniform
-                if (s + 1 < 16 / V2_CH) {
-#pragma unroll
-                    for (int u = 0; u < V2_CH; ++u)
-                        av[(s + 1) & 1][u] = *reinterpret_cast<const float4 *>(ar + 16 * min((s + 1) * V2_CH + u, kc1 - 1));
+                for (int c = 0; c < 16; ++c) {
+                    if (c >= kc1) break;  // wave-uniform
+                    if (c + 1 < 16) av[(c + 1) & 1] = *reinterpret_cast<const float4 *>(ar + 16 * min(c + 1, kc1 - 1));
+                    const float4 a4 = av[c & 1], b0 = bq0[c % NB], b1 = bq1[c % NB];
+                    // the first version's accumulator assignment (elements x, z -> one chain, y, w -> the other): same bits
+                    c00 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, b0.x, c00, 0, 0, 0);
+                    if (SECOND) c10 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, b1.x, c10, 0, 0, 0);
+                    c01 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, b0.y, c01, 0, 0, 0);
+                    if (SECOND) c11 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, b1.y, c11, 0, 0, 0);
+                    c00 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, b0.z, c00, 0, 0, 0);
+                    if (SECOND) c10 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, b1.z, c10, 0, 0, 0);
+                    c01 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, b0.w, c01, 0, 0, 0);
+                    if (SECOND) c11 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, b1.w, c11, 0, 0, 0);
+                    // the scheduler must leave the request HERE: left alone it sinks every load down to its use (fewer registers), i.e.
+                    // load / wait for it / 8 MFMAs -- no chunk in flight at all
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (c + NB < 16) {  // unconditional on a clamped chunk (see above): beyond K it is a harmless re-read
+                        const int cn = min(c + NB, kc1 - 1);
+                        bq0[c % NB] = v2_piece(w2rs, lane16, t0 * kc1 + cn);
+                        bq1[c % NB] = v2_piece(w2rs, lane16, t1 * kc1 + cn);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if ((c & 3) == 3) V2_STAMP2(1 + (c >> 2));
                 }
-                float4 b0[V2_CH], b1[V2_CH];
-#pragma unroll
-                for (int u = 0; u < V2_CH; ++u) { b0[u] = bq0[(s * V2_CH + u) % NB]; b1[u] = bq1[(s * V2_CH + u) % NB]; }
-                if (second) v2_mfma_stage<true, false>(s * V2_CH, kc1, av[s & 1], b0, b1, c00, c01, c10, c11);
-                else v2_mfma_stage<false, false>(s * V2_CH, kc1, av[s & 1], b0, b1, c00, c01, c10, c11);
-            }
+            };
+            if (second) walk(std::true_type{});
+            else walk(std::false_type{});
             V2_EPILOGUE(t, second, true);
+            V2_STAMP2(5);
         }
     } else {
         // K in stages of V2_CH chunks, two register sets: stage s + 1's operands in flight while stage s's MFMAs issue
@@ -1913,7 +1974,6 @@ __device__ __forceinline__ void policy_rows_v2_body(const PolicyArgs &a, const R
         }
     }
     V2_STAMP(6);
-    if (__builtin_isnan(warm) && a.m < 0) a.action[0] = warm;  // never true; keeps the warm-up load alive
     if (!FUSE && a.rng_ctl && !(a.flags & 1) && last_block_ticket_tree(reinterpret_cast<unsigned long long *>(a.rng_ctl + 2),
                                                                        reinterpret_cast<unsigned long long *>(a.rng_ctl + 4)) && tid == 0)
         a.rng_ctl[1] += (uint64_t)a.m;
@@ -1928,9 +1988,16 @@ __global__ __launch_bounds__(64 * POLICY_WAVES) void policy_rows_v2_kernel(const
 // The rollout of one vec-step in ONE launch: policy network + sampling (policy_rows_v2_body) + fused collect step + the replay
 // index draw (RolloutArgs). Layer-1 input width <= 16 (the CSTR observations), 16-byte aligned rows.
 template <int ACT, int HEAD, bool SMALL>
-__global__ __launch_bounds__(64 * POLICY_WAVES) void rollout_step_kernel(const PolicyArgs a, const RolloutArgs ro)
+__global__ __launch_bounds__(64 * POLICY_WAVES) void rollout_step_kernel(const float *x, const int64_t ldx, const float *w1, const float *b1,
+                                                                         const float *w2s, const int m, const int k0, const int h1, const int h2,
+                                                                         const PolicyArgs a0, const RolloutArgs ro)
 {
-    policy_rows_v2_body<ACT, HEAD, true, true, SMALL, true>(a, &ro);
+    // the leading scalars (14 dwords: preloaded into SGPRs) are what layer 1's operand requests and the L2 warm-up touch need; the same
+    // fields of a0 are not read
+    uint32_t kt = kernarg_touch_issue<64 + sizeof(PolicyArgs) + sizeof(RolloutArgs)>();
+    PolicyArgs a = a0;
+    a.x = x; a.ldx = ldx; a.w1 = w1; a.b1 = b1; a.w2s = w2s; a.m = m; a.k0 = k0; a.h1 = h1; a.h2 = h2;
+    policy_rows_v2_body<ACT, HEAD, true, true, SMALL, true>(a, &ro, &kt);
 }
 
 // ---- loss heads (single workgroup; batch <= 16384) -----------------------------------------------------
@@ -2583,8 +2650,8 @@ extern "C" int cstr_rollout_step_f32(const cstr_policy_mlp_t *net, const float *
     const size_t lds2 = policy_v2_lds(n);
     const bool small = (n.h1 + 15) / 16 <= 16 && (n.h2 + 15) / 16 <= 16;
     hipStream_t s = (hipStream_t)stream;
-#define ROL2(A, H) do { if (small) rollout_step_kernel<A, H, true><<<grid, 64 * POLICY_WAVES, lds2, s>>>(a, ro); \
-                        else rollout_step_kernel<A, H, false><<<grid, 64 * POLICY_WAVES, lds2, s>>>(a, ro); } while (0)
+#define ROL2(A, H) do { if (small) rollout_step_kernel<A, H, true><<<grid, 64 * POLICY_WAVES, lds2, s>>>(a.x, a.ldx, a.w1, a.b1, a.w2s, (int)a.m, a.k0, a.h1, a.h2, a, ro); \
+                        else rollout_step_kernel<A, H, false><<<grid, 64 * POLICY_WAVES, lds2, s>>>(a.x, a.ldx, a.w1, a.b1, a.w2s, (int)a.m, a.k0, a.h1, a.h2, a, ro); } while (0)
     if (n.head == 0) { if (n.act == 0) ROL2(0, 0); else if (n.act == 1) ROL2(1, 0); else ROL2(2, 0); }
     else { if (n.act == 0) ROL2(0, 1); else if (n.act == 1) ROL2(1, 1); else ROL2(2, 1); }
 #undef ROL2

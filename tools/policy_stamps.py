@@ -54,4 +54,9 @@ if __name__ == "__main__":
     for i, nm in enumerate(names):
         v = rel[:, :, i]
         out[nm] = dict(per_wave_median=[int(np.median(v[:, w])) for w in range(8)])
+    # second bank (h <= 256 instantiation): inside layer 2 -- 0 at the loop's entry, 1-4 behind the MFMAs of each k stage, 5 epilogue done
+    st2 = np.frombuffer(buf, dtype=np.uint64).reshape(n_blocks, 16, 8)[:, 8:, :].astype(np.int64)
+    rel2 = st2 - st[:, :, 0].min(axis=1)[:, None, None]
+    for i, nm in enumerate(["l2_entry", "l2_stage0", "l2_stage1", "l2_stage2", "l2_stage3", "l2_epilogue"]):
+        out[nm] = dict(per_wave_median=[int(np.median(rel2[:, w, i])) for w in range(8)])
     print(json.dumps(out))
