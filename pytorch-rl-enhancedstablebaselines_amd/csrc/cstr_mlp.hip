@@ -1553,9 +1553,14 @@ struct RolloutArgs {
     uint32_t *mt_state; int32_t *sample_idx; int batch;
 };
 
-template <int ACT, int HEAD, bool VEC0, bool K0_SMALL, bool SMALL, bool FUSE>
+// SHAPE: 0 = widths <= 512, 1 = widths <= 256 (one tile pair per wave), 2 = exactly 256 x 256 and 3 = exactly 400 x 300 (the class-default
+// networks of SAC and of TD3 / DDPG / MADDPG: every loop bound and piece index of layer 2 is a constant -- with run-time widths the
+// hoisted bounds and indices overflow the scalar registers and come back through v_readlane in front of every request)
+template <int ACT, int HEAD, bool VEC0, bool K0_SMALL, int SHAPE, bool FUSE>
 __device__ __forceinline__ void policy_rows_v2_body(const PolicyArgs &a, const RolloutArgs *ro, uint32_t *kernarg_touch = nullptr)
 {
+    constexpr bool SMALL = SHAPE == 1 || SHAPE == 2, EXACT = SHAPE >= 2;
+    constexpr int H1C = SHAPE == 2 ? 256 : 400, H2C = SHAPE == 2 ? 256 : 300;
     constexpr int WAVES = POLICY_WAVES, L1_WAVES = 4;
     constexpr int MAXC = SMALL ? 16 : V2_MAX_WIDTH / 16;  // 16-wide k chunks / column tiles the instantiation is sized for (register budget)
     constexpr int V2_HEAD_Q = MAXC / WAVES;     // head k chunks per wave
@@ -1563,9 +1568,9 @@ __device__ __forceinline__ void policy_rows_v2_body(const PolicyArgs &a, const R
 #ifndef CSTR_L2_DEPTH
 #define CSTR_L2_DEPTH 4
 #endif
-    constexpr int NB = SMALL ? CSTR_L2_DEPTH : V2_CH;  // B chunks per tile requested before the first barrier: the ring of the per-chunk pipeline (SMALL) or stage 0
+    constexpr int NB = SMALL ? CSTR_L2_DEPTH : CSTR_L2_DEPTH + 1;  // the ring of layer 2's per-chunk pipeline: B chunks per tile in flight (5 divides TD3's 400 = 25 chunks)
     extern __shared__ float policy_lds[];
-    const int H1 = a.h1, H2 = a.h2, kc1 = (H1 + 15) >> 4, kc2 = (H2 + 15) >> 4, S1 = 16 * kc1 + 4, S2 = 16 * kc2 + 4;
+    const int H1 = EXACT ? H1C : a.h1, H2 = EXACT ? H2C : a.h2, kc1 = (H1 + 15) >> 4, kc2 = (H2 + 15) >> 4, S1 = 16 * kc1 + 4, S2 = 16 * kc2 + 4;
     float *h1s = policy_lds, *h2s = h1s + POLICY_ROWS * S1, *part = h2s + POLICY_ROWS * S2;  // part [8 waves][16 rows][8]
     float *eps_s = part + WAVES * POLICY_ROWS * 8, *term = eps_s + POLICY_ROWS * 8;          // eps [16][8], terms [2][16][8]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, h = lane >> 4;
@@ -1611,10 +1616,6 @@ __device__ __forceinline__ void policy_rows_v2_body(const PolicyArgs &a, const R
     __builtin_amdgcn_sched_barrier(0);
     const bool draw = HEAD == 0 && a.rng_ctl != nullptr;
     const int n_out = HEAD == 0 ? 2 * a.act_dim : a.act_dim;
-    constexpr int MT_Q = (MT_N + 63) / 64;
-    __shared__ uint32_t mt_lds[FUSE ? MT_N : 1];
-    const bool mt_wave = FUSE && K0_SMALL && ro->mt_state != nullptr && blockIdx.x == gridDim.x - 1 && wave == 2;  // wave-uniform
-    uint32_t mtq[MT_Q];
     // the lanes that step an env at the end (thread 8 * row of the sampling tail, waves 0-1 = layer-1 waves)
     const bool env_lane = FUSE && K0_SMALL && tid < POLICY_ROWS * 8 && (tid & 7) == 0 && m0 + (tid >> 3) < a.m;
     CollectIn env_in;   // layout 2 (two trains): a lane per env
@@ -1681,27 +1682,25 @@ __device__ __forceinline__ void policy_rows_v2_body(const PolicyArgs &a, const R
     // zero the k padding of both activation images (widths that are not multiples of 16: the MFMA chunks read them)
     {
         const int p1 = 16 * kc1 - H1, p2 = 16 * kc2 - H2;
-        if (tid < POLICY_ROWS * p1) h1s[(tid / p1) * S1 + H1 + tid % p1] = 0.0f;
-        if (tid < POLICY_ROWS * p2) h2s[(tid / p2) * S2 + H2 + tid % p2] = 0.0f;
+        if (p1 > 0 && tid < POLICY_ROWS * p1) h1s[(tid / max(p1, 1)) * S1 + H1 + tid % max(p1, 1)] = 0.0f;
+        if (p2 > 0 && tid < POLICY_ROWS * p2) h2s[(tid / max(p2, 1)) * S2 + H2 + tid % max(p2, 1)] = 0.0f;
     }
     if (!l1_wave) {
-        if (SMALL && noise_wave) draw_noise();  // in front of its few ring requests: nobody is waiting for them before the first barrier
+        if (noise_wave) draw_noise();  // in front of its few ring requests: nobody is waiting for them before the first barrier
         warm_wait();
         V2_REQUEST_B(0, PRE_YOUNG);
-        if (!SMALL && noise_wave) draw_noise();
     } else if (K0_SMALL) {
         if (FUSE && wave < (POLICY_ROWS * 8) / 64) {  // the collect step's operands of this lane's env: requested now, used by the sampling tail
             const int64_t e = min(m0 + (tid >> 3), a.m - 1);
-            ring_pos = ro->ring_ctl[0];  // (behind layer 1's operand requests: see draw_noise)
+            // a VECTOR load (per-lane zero offset the compiler cannot see through): as a scalar load the cold round trip of the ring
+            // position counts in lgkmcnt, which the LDS-only first barrier waits for -- waves 0-1 arrived ~1,100 cycles after waves 2-3
+            int zero;
+            asm volatile("v_mov_b32 %0, 0" : "=v"(zero));
+            ring_pos = ro->ring_ctl[zero];
             if (ro->layout == 0) collect_quad_load<0>(ro->c, e, tid & 7, env_q);
             else if (ro->layout == 1) collect_quad_load<1>(ro->c, e, tid & 7, env_q);
             else if (env_lane) collect_env_load<2>(ro->c, e, env_in);
         }
-        if (FUSE && mt_wave) {  // the sampler's MT19937 image: requested behind layer 1's operands, parked in LDS before the first barrier
-#pragma unroll
-            for (int i = 0; i < MT_Q; ++i) mtq[i] = ro->mt_state[min(lane + 64 * i, MT_N - 1)];
-        }
-        if (!SMALL) { warm_wait(); V2_REQUEST_B(0, PRE_OLD); }
 #pragma unroll
         for (int i = 0; i < L1_T; ++i) {
             const int t = wave + L1_WAVES * i;
@@ -1724,12 +1723,8 @@ __device__ __forceinline__ void policy_rows_v2_body(const PolicyArgs &a, const R
                 }
             }
         }
-        if (FUSE && mt_wave) {
-#pragma unroll
-            for (int i = 0; i < MT_Q; ++i)
-                if (lane + 64 * i < MT_N) mt_lds[lane + 64 * i] = mtq[i];
-        }
-        if (SMALL) { warm_wait(); V2_REQUEST_B(0, PRE_OLD); }
+        warm_wait();
+        V2_REQUEST_B(0, PRE_OLD);
     } else {
         warm_wait();
         policy_layer<ACT, true, VEC0, false, 16>(a.x + m0 * a.ldx, a.ldx, m0 + r < a.m, a.k0, a.w1, a.b1, H1, h1s, S1, wave, L1_WAVES);
@@ -1761,100 +1756,78 @@ __device__ __forceinline__ void policy_rows_v2_body(const PolicyArgs &a, const R
                     if (ACT == ACT_RELU) v = fmaxf(v, 0.0f); \
                     if (ACT == ACT_TANH) v = tanhf(v); \
                     h2s[(4 * h + e) * S2 + col] = v; } } } } while (0)
-    if (SMALL) {
-        // ONE tile pair per wave, K walked chunk by chunk with a ring of NB B chunks per tile in registers: chunk c's 8 MFMAs, then the
-        // request for chunk c + NB into the slot they have just read. Why per chunk and per wave (tools/probes/stream_mfma_probe.hip,
-        // profiles/r03_stream_mfma_probe.txt; one workgroup per CU, 256 KB stream + 1024 MFMAs per CU):
+    {
+        // Tile pairs (t, t + 8) per wave, K walked chunk by chunk with a ring of NB B chunks per tile in registers: chunk c's 8 MFMAs, then
+        // the request for chunk c + NB into the slot they have just read (beyond K: the first chunks of the wave's NEXT tile pair when
+        // the ring divides K, else a harmless re-read and the next pair starts with fresh requests). Why per chunk and per wave
+        // (tools/probes/stream_mfma_probe.hip, profiles/r03_stream_mfma_probe.txt; one workgroup per CU, 256 KB stream + 1024 MFMAs per CU):
         //   * requesting the whole operand ahead and then consuming it in k order costs 16,200 cycles (the waves' load issue and MFMA issue
         //     serialise: stream 5,000 + MFMAs 8,400 would be the sum, 8,400 the ideal); the round-2 form of this loop was that;
         //   * loader waves beside matrix waves on the same SIMD slow each other down (loads x 3.7, MFMAs x 1.5);
         //   * a wave that interleaves ONE load with the MFMAs of one chunk, 4 chunks ahead, does both in 9,900 cycles.
-        const int t = wave;
-        if (t < kc2) {
+        const bool wrap = kc1 % NB == 0;  // wave-uniform
+        int ring_t = wave_s;              // the tile pair whose first NB chunks the ring holds (requested before the first barrier)
+        // Both loops are FULLY unrolled (<= 2 tile pairs, <= MAXC chunks): a ring carried around a back-edge is copied into fixed
+        // registers there, behind s_waitcnt vmcnt(0) -- the pipeline would drain once per trip.
+#pragma unroll
+        for (int pair = 0; pair < MAXC / (2 * WAVES); ++pair) {
+            const int t = wave_s + 2 * WAVES * pair;
+            if (t >= kc2) break;                  // wave-uniform
             const bool second = t + WAVES < kc2;  // wave-uniform
+            const int ta = t, tb = second ? t + WAVES : t, tn = t + 2 * WAVES;
+            const int na = tn < kc2 ? tn : ta, nb = tn + WAVES < kc2 ? tn + WAVES : na;  // the next pair (clamped to a valid tile)
+            const int base_a = ta * kc1, base_b = tb * kc1, base_na = (na - 1) * kc1, base_nb = (nb - 1) * kc1;  // piece = base + chunk
+            if (ring_t != t) {  // (the ring does not divide K: no requests were carried over from the previous pair)
+#pragma unroll
+                for (int u = 0; u < NB; ++u) {
+                    bq0[u] = v2_piece(w2rs, lane16, ta * kc1 + min(u, kc1 - 1));
+                    bq1[u] = v2_piece(w2rs, lane16, tb * kc1 + min(u, kc1 - 1));
+                }
+            }
             f32x4 c00 = {0.0f, 0.0f, 0.0f, 0.0f}, c01 = c00, c10 = c00, c11 = c00;
-            float4 av[2];
 #ifdef CSTR_STAMP_VM0  // diagnostic: when has this wave's ring landed?
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
-            V2_STAMP2(0);
-            av[0] = *reinterpret_cast<const float4 *>(ar);
+            if (t == wave_s) V2_STAMP2(0);
+            float4 a_cur = *reinterpret_cast<const float4 *>(ar);  // the A operand (layer 1's activations, LDS) runs one chunk ahead
             auto walk = [&](auto second_c) {
                 constexpr bool SECOND = decltype(second_c)::value;
 #pragma unroll
-                for (int c = 0; c < 16; ++c) {
-                    if (c >= kc1) break;  // wave-uniform
-                    if (c + 1 < 16) av[(c + 1) & 1] = *reinterpret_cast<const float4 *>(ar + 16 * min(c + 1, kc1 - 1));
-                    const float4 a4 = av[c & 1], b0 = bq0[c % NB], b1 = bq1[c % NB];
-                    // the first version's accumulator assignment (elements x, z -> one chain, y, w -> the other): same bits
-                    c00 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, b0.x, c00, 0, 0, 0);
-                    if (SECOND) c10 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, b1.x, c10, 0, 0, 0);
-                    c01 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, b0.y, c01, 0, 0, 0);
-                    if (SECOND) c11 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, b1.y, c11, 0, 0, 0);
-                    c00 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, b0.z, c00, 0, 0, 0);
-                    if (SECOND) c10 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, b1.z, c10, 0, 0, 0);
-                    c01 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, b0.w, c01, 0, 0, 0);
-                    if (SECOND) c11 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, b1.w, c11, 0, 0, 0);
-                    // the scheduler must leave the request HERE: left alone it sinks every load down to its use (fewer registers), i.e.
-                    // load / wait for it / 8 MFMAs -- no chunk in flight at all
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (c + NB < 16) {  // unconditional on a clamped chunk (see above): beyond K it is a harmless re-read
-                        const int cn = min(c + NB, kc1 - 1);
-                        bq0[c % NB] = v2_piece(w2rs, lane16, t0 * kc1 + cn);
-                        bq1[c % NB] = v2_piece(w2rs, lane16, t1 * kc1 + cn);
+                for (int c = 0; c < MAXC; ++c) {
+                    {
+                        if (c >= kc1) break;   // wave-uniform (a constant in the exact-shape instantiations)
+                        const int u = c % NB;  // a constant once the loop is unrolled: the ring is registers
+                        const float4 a4 = a_cur, b0 = bq0[u], b1 = bq1[u];
+                        a_cur = *reinterpret_cast<const float4 *>(ar + 16 * min(c + 1, kc1 - 1));
+                        // the first version's accumulator assignment (elements x, z -> one chain, y, w -> the other): same bits
+                        c00 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, b0.x, c00, 0, 0, 0);
+                        if (SECOND) c10 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, b1.x, c10, 0, 0, 0);
+                        c01 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, b0.y, c01, 0, 0, 0);
+                        if (SECOND) c11 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, b1.y, c11, 0, 0, 0);
+                        c00 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, b0.z, c00, 0, 0, 0);
+                        if (SECOND) c10 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, b1.z, c10, 0, 0, 0);
+                        c01 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, b0.w, c01, 0, 0, 0);
+                        if (SECOND) c11 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, b1.w, c11, 0, 0, 0);
+                        // the scheduler must leave the request HERE: left alone it sinks every load down to its use (fewer registers),
+                        // i.e. load / wait for it / 8 MFMAs -- no chunk in flight at all. Unconditional on a clamped (always valid) piece.
+                        __builtin_amdgcn_sched_barrier(0);
+                        const int cn = c + NB;
+                        if (EXACT && SMALL && cn >= MAXC) continue;  // one pair per wave: nothing left to request
+                        const bool next = wrap && cn >= kc1;  // wave-uniform: the request belongs to the next pair
+                        // (readfirstlane: under scalar-register pressure the compiler moves this index arithmetic to the vector unit and
+                        // then wraps every load in a first-lane loop)
+                        bq0[u] = v2_piece(w2rs, lane16, __builtin_amdgcn_readfirstlane(next ? base_na + cn : base_a + min(cn, kc1 - 1)));
+                        bq1[u] = v2_piece(w2rs, lane16, __builtin_amdgcn_readfirstlane(next ? base_nb + cn : base_b + min(cn, kc1 - 1)));
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (SMALL && t == wave_s && (c & 3) == 3) V2_STAMP2(1 + (c >> 2));
                     }
-                    __builtin_amdgcn_sched_barrier(0);
-                    if ((c & 3) == 3) V2_STAMP2(1 + (c >> 2));
                 }
             };
             if (second) walk(std::true_type{});
             else walk(std::false_type{});
-            V2_EPILOGUE(t, second, true);
-            V2_STAMP2(5);
-        }
-    } else {
-        // K in stages of V2_CH chunks, two register sets: stage s + 1's operands in flight while stage s's MFMAs issue
-        const int nst = (kc1 + V2_CH - 1) / V2_CH;
-        for (int t = wave; t < kc2; t += 2 * WAVES) {
-            const bool second = t + WAVES < kc2;  // wave-uniform
-            const float4 *wb0 = w2s + (int64_t)t * kc1 * 64 + lane, *wb1 = w2s + (int64_t)(second ? t + WAVES : t) * kc1 * 64 + lane;
-            f32x4 c00 = {0.0f, 0.0f, 0.0f, 0.0f}, c01 = c00, c10 = c00, c11 = c00;
-            float4 aA[V2_CH], aB[V2_CH], b0A[V2_CH], b1A[V2_CH], b0B[V2_CH], b1B[V2_CH];
-#define V2_LOAD(S, AV, B0, B1) do { _Pragma("unroll") for (int u = 0; u < V2_CH; ++u) { const int c = min((S) * V2_CH + u, kc1 - 1); \
-                B0[u] = wb0[(int64_t)c * 64]; B1[u] = wb1[(int64_t)c * 64]; \
-                AV[u] = *reinterpret_cast<const float4 *>(ar + 16 * c); } } while (0)
-#define V2_MFMA(S, AV, B0, B1, FULL) do { if (second) v2_mfma_stage<true, FULL>((S) * V2_CH, kc1, AV, B0, B1, c00, c01, c10, c11); \
-                else v2_mfma_stage<false, FULL>((S) * V2_CH, kc1, AV, B0, B1, c00, c01, c10, c11); } while (0)
-            if (t == wave) {
-#pragma unroll
-                for (int u = 0; u < V2_CH; ++u) {
-                    b0A[u] = bq0[u % NB];
-                    b1A[u] = bq1[u % NB];
-                    aA[u] = *reinterpret_cast<const float4 *>(ar + 16 * min(u, kc1 - 1));
-                }
-            } else {
-                V2_LOAD(0, aA, b0A, b1A);
-            }
-            // Steady state WITHOUT a branch around any load: hipcc's s_waitcnt insertion merges the "loaded" and "not loaded" paths
-            // of a conditional prefetch and then waits for the NEW loads before the current stage's MFMAs (vmcnt(7), (5), (3), (1)
-            // in the first build of this loop: no overlap at all). Only the last stage can hold chunks beyond K.
-            int s = 0;
-            for (; s + 2 < nst; s += 2) {
-                V2_LOAD(s + 1, aB, b0B, b1B);
-                V2_MFMA(s, aA, b0A, b1A, true);
-                V2_LOAD(s + 2, aA, b0A, b1A);
-                V2_MFMA(s + 1, aB, b0B, b1B, true);
-            }
-            if (s + 1 < nst) {
-                V2_LOAD(s + 1, aB, b0B, b1B);
-                V2_MFMA(s, aA, b0A, b1A, true);
-                V2_MFMA(s + 1, aB, b0B, b1B, false);
-            } else {
-                V2_MFMA(s, aA, b0A, b1A, false);
-            }
-#undef V2_LOAD
-#undef V2_MFMA
-            V2_EPILOGUE(t, second, t == wave);
+            if (wrap) ring_t = tn;
+            V2_EPILOGUE(t, second, t == wave_s);
+            if (t == wave_s) V2_STAMP2(5);
         }
     }
 #undef V2_EPILOGUE
@@ -1887,21 +1860,6 @@ __device__ __forceinline__ void policy_rows_v2_body(const PolicyArgs &a, const R
     }
     POLICY_BARRIER();
     V2_STAMP(5);
-    if (FUSE && mt_wave) {  // an idle wave from here on: the draw runs beside the sampling tail and the collect step of waves 0-1
-        // ReplayBuffer.sample's two index draws for the gather launch behind this one (buffers.py:112-113, :309), with the ring
-        // as ReplayBuffer.add leaves it after THIS launch's row: upper = rows if full else pos (buffers.py:280-283, :112)
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        const int64_t rpos = ro->ring_ctl[0], rows = ro->c.ring.rows;
-        const int64_t upper = (ro->ring_ctl[1] || rpos + 1 == rows) ? rows : rpos + 1;
-        int pos = (int)ro->mt_state[MT_N];
-        pos = mt_randint_fill_wave(mt_lds, pos, (uint32_t)(upper - 1), ro->batch, ro->sample_idx, lane);
-        pos = mt_randint_fill_wave(mt_lds, pos, (uint32_t)(ro->c.ring.n_envs - 1), ro->batch, ro->sample_idx + ro->batch, lane);
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-#pragma unroll
-        for (int i = 0; i < MT_Q; ++i)
-            if (lane + 64 * i < MT_N) ro->mt_state[lane + 64 * i] = mt_lds[lane + 64 * i];
-        if (lane == 0) ro->mt_state[MT_N] = (uint32_t)pos;
-    }
 
     // tail: a lane per (row, output slot): thread = 8 * row + j
     const int trow = tid >> 3, j = tid & 7;
@@ -1982,22 +1940,48 @@ __device__ __forceinline__ void policy_rows_v2_body(const PolicyArgs &a, const R
 template <int ACT, int HEAD, bool VEC0, bool K0_SMALL, bool SMALL>
 __global__ __launch_bounds__(64 * POLICY_WAVES) void policy_rows_v2_kernel(const PolicyArgs a)
 {
-    policy_rows_v2_body<ACT, HEAD, VEC0, K0_SMALL, SMALL, false>(a, nullptr);
+    policy_rows_v2_body<ACT, HEAD, VEC0, K0_SMALL, SMALL ? 1 : 0, false>(a, nullptr);
 }
 
 // The rollout of one vec-step in ONE launch: policy network + sampling (policy_rows_v2_body) + fused collect step + the replay
 // index draw (RolloutArgs). Layer-1 input width <= 16 (the CSTR observations), 16-byte aligned rows.
-template <int ACT, int HEAD, bool SMALL>
+template <int ACT, int HEAD, int SHAPE>
 __global__ __launch_bounds__(64 * POLICY_WAVES) void rollout_step_kernel(const float *x, const int64_t ldx, const float *w1, const float *b1,
                                                                          const float *w2s, const int m, const int k0, const int h1, const int h2,
                                                                          const PolicyArgs a0, const RolloutArgs ro)
 {
+    // ReplayBuffer.sample's two index draws for the gather launch behind this one (buffers.py:112-113, :309) run on ONE wave of an extra
+    // workgroup (the grid's last one, present when mt_state is given): it shares a CU with a policy workgroup, starts at t = 0 and is done
+    // (~4 us of serial MT19937 work) long before the launch ends. On an idle wave of the last policy workgroup, beside its sampling tail,
+    // the draw ended 0.6 us AFTER everybody else (tools/rollout_ab.py: 9.9 us without the draw, 10.5 with it).
+    if (ro.mt_state != nullptr && blockIdx.x == gridDim.x - 1) {
+        __shared__ uint32_t mt_lds[MT_N];
+        const int lane = threadIdx.x & 63;
+        if (threadIdx.x >= 64) return;
+        constexpr int MT_Q = (MT_N + 63) / 64;
+#pragma unroll
+        for (int i = 0; i < MT_Q; ++i)
+            if (lane + 64 * i < MT_N) mt_lds[lane + 64 * i] = ro.mt_state[lane + 64 * i];
+        // the ring as ReplayBuffer.add leaves it after THIS launch's row: upper = rows if full else pos (buffers.py:280-283, :112)
+        const int64_t rpos = ro.ring_ctl[0], rows = ro.c.ring.rows;
+        const int64_t upper = (ro.ring_ctl[1] || rpos + 1 == rows) ? rows : rpos + 1;
+        int pos = (int)ro.mt_state[MT_N];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        pos = mt_randint_fill_wave(mt_lds, pos, (uint32_t)(upper - 1), ro.batch, ro.sample_idx, lane);
+        pos = mt_randint_fill_wave(mt_lds, pos, (uint32_t)(ro.c.ring.n_envs - 1), ro.batch, ro.sample_idx + ro.batch, lane);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+        for (int i = 0; i < MT_Q; ++i)
+            if (lane + 64 * i < MT_N) ro.mt_state[lane + 64 * i] = mt_lds[lane + 64 * i];
+        if (lane == 0) ro.mt_state[MT_N] = (uint32_t)pos;
+        return;
+    }
     // the leading scalars (14 dwords: preloaded into SGPRs) are what layer 1's operand requests and the L2 warm-up touch need; the same
     // fields of a0 are not read
     uint32_t kt = kernarg_touch_issue<64 + sizeof(PolicyArgs) + sizeof(RolloutArgs)>();
     PolicyArgs a = a0;
     a.x = x; a.ldx = ldx; a.w1 = w1; a.b1 = b1; a.w2s = w2s; a.m = m; a.k0 = k0; a.h1 = h1; a.h2 = h2;
-    policy_rows_v2_body<ACT, HEAD, true, true, SMALL, true>(a, &ro, &kt);
+    policy_rows_v2_body<ACT, HEAD, true, true, SHAPE, true>(a, &ro, &kt);
 }
 
 // ---- loss heads (single workgroup; batch <= 16384) -----------------------------------------------------
@@ -2646,15 +2630,17 @@ extern "C" int cstr_rollout_step_f32(const cstr_policy_mlp_t *net, const float *
     // reserved bit 0 is implied: nobody advances a control word in this launch (the gather launch behind it does)
     PolicyArgs a = {x, ldx, n.k0, n.w1, n.b1, n.h1, n.w2, n.b2, n.h2, n.w3, n.b3, n.act_dim, n.out_act, nullptr, rng_ctl,
                     action_out, n.act_dim, nullptr, m, n.w2_swizzled, n.reserved | 1};
-    const unsigned grid = (unsigned)((m + POLICY_ROWS - 1) / POLICY_ROWS);
+    const unsigned grid = (unsigned)((m + POLICY_ROWS - 1) / POLICY_ROWS) + (mt_state ? 1u : 0u);  // + the index-draw workgroup
     const size_t lds2 = policy_v2_lds(n);
     const bool small = (n.h1 + 15) / 16 <= 16 && (n.h2 + 15) / 16 <= 16;
     hipStream_t s = (hipStream_t)stream;
-#define ROL2(A, H) do { if (small) rollout_step_kernel<A, H, true><<<grid, 64 * POLICY_WAVES, lds2, s>>>(a.x, a.ldx, a.w1, a.b1, a.w2s, (int)a.m, a.k0, a.h1, a.h2, a, ro); \
-                        else rollout_step_kernel<A, H, false><<<grid, 64 * POLICY_WAVES, lds2, s>>>(a.x, a.ldx, a.w1, a.b1, a.w2s, (int)a.m, a.k0, a.h1, a.h2, a, ro); } while (0)
+#define ROL3(A, H, S) rollout_step_kernel<A, H, S><<<grid, 64 * POLICY_WAVES, lds2, s>>>(a.x, a.ldx, a.w1, a.b1, a.w2s, (int)a.m, a.k0, a.h1, a.h2, a, ro)
+#define ROL2(A, H) do { if (n.h1 == 256 && n.h2 == 256) ROL3(A, H, 2); else if (n.h1 == 400 && n.h2 == 300) ROL3(A, H, 3); else if (small) ROL3(A, H, 1); \
+                        else ROL3(A, H, 0); } while (0)
     if (n.head == 0) { if (n.act == 0) ROL2(0, 0); else if (n.act == 1) ROL2(1, 0); else ROL2(2, 0); }
     else { if (n.act == 0) ROL2(0, 1); else if (n.act == 1) ROL2(1, 1); else ROL2(2, 1); }
 #undef ROL2
+#undef ROL3
     return (int)hipGetLastError();
 }
 
