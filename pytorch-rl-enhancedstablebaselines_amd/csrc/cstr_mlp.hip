@@ -1572,7 +1572,8 @@ __device__ __forceinline__ void policy_rows_v2_body(const PolicyArgs &a, const R
     extern __shared__ float policy_lds[];
     const int H1 = EXACT ? H1C : a.h1, H2 = EXACT ? H2C : a.h2, kc1 = (H1 + 15) >> 4, kc2 = (H2 + 15) >> 4, S1 = 16 * kc1 + 4, S2 = 16 * kc2 + 4;
     float *h1s = policy_lds, *h2s = h1s + POLICY_ROWS * S1, *part = h2s + POLICY_ROWS * S2;  // part [8 waves][16 rows][8]
-    float *eps_s = part + WAVES * POLICY_ROWS * 8, *term = eps_s + POLICY_ROWS * 8;          // eps [16][8], terms [2][16][8]
+    float *eps_s = part + WAVES * POLICY_ROWS * 8, *term = eps_s + POLICY_ROWS * 8;          // eps [16][8] (radius), terms [2][16][8]
+    float *csn_s = term + 2 * POLICY_ROWS * 8;                                                 // [16][8]: cos | sin of the draw's angle
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, h = lane >> 4;
     const int64_t m0 = (int64_t)blockIdx.x * POLICY_ROWS;
     const float4 *w2s = reinterpret_cast<const float4 *>(a.w2s);
@@ -1656,7 +1657,10 @@ __device__ __forceinline__ void policy_rows_v2_body(const PolicyArgs &a, const R
     // With the draw in front of them the requests sat behind everybody else's in the CU's in-order queue and wave 7 left layer 2
     // ~1 us after the other seven (in-kernel stamps, profiles/r02_rollout_phase_stamps.json); on a layer-1 wave, between requesting
     // its operands and using them, the draw delayed the first barrier by as much as it saved.
-    const bool noise_wave = draw && wave == WAVES - 1;
+    // Round 3: TWO waves, each with half of Box-Muller behind its own Philox call (same counters, same words): wave 7 the radius
+    // sqrt(-2 log u1), wave 6 cos / sin of the angle; the sampling tail multiplies them (z = r * cos, r * sin: the same single product).
+    const bool noise_wave = draw && wave >= WAVES - 2;
+    const bool radius_wave = wave == WAVES - 1;  // wave-uniform
     auto draw_noise = [&]() {
         // the stream's control words are read HERE, by the one wave that needs them: a dependent scalar load at the top of the
         // kernel sits in front of every wave's first vector loads (the scalar-memory wait in front of them covers it too)
@@ -1670,11 +1674,17 @@ __device__ __forceinline__ void policy_rows_v2_body(const PolicyArgs &a, const R
 #endif
                 const uint64_t ctr = base + (uint64_t)row;
                 uint32_t rnd[4];
-                float e0, e1;
                 philox4x32_10((uint32_t)ctr, (uint32_t)(ctr >> 32), (uint32_t)(j0 >> 1), 0u, (uint32_t)seed, (uint32_t)(seed >> 32), rnd);
-                box_muller(rnd[0], rnd[1], e0, e1);
-                eps_s[lane * 8 + j0] = e0;
-                if (j0 + 1 < a.act_dim) eps_s[lane * 8 + j0 + 1] = e1;
+                if (radius_wave) {
+                    const float rad = box_muller_radius(rnd[0]);
+                    eps_s[lane * 8 + j0] = rad;
+                    eps_s[lane * 8 + j0 + 1] = rad;
+                } else {
+                    float cs, sn;
+                    box_muller_angle(rnd[1], cs, sn);
+                    csn_s[lane * 8 + j0] = cs;
+                    csn_s[lane * 8 + j0 + 1] = sn;
+                }
             }
         }
         V2_STAMP(7);
@@ -1686,21 +1696,10 @@ __device__ __forceinline__ void policy_rows_v2_body(const PolicyArgs &a, const R
         if (p2 > 0 && tid < POLICY_ROWS * p2) h2s[(tid / max(p2, 1)) * S2 + H2 + tid % max(p2, 1)] = 0.0f;
     }
     if (!l1_wave) {
-        if (noise_wave) draw_noise();  // in front of its few ring requests: nobody is waiting for them before the first barrier
         warm_wait();
         V2_REQUEST_B(0, PRE_YOUNG);
+        if (noise_wave) draw_noise();  // behind its ring requests (8 loads, not the 32 of round 2: their issue is short)
     } else if (K0_SMALL) {
-        if (FUSE && wave < (POLICY_ROWS * 8) / 64) {  // the collect step's operands of this lane's env: requested now, used by the sampling tail
-            const int64_t e = min(m0 + (tid >> 3), a.m - 1);
-            // a VECTOR load (per-lane zero offset the compiler cannot see through): as a scalar load the cold round trip of the ring
-            // position counts in lgkmcnt, which the LDS-only first barrier waits for -- waves 0-1 arrived ~1,100 cycles after waves 2-3
-            int zero;
-            asm volatile("v_mov_b32 %0, 0" : "=v"(zero));
-            ring_pos = ro->ring_ctl[zero];
-            if (ro->layout == 0) collect_quad_load<0>(ro->c, e, tid & 7, env_q);
-            else if (ro->layout == 1) collect_quad_load<1>(ro->c, e, tid & 7, env_q);
-            else if (env_lane) collect_env_load<2>(ro->c, e, env_in);
-        }
 #pragma unroll
         for (int i = 0; i < L1_T; ++i) {
             const int t = wave + L1_WAVES * i;
@@ -1743,6 +1742,20 @@ __device__ __forceinline__ void policy_rows_v2_body(const PolicyArgs &a, const R
     POLICY_BARRIER();
     V2_STAMP(2);
 #undef V2_REQUEST_B
+    if (FUSE && K0_SMALL && wave < (POLICY_ROWS * 8) / 64) {
+        // The collect step's operands of this lane's env, used by the sampling tail: requested HERE, behind the first barrier -- in
+        // front of it the argument reads of this block (a chain of scalar-cache round trips) held waves 0-1, and with them the barrier,
+        // ~1,100 cycles longer than waves 2-3; the loads land while the wave walks its first chunks of layer 2.
+        const int64_t e = min(m0 + (tid >> 3), a.m - 1);
+        // the ring position as a VECTOR load (per-lane zero offset the compiler cannot see through): a scalar load's cold round trip
+        // counts in lgkmcnt, which every LDS wait of layer 2 would sit out
+        int zero;
+        asm volatile("v_mov_b32 %0, 0" : "=v"(zero));
+        ring_pos = ro->ring_ctl[zero];
+        if (ro->layout == 0) collect_quad_load<0>(ro->c, e, tid & 7, env_q);
+        else if (ro->layout == 1) collect_quad_load<1>(ro->c, e, tid & 7, env_q);
+        else if (env_lane) collect_env_load<2>(ro->c, e, env_in);
+    }
 
     // layer 2: tile pairs (t, t + 8); column = lane & 15, row = 4 * (lane >> 4) + register in the epilogue
     const float *ar = h1s + r * S1 + 4 * h;
@@ -1884,7 +1897,7 @@ __device__ __forceinline__ void policy_rows_v2_body(const PolicyArgs &a, const R
         if (live && j < a.act_dim) {
             const float half_log_2pi = 0.91893853320467274178f;
             const float mu = head_out(j, b3v0), raw = head_out(a.act_dim + j, b3v1);
-            const float e = a.eps_in ? a.eps_in[row * a.act_dim + j] : eps_s[trow * 8 + j];
+            const float e = a.eps_in ? a.eps_in[row * a.act_dim + j] : eps_s[trow * 8 + j] * csn_s[trow * 8 + j];
             const float ls = fminf(fmaxf(raw, LOG_STD_MIN), LOG_STD_MAX);
             const float sd = expf(ls);
             const float u = mu + sd * e;
@@ -2556,7 +2569,7 @@ static int check_policy_net(const cstr_policy_mlp_t *net, const float *x, int64_
 static size_t policy_v2_lds(const cstr_policy_mlp_t &n)
 {
     const int kc1 = (n.h1 + 15) / 16, kc2 = (n.h2 + 15) / 16;
-    return (size_t)(POLICY_ROWS * (16 * kc1 + 4 + 16 * kc2 + 4) + POLICY_WAVES * POLICY_ROWS * 8 + 3 * POLICY_ROWS * 8) * sizeof(float);
+    return (size_t)(POLICY_ROWS * (16 * kc1 + 4 + 16 * kc2 + 4) + POLICY_WAVES * POLICY_ROWS * 8 + 4 * POLICY_ROWS * 8) * sizeof(float);
 }
 
 extern "C" int cstr_policy_rows_fwd_f32(const cstr_policy_mlp_t *net, const float *x, int64_t ldx, const float *eps, uint64_t *rng_ctl,

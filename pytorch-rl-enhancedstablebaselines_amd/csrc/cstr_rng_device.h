@@ -19,15 +19,26 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-__device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float &z0, float &z1)
+// Box-Muller in two independent halves (the rollout kernel gives them to two waves): z0 = radius(a) * cos, z1 = radius(a) * sin
+__device__ __forceinline__ float box_muller_radius(uint32_t a)
 {
     const float u1 = ((float)(a >> 8) + 0.5f) * (1.0f / 16777216.0f);  // (0, 1): 24 random bits, never 0
+    return sqrtf(-2.0f * logf(u1));
+}
+
+// cos / sin(2 pi u2) through sincospif: one shared, exact argument reduction (the angle is given in half-turns) instead of two
+// full-range reductions of 2 pi u2 -- the same distribution, a shorter dependent chain
+__device__ __forceinline__ void box_muller_angle(uint32_t b, float &cs, float &sn)
+{
     const float u2 = ((float)(b >> 8) + 0.5f) * (1.0f / 16777216.0f);
-    // cos / sin(2 pi u2) through sincospif: one shared, exact argument reduction (the angle is given in half-turns) instead of two
-    // full-range reductions of 2 pi u2 -- the same distribution, a shorter dependent chain (the rollout's noise is drawn by ONE wave)
-    const float r = sqrtf(-2.0f * logf(u1));
-    float sn, cs;
     sincospif(2.0f * u2, &sn, &cs);
+}
+
+__device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float &z0, float &z1)
+{
+    const float r = box_muller_radius(a);
+    float sn, cs;
+    box_muller_angle(b, cs, sn);
     z0 = r * cs;
     z1 = r * sn;
 }
