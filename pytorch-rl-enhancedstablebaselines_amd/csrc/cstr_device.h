@@ -46,35 +46,6 @@ static inline void flat_launch_shape(int64_t n_vec, int &block, int &grid)
 }
 
 #ifdef __HIPCC__
-// A kernel with a few hundred bytes of arguments in a struct reads them with scalar loads where it first needs them: hipcc places
-// each s_load (+ s_waitcnt) in front of its first use, and every 64-byte line of the kernarg segment it has not touched yet is a
-// miss of the scalar cache, one after the other, in front of the launch's first vector loads. Two measures:
-//   * the few values a kernel's FIRST vector loads need are separate leading scalar parameters: gfx950 preloads them into SGPRs
-//     with the wave (-amdgpu-kernarg-preload-count; struct parameters are never preloaded), so those loads leave at once;
-//   * kernarg_touch_issue<BYTES>() requests one dword of every further line right away, kernarg_touch_wait() behind the first
-//     vector loads waits for all of them ONCE: the compiler's own scalar loads then hit.
-template <int LINE>
-__device__ __forceinline__ void kernarg_touch_line(const uint64_t kp, uint32_t &d)
-{
-    asm volatile("s_load_dword %0, %1, %2" : "+s"(d) : "s"(kp), "n"(LINE * 64));
-}
-// ONE destination for all touches (the values are not used); it stays reserved until kernarg_touch_wait() (the compiler does not
-// know that an asm load's result arrives later)
-template <int BYTES>
-__device__ __forceinline__ uint32_t kernarg_touch_issue()
-{
-    constexpr int LINES = (BYTES + 63) / 64;
-    static_assert(LINES <= 17, "add touches");
-    const uint64_t kp = (uint64_t)__builtin_amdgcn_kernarg_segment_ptr();
-    uint32_t d = 0;
-#define CSTR_KT(i) if (LINES > (i) + 1) kernarg_touch_line<(i) + 1>(kp, d);
-    CSTR_KT(0) CSTR_KT(1) CSTR_KT(2) CSTR_KT(3) CSTR_KT(4) CSTR_KT(5) CSTR_KT(6) CSTR_KT(7)
-    CSTR_KT(8) CSTR_KT(9) CSTR_KT(10) CSTR_KT(11) CSTR_KT(12) CSTR_KT(13) CSTR_KT(14) CSTR_KT(15)
-#undef CSTR_KT
-    return d;
-}
-__device__ __forceinline__ void kernarg_touch_wait(uint32_t &d) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(d)); }
-
 // "Last workgroup out" ticket: every workgroup has finished READING the control words it needs before it
 // takes a ticket (the barrier orders its waves' loads, whose values were already consumed for addressing),
 // so the workgroup that draws gridDim.x-1 may advance them. No data is handed between workgroups inside the

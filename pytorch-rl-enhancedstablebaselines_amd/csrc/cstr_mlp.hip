@@ -1557,7 +1557,7 @@ struct RolloutArgs {
 // networks of SAC and of TD3 / DDPG / MADDPG: every loop bound and piece index of layer 2 is a constant -- with run-time widths the
 // hoisted bounds and indices overflow the scalar registers and come back through v_readlane in front of every request)
 template <int ACT, int HEAD, bool VEC0, bool K0_SMALL, int SHAPE, bool FUSE>
-__device__ __forceinline__ void policy_rows_v2_body(const PolicyArgs &a, const RolloutArgs *ro, uint32_t *kernarg_touch = nullptr)
+__device__ __forceinline__ void policy_rows_v2_body(const PolicyArgs &a, const RolloutArgs *ro)
 {
     constexpr bool SMALL = SHAPE == 1 || SHAPE == 2, EXACT = SHAPE >= 2;
     constexpr int H1C = SHAPE == 2 ? 256 : 400, H2C = SHAPE == 2 ? 256 : 300;
@@ -1599,8 +1599,8 @@ __device__ __forceinline__ void policy_rows_v2_body(const PolicyArgs &a, const R
 #pragma unroll
         for (int i = 0; i < WARM_N; ++i) asm volatile("" ::"v"(warm[i]));  // the value has to be in its register here
     };
-    // ---- the launch's first requests: everything up to the sched_barrier reads only what the kernel's leading scalar parameters carry
-    // (preloaded SGPRs); the first wait for the argument structs sits behind them ----
+    // ---- the launch's first requests: everything up to the sched_barrier reads only what the rollout kernel's leading scalar parameters
+    // carry (preloaded SGPRs); the first wait for the argument structs sits behind them ----
     float4 xa = make_float4(0.0f, 0.0f, 0.0f, 0.0f), w1v[L1_T];
     float b1v[L1_T];
     warm_issue();  // in front of layer 1's operands: their out-of-range zeroing below already waits for them
@@ -1613,7 +1613,6 @@ __device__ __forceinline__ void policy_rows_v2_body(const PolicyArgs &a, const R
             b1v[i] = a.b1[min(n, H1 - 1)];
         }
     }
-    if (kernarg_touch) kernarg_touch_wait(*kernarg_touch);
     __builtin_amdgcn_sched_barrier(0);
     const bool draw = HEAD == 0 && a.rng_ctl != nullptr;
     const int n_out = HEAD == 0 ? 2 * a.act_dim : a.act_dim;
@@ -1989,12 +1988,12 @@ __global__ __launch_bounds__(64 * POLICY_WAVES) void rollout_step_kernel(const f
         if (lane == 0) ro.mt_state[MT_N] = (uint32_t)pos;
         return;
     }
-    // the leading scalars (14 dwords: preloaded into SGPRs) are what layer 1's operand requests and the L2 warm-up touch need; the same
-    // fields of a0 are not read
-    uint32_t kt = kernarg_touch_issue<64 + sizeof(PolicyArgs) + sizeof(RolloutArgs)>();
+    // The leading scalars (14 dwords: gfx950 preloads them into SGPRs with the wave; struct parameters are never preloaded) are what
+    // layer 1's operand requests and the L2 warm-up touch need: those leave before the first scalar load of the argument structs
+    // has returned. The same fields of a0 are not read.
     PolicyArgs a = a0;
     a.x = x; a.ldx = ldx; a.w1 = w1; a.b1 = b1; a.w2s = w2s; a.m = m; a.k0 = k0; a.h1 = h1; a.h2 = h2;
-    policy_rows_v2_body<ACT, HEAD, true, true, SHAPE, true>(a, &ro, &kt);
+    policy_rows_v2_body<ACT, HEAD, true, true, SHAPE, true>(a, &ro);
 }
 
 // ---- loss heads (single workgroup; batch <= 16384) -----------------------------------------------------
