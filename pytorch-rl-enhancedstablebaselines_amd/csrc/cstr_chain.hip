@@ -53,6 +53,16 @@ __device__ __forceinline__ float ld32(const __amdgpu_buffer_rsrc_t rs, const int
     return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, byte_off, 0, 0));
 }
 
+// WX: the class-default hidden widths as compile-time constants -- 1 = 256 x 256 (SAC), 2 = 400 x 300 (TD3 / DDPG / MADDPG), 0 = run-time
+// widths. With run-time widths and tiles the kernels' loop bounds, split-K shares and operand offsets are hoisted into dozens of
+// scalars that overflow the SGPR file (v_readlane / v_writelane traffic) and every trip count is a compare-and-branch; the SAC iteration
+// at the class defaults went 0.0662 -> 0.0613 ms with them constant (A/B on MI355X, profiles/r03_notes.md section 10). The column
+// groups per workgroup follow from the per-wave share NQ the host picked: 256 / 16 = 16 chunks over S = 4 / T waves -> NQ = 4 T;
+// 400 (25 chunks) or 300 (19 chunks) over S waves, rounded up to the instantiated share -> NQ = 8 T.
+template <int WX> __device__ __forceinline__ constexpr int exact_h1() { return WX == 1 ? 256 : 400; }
+template <int WX> __device__ __forceinline__ constexpr int exact_h2() { return WX == 1 ? 256 : 300; }
+template <int NQ, int WX> __device__ __forceinline__ constexpr int exact_tiles() { return WX == 1 ? NQ / 4 : (NQ >= 8 ? NQ / 8 : 1); }  // (400 x 300 with a share of 4 is never dispatched)
+
 #ifdef CSTR_CHAIN_STAMPS  // diagnostic build only (make diag): s_memtime per wave at the phase boundaries, read by tools/chain_stamps.py
 __device__ unsigned long long chain_stamps[4 * 1024 * 4 * 8];  // [kernel][workgroup (linear, < 1024)][wave][stamp]
 #define CH_STAMP(K, I) do { const unsigned wg_ = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x; \
@@ -336,14 +346,14 @@ struct ActorFwdArgs {
     int rows_mode, head_n;  // CSTR_CHAIN_ROWS_*; head outputs: 2A (mu | log_std) or A (deterministic actor)
 };
 
-template <int D, int A, int NQ>
+template <int D, int A, int NQ, int WX>
 __global__ __launch_bounds__(CH_THREADS) void sac_actor_chain_fwd_kernel(const ActorFwdArgs a)
 {
     extern __shared__ __align__(16) float smem[];
     constexpr int W = D + A, QPR = D / 4;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, r = lane & 15, h = lane >> 4;
-    const int T = a.tiles, S = CH_WAVES / T, tile = wave % T, ks = wave / T;
-    const int H1 = a.net.h1, H2 = a.net.h2, B = a.batch, mode = a.rows_mode, HN = a.head_n;
+    const int T = WX ? exact_tiles<NQ, WX>() : a.tiles, S = CH_WAVES / T, tile = wave % T, ks = wave / T;
+    const int H1 = WX ? exact_h1<WX>() : a.net.h1, H2 = WX ? exact_h2<WX>() : a.net.h2, B = a.batch, mode = a.rows_mode, HN = a.head_n;
     const int M = mode == CSTR_CHAIN_ROWS_PAIR ? 2 * B : B;
     const int n0 = (blockIdx.x * T + tile) * 16, m0 = blockIdx.y * 16;
     float *xs = smem + SM_XS, *red = smem + SM_RED, *panel = smem + SM_PANEL;
@@ -496,15 +506,15 @@ struct QFwdArgs {
     int n_nets, h1, h2, batch, tiles, has_fin;
 };
 
-template <int D, int A, int NQ>
+template <int D, int A, int NQ, int WX>
 __global__ __launch_bounds__(CH_THREADS) void q_chain_fwd_kernel(const QFwdArgs a)
 {
     extern __shared__ __align__(16) float smem[];
     constexpr int W = D + A;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, r = lane & 15, h = lane >> 4;
-    const int T = a.tiles, S = CH_WAVES / T, tile = wave % T, ks = wave / T;
+    const int T = WX ? exact_tiles<NQ, WX>() : a.tiles, S = CH_WAVES / T, tile = wave % T, ks = wave / T;
     const cstr_chain_net_t &net = a.nets[blockIdx.z];
-    const int H1 = a.h1, H2 = a.h2, B = a.batch;
+    const int H1 = WX ? exact_h1<WX>() : a.h1, H2 = WX ? exact_h2<WX>() : a.h2, B = a.batch;
     const int n0 = (blockIdx.x * T + tile) * 16, m0 = blockIdx.y * 16;
     float *xs = smem + SM_XS, *red = smem + SM_RED, *panel = smem + SM_PANEL;
     const int ld = H1 + 4;
@@ -723,20 +733,20 @@ __device__ void chain_loss_workgroup(const cstr_chain_root_t &rt, float *sm)
     }
 }
 
-template <int D, int A, int NQ>
+template <int D, int A, int NQ, int WX>
 __global__ __launch_bounds__(CH_THREADS) void q_chain_bwd_kernel(const QBwdArgs a)
 {
     extern __shared__ __align__(16) float smem[];
     constexpr int W = D + A;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, r = lane & 15, h = lane >> 4;
     const cstr_chain_root_t &rt = a.root;
-    const int B = rt.batch, H1 = a.h1, H2 = a.h2;
+    const int B = rt.batch, H1 = WX ? exact_h1<WX>() : a.h1, H2 = WX ? exact_h2<WX>() : a.h2;
     const int g = blockIdx.z;
     if ((int)blockIdx.y == B / 16) {  // the loss workgroup
         if (g == 0 && blockIdx.x == 0) chain_loss_workgroup(rt, smem + SM_RED);
         return;
     }
-    const int T = a.tiles, S = CH_WAVES / T, tile = wave % T, ks = wave / T;
+    const int T = WX ? exact_tiles<NQ, WX>() : a.tiles, S = CH_WAVES / T, tile = wave % T, ks = wave / T;
     const cstr_chain_net_t &net = a.nets[g];
     const int k0 = (blockIdx.x * T + tile) * 16, m0 = blockIdx.y * 16;
     const bool col_ok = k0 + r < H1;
@@ -899,14 +909,14 @@ struct ActorBwdArgs {
     int batch, tiles, kind;  // CSTR_CHAIN_HEAD_*
 };
 
-template <int D, int A, int NQ>
+template <int D, int A, int NQ, int WX>
 __global__ __launch_bounds__(CH_THREADS) void sac_actor_chain_bwd_kernel(const ActorBwdArgs a)
 {
     extern __shared__ __align__(16) float smem[];
     constexpr int W = D + A;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, r = lane & 15, h = lane >> 4;
-    const int T = a.tiles, S = CH_WAVES / T, tile = wave % T, ks = wave / T;
-    const int H1 = a.net.h1, H2 = a.net.h2, B = a.batch;
+    const int T = WX ? exact_tiles<NQ, WX>() : a.tiles, S = CH_WAVES / T, tile = wave % T, ks = wave / T;
+    const int H1 = WX ? exact_h1<WX>() : a.net.h1, H2 = WX ? exact_h2<WX>() : a.net.h2, B = a.batch;
     const int k0 = (blockIdx.x * T + tile) * 16, m0 = blockIdx.y * 16;
     const bool col_ok = k0 + r < H1, det = a.kind == CSTR_CHAIN_HEAD_DETERMINISTIC;
     const int col = min(k0 + r, H1 - 1), HN = det ? A : 2 * A;
@@ -1035,12 +1045,12 @@ static int chain_layout(int obs_dim, int act_dim)
     return (obs_dim == 4 && act_dim == 2) ? 0 : (obs_dim == 8 && act_dim == 2) ? 1 : (obs_dim == 8 && act_dim == 4) ? 2 : -1;
 }
 
-#define CHAIN_NQ(KERNEL, D_, A_, NQV, GRID, LDS, STREAM, ARGS)                                     \
+#define CHAIN_NQ(KERNEL, D_, A_, WX_, NQV, GRID, LDS, STREAM, ARGS)                                \
     do {                                                                                           \
-        if ((NQV) == 4) KERNEL<D_, A_, 4><<<GRID, CH_THREADS, LDS, STREAM>>>(ARGS);                \
-        else if ((NQV) == 8) KERNEL<D_, A_, 8><<<GRID, CH_THREADS, LDS, STREAM>>>(ARGS);           \
-        else if ((NQV) == 16) KERNEL<D_, A_, 16><<<GRID, CH_THREADS, LDS, STREAM>>>(ARGS);         \
-        else KERNEL<D_, A_, NQ_TOP_##KERNEL><<<GRID, CH_THREADS, LDS, STREAM>>>(ARGS);             \
+        if ((NQV) == 4) KERNEL<D_, A_, 4, WX_><<<GRID, CH_THREADS, LDS, STREAM>>>(ARGS);           \
+        else if ((NQV) == 8) KERNEL<D_, A_, 8, WX_><<<GRID, CH_THREADS, LDS, STREAM>>>(ARGS);      \
+        else if ((NQV) == 16) KERNEL<D_, A_, 16, WX_><<<GRID, CH_THREADS, LDS, STREAM>>>(ARGS);    \
+        else KERNEL<D_, A_, NQ_TOP_##KERNEL, 0><<<GRID, CH_THREADS, LDS, STREAM>>>(ARGS);          \
     } while (0)
 // the widest per-wave share instantiated per kernel: the forward chains (B operand = 16-byte quads) also exist with 32 chunks (wide
 // first hidden layers with 4 tiles per workgroup: TD3's / MADDPG's 400); the backward chains stop at 16
@@ -1048,12 +1058,28 @@ static int chain_layout(int obs_dim, int act_dim)
 #define NQ_TOP_q_chain_fwd_kernel 32
 #define NQ_TOP_q_chain_bwd_kernel 16
 #define NQ_TOP_sac_actor_chain_bwd_kernel 16
-#define CHAIN_DISPATCH(KERNEL, LAY, NQV, GRID, LDS, STREAM, ARGS)                                  \
+// WXV (chain_wx): exact-width instantiations exist where a class default uses them -- 256 x 256 with the 4 / 2 and 8 / 2 layouts
+// (SAC on the 4- and 8-wide observation), 400 x 300 with 4 / 2 (TD3, DDPG) and 8 / 4 (MADDPG's twin train); everything else runs
+// the run-time-width kernels
+#define CHAIN_DISPATCH(KERNEL, LAY, WXV, NQV, GRID, LDS, STREAM, ARGS)                             \
     do {                                                                                           \
-        if ((LAY) == 0) CHAIN_NQ(KERNEL, 4, 2, NQV, GRID, LDS, STREAM, ARGS);                      \
-        else if ((LAY) == 1) CHAIN_NQ(KERNEL, 8, 2, NQV, GRID, LDS, STREAM, ARGS);                 \
-        else CHAIN_NQ(KERNEL, 8, 4, NQV, GRID, LDS, STREAM, ARGS);                                 \
+        if ((LAY) == 0 && (WXV) == 1) CHAIN_NQ(KERNEL, 4, 2, 1, NQV, GRID, LDS, STREAM, ARGS);     \
+        else if ((LAY) == 0 && (WXV) == 2) CHAIN_NQ(KERNEL, 4, 2, 2, NQV, GRID, LDS, STREAM, ARGS); \
+        else if ((LAY) == 0) CHAIN_NQ(KERNEL, 4, 2, 0, NQV, GRID, LDS, STREAM, ARGS);              \
+        else if ((LAY) == 1 && (WXV) == 1) CHAIN_NQ(KERNEL, 8, 2, 1, NQV, GRID, LDS, STREAM, ARGS); \
+        else if ((LAY) == 1) CHAIN_NQ(KERNEL, 8, 2, 0, NQV, GRID, LDS, STREAM, ARGS);              \
+        else if ((WXV) == 2) CHAIN_NQ(KERNEL, 8, 4, 2, NQV, GRID, LDS, STREAM, ARGS);              \
+        else CHAIN_NQ(KERNEL, 8, 4, 0, NQV, GRID, LDS, STREAM, ARGS);                              \
     } while (0)
+
+// which exact-width instantiation (0: none) serves widths (h1, h2) with `tiles` column groups per workgroup and per-wave share nq
+static int chain_wx(int h1, int h2, int tiles, int nq)
+{
+    if (nq != 4 && nq != 8 && nq != 16) return 0;
+    if (h1 == 256 && h2 == 256 && nq == 4 * tiles) return 1;
+    if (h1 == 400 && h2 == 300 && nq == 8 * tiles) return 2;
+    return 0;
+}
 
 constexpr size_t CHAIN_LDS_LIMIT = 64 * 1024;
 
@@ -1109,7 +1135,7 @@ extern "C" int cstr_sac_actor_chain_fwd_f32(const cstr_sac_actor_t *actor, const
     const int nq = nq_for(actor->h1, tiles, 32), lay = chain_layout(actor->obs_dim, actor->act_dim);
     if (!nq || lds > CHAIN_LDS_LIMIT) return CSTR_E_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
-    CHAIN_DISPATCH(sac_actor_chain_fwd_kernel, lay, nq, grid, lds, s, a);
+    CHAIN_DISPATCH(sac_actor_chain_fwd_kernel, lay, chain_wx(actor->h1, actor->h2, tiles, nq), nq, grid, lds, s, a);
     return (int)hipGetLastError();
 }
 
@@ -1146,7 +1172,7 @@ extern "C" int cstr_q_chain_fwd_f32(const cstr_chain_net_t *nets, int n_nets, in
     const int nq = nq_for(h1, tiles, 32), lay = chain_layout(obs_dim, w_in - obs_dim);
     if (!nq || lay < 0 || lds > CHAIN_LDS_LIMIT) return CSTR_E_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
-    CHAIN_DISPATCH(q_chain_fwd_kernel, lay, nq, grid, lds, s, a);
+    CHAIN_DISPATCH(q_chain_fwd_kernel, lay, chain_wx(h1, h2, tiles, nq), nq, grid, lds, s, a);
     return (int)hipGetLastError();
 }
 
@@ -1177,7 +1203,7 @@ extern "C" int cstr_q_chain_bwd_f32(const cstr_chain_net_t *nets, int n_nets, co
     const int nq = nq_for(h2, tiles), lay = chain_layout(obs_dim, w_in - obs_dim);
     if (!nq || lay < 0 || lds > CHAIN_LDS_LIMIT) return CSTR_E_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
-    CHAIN_DISPATCH(q_chain_bwd_kernel, lay, nq, grid, lds, s, a);
+    CHAIN_DISPATCH(q_chain_bwd_kernel, lay, chain_wx(h1, h2, tiles, nq), nq, grid, lds, s, a);
     return (int)hipGetLastError();
 }
 
@@ -1211,6 +1237,6 @@ extern "C" int cstr_sac_actor_chain_bwd_f32(const cstr_sac_actor_t *actor, const
     const int nq = nq_for(actor->h2, tiles), lay = chain_layout(actor->obs_dim, actor->act_dim);
     if (!nq || lds > CHAIN_LDS_LIMIT) return CSTR_E_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
-    CHAIN_DISPATCH(sac_actor_chain_bwd_kernel, lay, nq, grid, lds, s, a);
+    CHAIN_DISPATCH(sac_actor_chain_bwd_kernel, lay, chain_wx(actor->h1, actor->h2, tiles, nq), nq, grid, lds, s, a);
     return (int)hipGetLastError();
 }
