@@ -50,8 +50,11 @@ __device__ __forceinline__ void adam_body(float *__restrict__ param, const float
     // control words into the step's scalars (a dependent load of adam_ctl / lr, an f64 division and square root, a barrier) --
     // the two latencies overlap instead of adding up.
     const bool first = !stream_out && tid < nv;
-    float4 fp = make_float4(0.0f, 0.0f, 0.0f, 0.0f), fm = fp, fv = fp, fg = fp;
-    if (first) { fp = p4[tid]; fm = m4[tid]; fv = v4[tid]; fg = g4[tid]; }
+    float4 fp = make_float4(0.0f, 0.0f, 0.0f, 0.0f), fm = fp, fv = fp, fg = fp, ft = fp;
+    if (first) {
+        fp = p4[tid]; fm = m4[tid]; fv = v4[tid]; fg = g4[tid];
+        if (own_target) ft = reinterpret_cast<const float4 *>(own_target)[tid];  // (behind the stores of p / m / v it is one more round trip)
+    }
     if (threadIdx.x == 0) {
         // state["step"] += 1; beta^step is carried in adam_ctl as a running product (two f64 multiplies instead of two
         // f64 pow() calls in every workgroup's prologue: 5.4 -> ~2 us per launch at 136 k parameters)
@@ -68,12 +71,11 @@ __device__ __forceinline__ void adam_body(float *__restrict__ param, const float
     __syncthreads();
     const AdamScalars a = sa;
     typedef float v4f __attribute__((ext_vector_type(4)));
-    auto update = [&](const int64_t i, float4 p, float4 m, float4 v, const float4 g) {
+    auto update = [&](const int64_t i, float4 p, float4 m, float4 v, const float4 g, float4 t) {
         adam1(p.x, g.x, m.x, v.x, a); adam1(p.y, g.y, m.y, v.y, a);
         adam1(p.z, g.z, m.z, v.z, a); adam1(p.w, g.w, m.w, v.w, a);
         p4[i] = p; m4[i] = m; v4[i] = v;
         if (own_target) {  // the soft update of these parameters' target with the value just computed (cstr_polyak_f32's arithmetic)
-            float4 t = reinterpret_cast<float4 *>(own_target)[i];
             t.x = polyak1(p.x, t.x, tau, om); t.y = polyak1(p.y, t.y, tau, om);
             t.z = polyak1(p.z, t.z, tau, om); t.w = polyak1(p.w, t.w, tau, om);
             reinterpret_cast<float4 *>(own_target)[i] = t;
@@ -113,8 +115,9 @@ __device__ __forceinline__ void adam_body(float *__restrict__ param, const float
             p4[i] = p; m4[i] = m; v4[i] = v;
         }
     } else {
-        if (first) update(tid, fp, fm, fv, fg);
-        for (int64_t i = tid + stride; i < nv; i += stride) update(i, p4[i], m4[i], v4[i], g4[i]);
+        if (first) update(tid, fp, fm, fv, fg, ft);
+        for (int64_t i = tid + stride; i < nv; i += stride)
+            update(i, p4[i], m4[i], v4[i], g4[i], own_target ? reinterpret_cast<const float4 *>(own_target)[i] : fp);
     }
     for (int64_t i = (nv << 2) + tid; i < n; i += stride) {
         float p = param[i], m = exp_avg[i], v = exp_avg_sq[i];

@@ -548,6 +548,7 @@ __device__ __forceinline__ void linear_bwd_weight_tile(const float *__restrict__
     const bool n_ok = n0 + r < N, k_ok = k0 + r < K;
     const bool want_db = db != nullptr && tile_k == 0;
     float pw[4] = {0.0f, 0.0f, 0.0f, 0.0f}, pm[4] = {0.0f, 0.0f, 0.0f, 0.0f}, pv[4] = {0.0f, 0.0f, 0.0f, 0.0f}, bw = 0.0f, bm = 0.0f, bvv = 0.0f;
+    float pt[4] = {0.0f, 0.0f, 0.0f, 0.0f}, bt = 0.0f;  // the parameters' own target (soft update in the same pass)
     if (ADAM) {
         if (wave == 0 && k_ok) {
 #pragma unroll
@@ -555,10 +556,16 @@ __device__ __forceinline__ void linear_bwd_weight_tile(const float *__restrict__
                 if (n0 + 4 * h + e < N) {
                     const int64_t i = (int64_t)(n0 + 4 * h + e) * K + k0 + r;
                     pw[e] = ad->w[i]; pm[e] = ad->w_m[i]; pv[e] = ad->w_v[i];
+                    // requested HERE with the parameter and its moments: read where it is used -- behind the stores of p / m / v, which
+                    // the compiler cannot move it across -- it was one more cold round trip at the end of the launch
+                    if (ad->w_target) pt[e] = ad->w_target[i];
                 }
             }
         }
-        if (wave == 0 && want_db && lane < 16 && n_ok) { bw = ad->b[n0 + lane]; bm = ad->b_m[n0 + lane]; bvv = ad->b_v[n0 + lane]; }
+        if (wave == 0 && want_db && lane < 16 && n_ok) {
+            bw = ad->b[n0 + lane]; bm = ad->b_m[n0 + lane]; bvv = ad->b_v[n0 + lane];
+            if (ad->b_target) bt = ad->b_target[n0 + lane];
+        }
         if (threadIdx.x == 64 * (WAVES - 1)) adam_sc = adam_scalars_advanced(ad->adam_ctl, ad->lr, ad->beta1, ad->beta2, ad->eps, ad->gscale);
     }
     f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -630,7 +637,7 @@ __device__ __forceinline__ void linear_bwd_weight_tile(const float *__restrict__
                     const int64_t i = (int64_t)row * K + colk;
                     adam1(pw[e], acc[e], pm[e], pv[e], a);
                     ad->w[i] = pw[e]; ad->w_m[i] = pm[e]; ad->w_v[i] = pv[e];
-                    if (ad->w_target) ad->w_target[i] = polyak1(pw[e], ad->w_target[i], ad->tau, 1.0f - ad->tau);
+                    if (ad->w_target) ad->w_target[i] = polyak1(pw[e], pt[e], ad->tau, 1.0f - ad->tau);
                     if (ad->shadow)  // the tile-major copy the rollout kernel reads (cstr_policy_swizzle_f32's layout)
                         ad->shadow[(((int64_t)(row >> 4) * ((K + 15) >> 4) + (colk >> 4)) * 64 + (row & 15) + 16 * ((colk & 15) >> 2)) * 4 + (colk & 3)] = pw[e];
                 }
@@ -645,7 +652,7 @@ __device__ __forceinline__ void linear_bwd_weight_tile(const float *__restrict__
         if (ADAM) {
             adam1(bw, sum, bm, bvv, adam_sc);
             ad->b[n0 + lane] = bw; ad->b_m[n0 + lane] = bm; ad->b_v[n0 + lane] = bvv;
-            if (ad->b_target) ad->b_target[n0 + lane] = polyak1(bw, ad->b_target[n0 + lane], ad->tau, 1.0f - ad->tau);
+            if (ad->b_target) ad->b_target[n0 + lane] = polyak1(bw, bt, ad->tau, 1.0f - ad->tau);
         }
     }
 }
