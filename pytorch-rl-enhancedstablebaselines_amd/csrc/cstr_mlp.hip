@@ -1563,7 +1563,7 @@ struct RolloutArgs {
 // SHAPE: 0 = widths <= 512, 1 = widths <= 256 (one tile pair per wave), 2 = exactly 256 x 256 and 3 = exactly 400 x 300 (the class-default
 // networks of SAC and of TD3 / DDPG / MADDPG: every loop bound and piece index of layer 2 is a constant -- with run-time widths the
 // hoisted bounds and indices overflow the scalar registers and come back through v_readlane in front of every request)
-template <int ACT, int HEAD, bool VEC0, bool K0_SMALL, int SHAPE, bool FUSE>
+template <int ACT, int HEAD, bool VEC0, bool K0_SMALL, int SHAPE, bool FUSE, int ENV = -1>
 __device__ __forceinline__ void policy_rows_v2_body(const PolicyArgs &a, const RolloutArgs *ro)
 {
     constexpr bool SMALL = SHAPE == 1 || SHAPE == 2, EXACT = SHAPE >= 2;
@@ -1758,8 +1758,8 @@ __device__ __forceinline__ void policy_rows_v2_body(const PolicyArgs &a, const R
         int zero;
         asm volatile("v_mov_b32 %0, 0" : "=v"(zero));
         ring_pos = ro->ring_ctl[zero];
-        if (ro->layout == 0) collect_quad_load<0>(ro->c, e, tid & 7, env_q);
-        else if (ro->layout == 1) collect_quad_load<1>(ro->c, e, tid & 7, env_q);
+        if (ENV == 0 || (ENV < 0 && ro->layout == 0)) collect_quad_load<0>(ro->c, e, tid & 7, env_q);
+        else if (ENV == 3 || (ENV < 0 && ro->layout == 1)) collect_quad_load<1>(ro->c, e, tid & 7, env_q);
         else if (env_lane) collect_env_load<2>(ro->c, e, env_in);
     }
 
@@ -1934,11 +1934,13 @@ __device__ __forceinline__ void policy_rows_v2_body(const PolicyArgs &a, const R
         // action components from its neighbours and steps env `row`; the ring position is only READ here (the gather launch behind
         // this one advances it: cstr_replay_gather_packed_f32), so no workgroup hands anything to another one
         const int64_t ring_row = ring_pos * ro->c.ring.n_envs, env = min(row, a.m - 1);
-        const bool eu = ro->integrator == CSTR_INTEGRATOR_EULER;
-        if (ro->layout == 0) {
+        // ENV >= 0: the environment variant is a template constant (2 * layout + integrator) -- the six variants of the collect step are
+        // ~2.5 k instructions each, and only one of them runs
+        const bool eu = ENV >= 0 ? (ENV & 1) == 0 : ro->integrator == CSTR_INTEGRATOR_EULER;
+        if (ENV == 0 || (ENV < 0 && ro->layout == 0)) {
             if (eu) collect_env_quad<0, CSTR_INTEGRATOR_EULER>(ro->k, ro->c, ring_row, env, j, live, act_out, env_q);
             else collect_env_quad<0, CSTR_INTEGRATOR_RK4>(ro->k, ro->c, ring_row, env, j, live, act_out, env_q);
-        } else if (ro->layout == 1) {
+        } else if (ENV == 3 || (ENV < 0 && ro->layout == 1)) {
             if (eu) collect_env_quad<1, CSTR_INTEGRATOR_EULER>(ro->k, ro->c, ring_row, env, j, live, act_out, env_q);
             else collect_env_quad<1, CSTR_INTEGRATOR_RK4>(ro->k, ro->c, ring_row, env, j, live, act_out, env_q);
         } else {
@@ -1964,7 +1966,7 @@ __global__ __launch_bounds__(64 * POLICY_WAVES) void policy_rows_v2_kernel(const
 
 // The rollout of one vec-step in ONE launch: policy network + sampling (policy_rows_v2_body) + fused collect step + the replay
 // index draw (RolloutArgs). Layer-1 input width <= 16 (the CSTR observations), 16-byte aligned rows.
-template <int ACT, int HEAD, int SHAPE>
+template <int ACT, int HEAD, int SHAPE, int ENV>
 __global__ __launch_bounds__(64 * POLICY_WAVES) void rollout_step_kernel(const float *x, const int64_t ldx, const float *w1, const float *b1,
                                                                          const float *w2s, const int m, const int k0, const int h1, const int h2,
                                                                          const PolicyArgs a0, const RolloutArgs ro)
@@ -2000,7 +2002,7 @@ __global__ __launch_bounds__(64 * POLICY_WAVES) void rollout_step_kernel(const f
     // has returned. The same fields of a0 are not read.
     PolicyArgs a = a0;
     a.x = x; a.ldx = ldx; a.w1 = w1; a.b1 = b1; a.w2s = w2s; a.m = m; a.k0 = k0; a.h1 = h1; a.h2 = h2;
-    policy_rows_v2_body<ACT, HEAD, true, true, SHAPE, true>(a, &ro);
+    policy_rows_v2_body<ACT, HEAD, true, true, SHAPE, true, ENV>(a, &ro);
 }
 
 // ---- loss heads (single workgroup; batch <= 16384) -----------------------------------------------------
@@ -2653,7 +2655,12 @@ extern "C" int cstr_rollout_step_f32(const cstr_policy_mlp_t *net, const float *
     const size_t lds2 = policy_v2_lds(n);
     const bool small = (n.h1 + 15) / 16 <= 16 && (n.h2 + 15) / 16 <= 16;
     hipStream_t s = (hipStream_t)stream;
-#define ROL3(A, H, S) rollout_step_kernel<A, H, S><<<grid, 64 * POLICY_WAVES, lds2, s>>>(a.x, a.ldx, a.w1, a.b1, a.w2s, (int)a.m, a.k0, a.h1, a.h2, a, ro)
+#define ROL4(A, H, S, E) rollout_step_kernel<A, H, S, E><<<grid, 64 * POLICY_WAVES, lds2, s>>>(a.x, a.ldx, a.w1, a.b1, a.w2s, (int)a.m, a.k0, a.h1, a.h2, a, ro)
+    // the environment variant as a template constant where a class default runs it (ReLU networks at the exact shapes): the one-train env
+    // with Euler steps (BASELINE configs 2-4) and with the raw state in the observation + RK4 (the north_star-literal variant)
+    const int env_variant = 2 * ro.layout + (integrator == CSTR_INTEGRATOR_RK4 ? 1 : 0);
+#define ROL3(A, H, S) do { if ((A) == 1 && (S) >= 2 && env_variant == 0) ROL4(1, H, (S) >= 2 ? (S) : 2, 0); \
+                           else if ((A) == 1 && (S) == 2 && env_variant == 3) ROL4(1, H, 2, 3); else ROL4(A, H, S, -1); } while (0)
     // CSTR_EXACT_SHAPES=0: run the run-time-width instantiations everywhere (tests compare the two bit for bit)
     static const bool exact = !(getenv("CSTR_EXACT_SHAPES") && atoi(getenv("CSTR_EXACT_SHAPES")) == 0);
 #define ROL2(A, H) do { if (exact && n.h1 == 256 && n.h2 == 256) ROL3(A, H, 2); else if (exact && n.h1 == 400 && n.h2 == 300) ROL3(A, H, 3); \
@@ -2662,6 +2669,7 @@ extern "C" int cstr_rollout_step_f32(const cstr_policy_mlp_t *net, const float *
     else { if (n.act == 0) ROL2(0, 1); else if (n.act == 1) ROL2(1, 1); else ROL2(2, 1); }
 #undef ROL2
 #undef ROL3
+#undef ROL4
     return (int)hipGetLastError();
 }
 
