@@ -1629,14 +1629,12 @@ __device__ __forceinline__ void policy_rows_v2_body(const PolicyArgs &a, const R
     CollectInQ env_q;   // layouts 0, 1: four lanes per env (collect_env_quad)
     int64_t ring_pos = 0;
 
-    // Roles before the first barrier. The CU's vector-memory path is ONE in-order queue that moves ~75 GB/s: layer 2's weights
-    // (256 KB per workgroup at 256 x 256) need ~3.4 us of it, as long as the layer's MFMAs, so the stream has to start at t = 0 and
-    // must not sit in front of layer 1's few small operand loads.
-    //   waves 4-7: request their layer-2 B operand at once -- ALL of it when it fits the register budget (SMALL: h1, h2 <= 256,
-    //              128 registers), else its first pipeline stage; wave 7 then draws the Gaussian noise (Philox + Box-Muller, a
-    //              lane per row, ~1.5 us of dependent VALU work that does not depend on the network).
-    //   waves 0-3: layer 1 first (operand loads at the head of the queue, one k chunk for k0 <= 16: lane (r, h) holds
-    //              x[row r][4h..4h+3] and W1[column tile row r][4h..4h+3]), THEN their own B requests.
+    // Roles before the first barrier (round 3; the round-2 form requested a wave's WHOLE layer-2 operand here, which serialised the
+    // stream and the MFMAs -- see the layer-2 loop below):
+    //   waves 0-3: layer 1 (its operand requests left at the top of the kernel; one k chunk for k0 <= 16: lane (r, h) holds
+    //              x[row r][4h..4h+3] and W1[column tile row r][4h..4h+3]), then the first NB chunks of their layer-2 ring;
+    //   waves 4-7: the first NB chunks of their ring; waves 6-7 then draw the Gaussian noise (Philox + one half of Box-Muller each, a
+    //              lane per row: dependent VALU work that does not depend on the network).
     // Every load is UNCONDITIONAL on a clamped (always valid) address: hipcc scalarises a float4 load under a condition into four
     // branchy dword loads; out-of-range chunks are never fed to an MFMA, out-of-range head lanes are zeroed after the load.
     float4 bq0[NB], bq1[NB], w3q[V2_HEAD_Q];
@@ -1652,17 +1650,13 @@ __device__ __forceinline__ void policy_rows_v2_body(const PolicyArgs &a, const R
     const int lane16 = 16 * lane;
 #define V2_REQUEST_B(FROM, TO) do { _Pragma("unroll") for (int u = (FROM); u < (TO); ++u) { const int c = V2_CHUNK(u); \
         bq0[u] = v2_piece(w2rs, lane16, t0 * kc1 + c); bq1[u] = v2_piece(w2rs, lane16, t1 * kc1 + c); } } while (0)
-    // how many of the NB chunks are requested BEFORE the first barrier: a wave is held while it issues loads (~60 ns per 1 KB wave
-    // load), and everybody waits at the barrier for the last issuer -- the rest follows right after the barrier, before the MFMAs
-    // (waves 0-3, SMALL: none before layer 1 -- A/B on MI355X: 0 / 2 / 4 chunks ahead of layer 1 = 10.60 / 10.61 / 10.73 us)
-    // (round 3: the barriers of this kernel are LDS-only -- see POLICY_BARRIER -- so requests no longer have to be held back for them)
-    // A/B (tools/rollout_ab.py, profiles/r03_rollout_ab.txt): __syncthreads + 12 / 0 ahead 12.93 us; LDS-only barriers 12.81; with all 16
-    // chunks of both wave groups requested ahead of the barrier 12.56 us (bit-identical outputs)
+    // History of this spot (tools/rollout_ab.py, graph-replayed launches): round 2 requested 12 of a wave's 16 chunks per tile ahead of
+    // the first barrier and the rest behind it (12.93 us per launch), LDS-only barriers 12.81, all 16 ahead 12.56; the per-chunk ring
+    // requests NB chunks here and one chunk per 8 MFMAs afterwards (9.4 us with everything else of round 3).
     constexpr int PRE_YOUNG = NB, PRE_OLD = NB;
-    // who draws the Gaussian noise (~1.7 us of dependent VALU work that needs nothing from memory): wave 7, AFTER its weight requests.
-    // With the draw in front of them the requests sat behind everybody else's in the CU's in-order queue and wave 7 left layer 2
-    // ~1 us after the other seven (in-kernel stamps, profiles/r02_rollout_phase_stamps.json); on a layer-1 wave, between requesting
-    // its operands and using them, the draw delayed the first barrier by as much as it saved.
+    // Who draws the Gaussian noise (dependent VALU work that needs nothing from memory but the stream's control words): behind the
+    // wave's ring requests (in front of them the requests queue behind everybody else's); on a layer-1 wave, between requesting its
+    // operands and using them, the draw delayed the first barrier by as much as it saved (round 2).
     // Round 3: TWO waves, each with half of Box-Muller behind its own Philox call (same counters, same words): wave 7 the radius
     // sqrt(-2 log u1), wave 6 cos / sin of the angle; the sampling tail multiplies them (z = r * cos, r * sin: the same single product).
     const bool noise_wave = draw && wave >= WAVES - 2;
