@@ -2588,7 +2588,7 @@ extern "C" int cstr_policy_rows_fwd_f32(const cstr_policy_mlp_t *net, const floa
     const bool vec0 = (n.k0 & 3) == 0 && (ldx & 3) == 0 && aligned16(x) && aligned16(n.w1);
     hipStream_t s = (hipStream_t)stream;
     static const bool force_v1 = getenv("CSTR_POLICY_V1") != nullptr;  // development A/B knob (tools/policy_ab.py)
-    if (n.w2_swizzled && n.h1 <= V2_MAX_WIDTH && n.h2 <= V2_MAX_WIDTH && !force_v1) {
+    if (n.w2_swizzled && n.h1 <= V2_MAX_WIDTH && n.h2 <= V2_MAX_WIDTH && policy_v2_lds(n) <= 64 * 1024 && !force_v1) {
         // the software-pipelined kernel (tile-major W2 required)
         const int kc1 = (n.h1 + 15) / 16, kc2 = (n.h2 + 15) / 16;
         const size_t lds2 = policy_v2_lds(n);
@@ -2634,7 +2634,7 @@ extern "C" int cstr_rollout_step_f32(const cstr_policy_mlp_t *net, const float *
     if (mt_state && (ring->rows >= 0xFFFFFFFFLL || ring->n_envs >= 0xFFFFFFFFLL)) return CSTR_E_UNSUPPORTED;
     // the software-pipelined kernel with a one-chunk first layer: tile-major W2, widths <= 512, k0 <= 16 in 16-byte rows
     const bool vec0 = (n.k0 & 3) == 0 && (ldx & 3) == 0 && aligned16(x) && aligned16(n.w1);
-    if (!n.w2_swizzled || n.h1 > V2_MAX_WIDTH || n.h2 > V2_MAX_WIDTH || n.k0 > 16 || !vec0) return CSTR_E_UNSUPPORTED;
+    if (!n.w2_swizzled || n.h1 > V2_MAX_WIDTH || n.h2 > V2_MAX_WIDTH || n.k0 > 16 || !vec0 || policy_v2_lds(n) > 64 * 1024) return CSTR_E_UNSUPPORTED;
     ro.k = *coef;
     ro.ring_ctl = ring_ctl;
     ro.layout = layout_of(ring->obs_dim, ring->act_dim);

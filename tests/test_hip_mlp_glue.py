@@ -665,6 +665,32 @@ def test_whole_policy_network_in_one_launch(ops, M, K0, H1, H2, A, act):
         hip_ops.policy_rows_fwd(x, w1, b1, w2, b2, w3, b3, act, 0, 0, a1)  # no noise source
 
 
+@pytest.mark.parametrize("M,K0,H1,H2,A,act", [(50, 4, 512, 400, 2, 1), (300, 4, 320, 272, 2, 1), (64, 4, 16, 16, 1, 2), (129, 8, 400, 300, 4, 1),
+                                              (200, 4, 256, 256, 2, 1), (77, 4, 400, 304, 2, 0), (33, 4, 64, 496, 2, 1), (4096, 4, 128, 80, 2, 1)])
+def test_pipelined_policy_kernel_at_many_widths(ops, M, K0, H1, H2, A, act):
+    """The pipelined policy kernel (tile-major weight copy given: layer 2 as a per-chunk register ring, round 3) at widths that exercise
+    every shape of its loops -- one and two tile pairs per wave, a ring that does / does not divide K (the next pair's chunks carried
+    over or requested afresh), partial last tiles and chunks, the exact-shape instantiations -- against the f64 layer-by-layer
+    evaluation and against the first-version kernel (no copy given)."""
+    from core.common import hip_ops
+
+    g = th.Generator(device="cuda").manual_seed(M + H1 + H2)
+    r = lambda *sh: th.randn(*sh, device="cuda", generator=g)  # noqa: E731
+    x = r(M, K0)
+    w1, b1, w2, b2 = r(H1, K0) / K0 ** 0.5, r(H1) * 0.1, r(H2, H1) / H1 ** 0.5, r(H2) * 0.1
+    w3, b3 = r(A, H2) / H2 ** 0.5, r(A) * 0.1
+    f = {0: lambda t: t, 1: th.relu, 2: th.tanh}[act]
+    h2 = f(f(x.double() @ w1.double().t() + b1.double()) @ w2.double().t() + b2.double())
+    ref = th.tanh(h2 @ w3.double().t() + b3.double())
+    tiles = hip_ops.policy_swizzle(w2)
+    out, out_v1 = th.empty(M, A, device="cuda"), th.empty(M, A, device="cuda")
+    hip_ops.policy_rows_fwd(x, w1, b1, w2, b2, w3, b3, act, 1, 2, out, w2_swz=tiles)
+    hip_ops.policy_rows_fwd(x, w1, b1, w2, b2, w3, b3, act, 1, 2, out_v1)
+    th.cuda.synchronize()
+    assert rel_err(out.cpu().numpy(), ref.cpu().numpy(), 1.0) < 1e-5
+    assert rel_err(out.cpu().numpy(), out_v1.cpu().numpy(), 1.0) < 2e-6  # (the two kernels sum the head in different orders)
+
+
 @pytest.mark.parametrize("N,K", [(256, 256), (300, 400), (20, 8), (16, 64)])
 def test_tile_major_weight_copy_and_its_adam_shadow(ops, N, K):
     """cstr_policy_swizzle_f32 against the torch permutation; the policy kernel with the copy is bit-identical to the one
