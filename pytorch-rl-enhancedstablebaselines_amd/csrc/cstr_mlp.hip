@@ -528,6 +528,13 @@ __global__ __launch_bounds__(64 * WAVES) void linear_bwd_input_kernel(const floa
 // ADAM: the workgroup that has reduced a tile of dW (and db) also applies the optimiser step to exactly those parameters
 // (cstr_linear_bwd_weight_adam_sets_f32): parameter and moment quads are requested at entry, thread 0 turns the (pre-advanced)
 // control words into the step's scalars beside the reduction, the tile's first wave updates p / m / v after the split-M combine.
+#ifdef CSTR_POLICY_STAMPS  // diagnostic build only: phase stamps of the dW + Adam tile in the policy kernel's stamp buffer (tools/wa_stamps.py)
+extern __device__ unsigned long long policy_stamps[4096 * 16 * 8];
+#define WA_STAMP(i) do { if (ADAM && lane == 0 && blockIdx.x < 4096) policy_stamps[(blockIdx.x * 16 + wave) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define WA_STAMP(i) do { } while (0)
+#endif
+
 struct AdamTile {
     float *w, *w_m, *w_v, *b, *b_m, *b_v, *shadow;
     const int64_t *adam_ctl; const double *lr; double beta1, beta2, eps; float gscale;
@@ -547,9 +554,16 @@ __device__ __forceinline__ void linear_bwd_weight_tile(const float *__restrict__
     const int k0 = tile_k * 16, n0 = tile_n * 16;
     const bool n_ok = n0 + r < N, k_ok = k0 + r < K;
     const bool want_db = db != nullptr && tile_k == 0;
+    WA_STAMP(0);
     float pw[4] = {0.0f, 0.0f, 0.0f, 0.0f}, pm[4] = {0.0f, 0.0f, 0.0f, 0.0f}, pv[4] = {0.0f, 0.0f, 0.0f, 0.0f}, bw = 0.0f, bm = 0.0f, bvv = 0.0f;
     float pt[4] = {0.0f, 0.0f, 0.0f, 0.0f}, bt = 0.0f;  // the parameters' own target (soft update in the same pass)
-    if (ADAM) {
+    // The optimiser's operands (wave 0: parameter, moments, own target of the tile's 256 elements; the last wave: the step's scalars)
+    // are requested BEHIND the wave's first batch of dz / x rows, not in front of it: their addresses come out of a chain of
+    // argument reads (~1,300 cycles on wave 0, in-kernel stamps tools/wa_stamps.py) that used to delay wave 0's row requests -- and with
+    // them the split-M barrier -- by as much; they are not needed before that barrier.
+    bool adam_requested = false;
+    auto adam_request = [&]() {
+        adam_requested = true;
         if (wave == 0 && k_ok) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -567,7 +581,8 @@ __device__ __forceinline__ void linear_bwd_weight_tile(const float *__restrict__
             if (ad->b_target) bt = ad->b_target[n0 + lane];
         }
         if (threadIdx.x == 64 * (WAVES - 1)) adam_sc = adam_scalars_advanced(ad->adam_ctl, ad->lr, ad->beta1, ad->beta2, ad->eps, ad->gscale);
-    }
+    };
+    WA_STAMP(1);
     f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
     float colsum = 0.0f;
     constexpr int UNROLL = 4;
@@ -602,6 +617,7 @@ __device__ __forceinline__ void linear_bwd_weight_tile(const float *__restrict__
             b[u].z = (k_ok && m + 2 < M) ? xr[2 * (int64_t)ldx] : 0.0f;
             b[u].w = (k_ok && m + 3 < M) ? xr[3 * (int64_t)ldx] : 0.0f;
         }
+        if (ADAM && !adam_requested) adam_request();
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
             acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].x, b[u].x, acc0, 0, 0, 0);
@@ -611,11 +627,14 @@ __device__ __forceinline__ void linear_bwd_weight_tile(const float *__restrict__
             colsum += (a[u].x + a[u].y) + (a[u].z + a[u].w);
         }
     }
+    if (ADAM && !adam_requested) adam_request();  // (a wave without rows: M <= 16 * wave)
     if (want_db) colpart[wave][lane] = colsum;
     f32x4 acc = acc0 + acc1;
+    WA_STAMP(2);
     if (WAVES > 1) {
         if (wave > 0) part[wave - 1][lane] = acc;
         __syncthreads();
+        WA_STAMP(3);
         if (wave > 0) return;
 #pragma unroll
         for (int v = 0; v < WAVES - 1; ++v) acc += part[v][lane];
@@ -630,6 +649,7 @@ __device__ __forceinline__ void linear_bwd_weight_tile(const float *__restrict__
             if (n0 + 4 * h + e < N) out[(int64_t)e * K] = acc[e];
         if (ADAM) {
             const AdamScalars a = adam_sc;
+            WA_STAMP(4);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int row = n0 + 4 * h + e, colk = k0 + r;
@@ -655,6 +675,7 @@ __device__ __forceinline__ void linear_bwd_weight_tile(const float *__restrict__
             if (ad->b_target) ad->b_target[n0 + lane] = polyak1(bw, bt, ad->tau, 1.0f - ad->tau);
         }
     }
+    WA_STAMP(5);
 }
 
 template <int WAVES, bool BUF>
