@@ -33,8 +33,9 @@ USE_WGRAD_ADAM = os.environ.get("CSTR_WGRAD_ADAM", "1") != "0"
 TILES = tuple(int(v) for v in os.environ.get("CSTR_CHAIN_TILES", "2,2,2,2,1").split(","))
 
 
-# TD3's class-default nets are [400, 300]; A/B on MI355X (bench --algo td3): 2,2,2,2,1 0.0888 ms, 2,4,2,2,1 0.0916, 4,4,2,2,1 0.0936
-TD3_TILES = tuple(int(v) for v in os.environ.get("CSTR_CHAIN_TILES_TD3", "2,2,2,2,1").split(","))
+# TD3's class-default nets are [400, 300]; A/B on MI355X (bench --algo td3, exact-width kernels, profiles/r03_chain_tiles_sweep_td3.txt):
+# 2,2,2,2,2 0.0705 ms, 2,2,2,2,1 0.0712, 2,4,2,2,1 0.0781, one column group everywhere 0.1037
+TD3_TILES = tuple(int(v) for v in os.environ.get("CSTR_CHAIN_TILES_TD3", "2,2,2,2,2").split(","))
 
 
 def _q_layers(qnet: nn.Sequential):
