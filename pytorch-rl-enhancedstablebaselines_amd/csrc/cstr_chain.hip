@@ -241,8 +241,31 @@ __device__ __forceinline__ void sample_action(const float mu, const float raw, c
 // Inputs whose rows are whole 16-byte quads (obs 4, obs 8, obs 8 + act 4 = 12) need no staging at all: the B operand quads come
 // straight from W1 in L2 and the bias is added in the tile's epilogue (l1_pad() == 0: no LDS image -- 25 KB less per workgroup at
 // H1 = 400, i.e. twice as many workgroups per CU).
+// Round 3: rows of an EVEN number of inputs that is not a multiple of 4 (obs 4 + act 2 = 6: every critic of SAC / TD3; 10) are read
+// straight from W1 as well, as 8-byte pairs, with b1 in the k slot behind the last input exactly as the staged image had it (same MFMA
+// operands, same bits): no staging pass through LDS in the prologue (global load -> LDS store -> barrier -> LDS load), no LDS image.
 template <int KIN>
-constexpr int l1_pad() { return KIN % 4 == 0 ? 0 : (KIN + 1 <= 8 ? 8 : 16); }
+constexpr int l1_pad() { return (KIN % 2 == 0 && KIN + 1 <= 16) ? 0 : (KIN + 1 <= 8 ? 8 : 16); }
+template <int KIN>
+constexpr bool l1_bias_in_k() { return KIN % 4 != 0; }  // the bias rides in the k chain (column KIN of the chunk; x holds 1.0 there)
+
+// lane (r, h)'s quad k = 4h .. 4h + 3 of W1 row n for the direct form, and the bias the tile's epilogue adds (0 when it rides in k)
+template <int KIN>
+__device__ __forceinline__ float4 l1_direct_quad(const float *w1, const float *b1, const int n, const int h, float &bias)
+{
+    if (KIN % 4 == 0) {
+        bias = b1[n];
+        return 4 * h < KIN ? *reinterpret_cast<const float4 *>(w1 + (int64_t)n * KIN + 4 * h) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+    bias = 0.0f;
+    const int k0 = 4 * h;
+    float2 lo = make_float2(0.0f, 0.0f), hi = lo;
+    if (k0 + 1 < KIN) lo = *reinterpret_cast<const float2 *>(w1 + (int64_t)n * KIN + k0);
+    else if (k0 == KIN) lo = make_float2(b1[n], 0.0f);
+    if (k0 + 3 < KIN) hi = *reinterpret_cast<const float2 *>(w1 + (int64_t)n * KIN + k0 + 2);
+    else if (k0 + 2 == KIN) hi = make_float2(b1[n], 0.0f);
+    return make_float4(lo.x, lo.y, hi.x, hi.y);
+}
 
 template <int KIN>
 __device__ __forceinline__ void stage_w1(float *w1s, const float *w1, const float *b1, const int h1)
@@ -268,11 +291,7 @@ struct L1Direct {
     {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, h = lane >> 4;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int n = min(16 * (wave + CH_WAVES * i) + r, h1 - 1);
-            wb[i] = 4 * h < KIN ? *reinterpret_cast<const float4 *>(w1 + (int64_t)n * KIN + 4 * h) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            bias[i] = b1[n];
-        }
+        for (int i = 0; i < 4; ++i) wb[i] = l1_direct_quad<KIN>(w1, b1, min(16 * (wave + CH_WAVES * i) + r, h1 - 1), h, bias[i]);
     }
 };
 
@@ -281,7 +300,7 @@ __device__ __forceinline__ void layer1_mfma(const float *xs, const float *w1s, f
                                             const L1Direct<KIN> *dir = nullptr, const float *w1 = nullptr, const float *b1 = nullptr)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, h = lane >> 4;
-    const bool hk = KP == 0 ? 4 * h < KIN : 4 * h < KP;  // this lane's quad of the k chunk exists
+    const bool hk = KP == 0 ? 4 * h < KIN + (l1_bias_in_k<KIN>() ? 1 : 0) : 4 * h < KP;  // this lane's quad of the k chunk exists
     const float4 zero4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     const float4 xa = hk ? *reinterpret_cast<const float4 *>(xs + r * 16 + 4 * h) : zero4;
     const int n_tiles = (h1 + 15) / 16;
@@ -292,11 +311,7 @@ __device__ __forceinline__ void layer1_mfma(const float *xs, const float *w1s, f
         for (int i = 0; i < 4; ++i) {
             if (KP == 0) {  // direct: requested at entry (first group) or here (wider layers)
                 if (t0 == wave) { wb[i] = dir->wb[i]; bb[i] = dir->bias[i]; }
-                else {
-                    const int n = min(16 * (t0 + CH_WAVES * i) + r, h1 - 1);
-                    wb[i] = hk ? *reinterpret_cast<const float4 *>(w1 + (int64_t)n * KIN + 4 * h) : zero4;
-                    bb[i] = b1[n];
-                }
+                else wb[i] = l1_direct_quad<KIN>(w1, b1, min(16 * (t0 + CH_WAVES * i) + r, h1 - 1), h, bb[i]);
             } else {
                 wb[i] = hk ? *reinterpret_cast<const float4 *>(w1s + min(16 * (t0 + CH_WAVES * i) + r, h1 - 1) * KP + 4 * h) : zero4;
             }
@@ -1170,7 +1185,7 @@ extern "C" int cstr_q_chain_fwd_f32(const cstr_chain_net_t *nets, int n_nets, in
     }
     a.n_nets = n_nets; a.h1 = h1; a.h2 = h2; a.batch = (int)batch; a.tiles = tiles;
     const dim3 grid((unsigned)((h2 + 16 * tiles - 1) / (16 * tiles)), (unsigned)(batch / 16), (unsigned)n_nets);
-    const size_t lds = chain_lds_bytes(h1, w_in % 4 == 0 ? 0 : (w_in + 1 <= 8 ? 8 : 16));
+    const size_t lds = chain_lds_bytes(h1, (w_in % 2 == 0 && w_in + 1 <= 16) ? 0 : (w_in + 1 <= 8 ? 8 : 16));  // l1_pad<w_in>()
     const int nq = nq_for(h1, tiles, 32), lay = chain_layout(obs_dim, w_in - obs_dim);
     if (!nq || lay < 0 || lds > CHAIN_LDS_LIMIT) return CSTR_E_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
