@@ -1662,14 +1662,9 @@ __device__ __forceinline__ void policy_rows_v2_body(const PolicyArgs &a, const R
     float b2q0, b2q1;
     const int wave_s = __builtin_amdgcn_readfirstlane(wave);  // the wave index as a SCALAR (piece offsets of the buffer loads)
     const int t0 = min(wave_s, kc2 - 1), t1 = min(wave_s + WAVES, kc2 - 1);
-#ifdef CSTR_DIAG_ROT  // diagnostic only (wrong results): do the waves' simultaneous requests collide in the L2's channels?
-#define V2_CHUNK(u) (((u) + CSTR_DIAG_ROT * wave + (int)(blockIdx.x >> 3)) & 15)
-#else
-#define V2_CHUNK(u) min((u), kc1 - 1)
-#endif
     const __amdgpu_buffer_rsrc_t w2rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.w2s), 0, kc2 * kc1 * 1024, 0x00020000);
     const int lane16 = 16 * lane;
-#define V2_REQUEST_B(FROM, TO) do { _Pragma("unroll") for (int u = (FROM); u < (TO); ++u) { const int c = V2_CHUNK(u); \
+#define V2_REQUEST_B(FROM, TO) do { _Pragma("unroll") for (int u = (FROM); u < (TO); ++u) { const int c = min(u, kc1 - 1); \
         bq0[u] = v2_piece(w2rs, lane16, t0 * kc1 + c); bq1[u] = v2_piece(w2rs, lane16, t1 * kc1 + c); } } while (0)
     // History of this spot (tools/rollout_ab.py, graph-replayed launches): round 2 requested 12 of a wave's 16 chunks per tile ahead of
     // the first barrier and the rest behind it (12.93 us per launch), LDS-only barriers 12.81, all 16 ahead 12.56; the per-chunk ring
@@ -1688,11 +1683,7 @@ __device__ __forceinline__ void policy_rows_v2_body(const PolicyArgs &a, const R
         const uint64_t seed = a.rng_ctl[0], base = a.rng_ctl[1];
         const int64_t row = m0 + lane;
         if (lane < POLICY_ROWS && row < a.m) {
-#ifdef CSTR_DIAG_NO_NOISE  // diagnostic only: what the launch costs without the draw on wave 7
-            for (int j0 = 0; j0 < 0; j0 += 2) {
-#else
             for (int j0 = 0; j0 < a.act_dim; j0 += 2) {
-#endif
                 const uint64_t ctr = base + (uint64_t)row;
                 uint32_t rnd[4];
                 philox4x32_10((uint32_t)ctr, (uint32_t)(ctr >> 32), (uint32_t)(j0 >> 1), 0u, (uint32_t)seed, (uint32_t)(seed >> 32), rnd);
@@ -1819,9 +1810,6 @@ __device__ __forceinline__ void policy_rows_v2_body(const PolicyArgs &a, const R
                 }
             }
             f32x4 c00 = {0.0f, 0.0f, 0.0f, 0.0f}, c01 = c00, c10 = c00, c11 = c00;
-#ifdef CSTR_STAMP_VM0  // diagnostic: when has this wave's ring landed?
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
             if (t == wave_s) V2_STAMP2(0);
             float4 a_cur = *reinterpret_cast<const float4 *>(ar);  // the A operand (layer 1's activations, LDS) runs one chunk ahead
             auto walk = [&](auto second_c) {
